@@ -1,0 +1,160 @@
+/*
+ * scannertools_hip.h -- C ABI of libscannertools_hip.so: the MI355X (gfx950) implementation of
+ * the arithmetic behind scannertools' Histogram and OpticalFlow ops.
+ *
+ * This is the boundary between host code (the Scanner kernels in
+ * the scannertools_amd/scanner_kernels sources, the Python front-end, bench.py) and the HIP
+ * kernels.  Plain pointers and sizes only; no C++ or torch types.  Every entry point
+ *   - returns an int status (ST_OK == 0), never throws, never aborts;
+ *   - selects the context's device on entry (Scanner calls kernel instances from their own
+ *     evaluator threads; cf. set_device() at the top of every method in
+ *     scannertools_cpp/imgproc/histogram_kernel_gpu.cpp:21,35 and
+ *     optical_flow_kernel_gpu.cpp:18,29,37,41,47);
+ *   - never allocates outputs: the caller passes device buffers it owns (Scanner allocates
+ *     them with new_block_buffer / new_frames, histogram_kernel_gpu.cpp:38-39,
+ *     optical_flow_kernel_gpu.cpp:61-64);
+ *   - enqueues work on the context's stream and returns without synchronising, unless
+ *     documented otherwise; call st_ctx_sync() before reading results on the host;
+ *   - is re-entrant across contexts (one context per kernel instance / thread).
+ *
+ * "frames_dev" arguments are HOST arrays of DEVICE pointers (one Scanner element buffer per
+ * frame); frames are dense interleaved U8 (h, w, 3), RGB order, no row padding -- the layout
+ * frame_to_mat()/frame_to_gpu_mat() view in the reference.
+ */
+#ifndef SCANNERTOOLS_HIP_H_
+#define SCANNERTOOLS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_ABI_VERSION 1
+
+enum st_status {
+  ST_OK = 0,
+  ST_ERR_INVALID = 1,     /* bad argument (null pointer, non-positive size, bins out of range ...) */
+  ST_ERR_HIP = 2,         /* a HIP runtime call failed; see st_ctx_last_error() */
+  ST_ERR_OOM = 3,         /* workspace allocation failed */
+  ST_ERR_UNSUPPORTED = 4  /* parameter combination the HIP path does not implement */
+};
+
+typedef struct st_ctx st_ctx;
+
+int st_abi_version(void);
+const char* st_status_string(int status);
+int st_device_count(int* count);
+
+/* Per-kernel-instance context: owns a stream and lazily-sized scratch (pyramids, polynomial
+ * expansions, matrices).  Replaces the per-instance state of the reference GPU wrappers
+ * (streams_, planes_, flow_finders_, grayscale_; histogram_kernel_gpu.cpp:71-75,
+ * optical_flow_kernel_gpu.cpp:101-107). */
+int st_ctx_create(int device_id, st_ctx** out_ctx);
+int st_ctx_destroy(st_ctx* ctx);
+/* Borrow an external hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+int st_ctx_set_stream(st_ctx* ctx, void* hip_stream);
+int st_ctx_sync(st_ctx* ctx);
+/* Cap on scratch the context may hold (bytes; 0 = default 24 GiB).  Large pair batches are
+ * processed in passes that fit. */
+int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes);
+int st_ctx_release_workspace(st_ctx* ctx);
+const char* st_ctx_last_error(const st_ctx* ctx);
+
+/* ---- per-kernel timing (HIP events on the context's stream) --------------------------------
+ * When enabled, every launch of the named kernel class is bracketed by hipEventRecord pairs;
+ * st_ctx_timing_read() synchronises the stream and returns launches and total milliseconds
+ * since the last reset.  Used by bench.py for the live roofline figure. */
+enum st_kernel_id {
+  ST_K_HIST = 0,
+  ST_K_GRAY = 1,
+  ST_K_PYR = 2,
+  ST_K_POLYEXP = 3,
+  ST_K_UPDATE_MATRICES = 4,
+  ST_K_BLUR_UPDATE = 5, /* box blur + 2x2 solve (+ fused UpdateMatrices): the dominant kernel */
+  ST_K_COUNT = 6
+};
+int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
+int st_ctx_timing_reset(st_ctx* ctx);
+int st_ctx_timing_read(st_ctx* ctx, int kernel_id, int* launches, double* total_ms);
+
+/* ---- Histogram -----------------------------------------------------------------------------
+ * Replaces HistogramKernelCPU::execute's per-frame body
+ * (scannertools_cpp/imgproc/histogram_kernel_cpu.cpp:25-45: cv::calcHist x3 + convertTo(CV_32S))
+ * and the GPU wrapper's cvc::split + cvc::histEven x3 (histogram_kernel_gpu.cpp:48-57) for a
+ * whole batch in one call.
+ * out_dev: n * 3 * bins int32, frame-major then channel-major (R,G,B) -- element i is the
+ * 3*bins*4-byte block the reference hands to insert_element() (histogram_kernel_cpu.cpp:44).
+ * bins in [1, 256]; bin(v) = floor(v * bins / 256) (cv::calcHist uniform 8U table); the
+ * reference's value is 16 (histogram_kernel_cpu.cpp:8). */
+int st_hist_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w,
+                       int bins, int32_t* out_dev);
+/* Same, frames at base_dev + i * frame_stride_bytes (a contiguous device-resident stream). */
+int st_hist_u8c3_strided(st_ctx* ctx, const uint8_t* base_dev, size_t frame_stride_bytes, int n,
+                         int h, int w, int bins, int32_t* out_dev);
+
+/* ---- OpticalFlow ---------------------------------------------------------------------------
+ * Parameters of cv::FarnebackOpticalFlow::create(numLevels, pyrScale, fastPyramids, winSize,
+ * numIters, polyN, polySigma, flags); st_fb_params_default() gives the reference's
+ * (3, 0.5, false, 15, 3, 5, 1.2, 0) (optical_flow_kernel_cpu.cpp:15-16).  Implemented:
+ * flags == 0 (box filter, no initial flow), fast_pyramids == 0, poly_n in {5, 7},
+ * odd win_size <= 63.  gray_bits selects cv::cvtColor's 8-bit luma table: 15 (OpenCV 4.x)
+ * or 14 (OpenCV <= 3.4.2). */
+typedef struct st_fb_params {
+  int num_levels;
+  double pyr_scale;
+  int fast_pyramids;
+  int win_size;
+  int num_iters;
+  int poly_n;
+  double poly_sigma;
+  int flags;
+  int gray_bits;
+} st_fb_params;
+void st_fb_params_default(st_fb_params* p);
+
+/* Replaces OpticalFlowKernelCPU::execute (optical_flow_kernel_cpu.cpp:27-43: cvtColor
+ * BGR2GRAY x2 + FarnebackOpticalFlow::calc) for a batch of stencil windows, and the
+ * calling convention of OpticalFlowKernelGPU::execute (optical_flow_kernel_gpu.cpp:45-93).
+ * pairs: HOST array of n_pairs x 2 indices into frames_dev; flow p goes FROM frame
+ * pairs[2p] TO frame pairs[2p+1] (CPU-kernel direction: stencil element 0 -> element 1;
+ * the reference GPU wrapper's reversed direction is a defect and is not reproduced).
+ * Pairs need not be consecutive; each distinct frame's pyramid and polynomial expansion is
+ * computed once per call.  flow_out_dev: HOST array of n_pairs DEVICE pointers, each a dense
+ * (h, w, 2) F32 frame (u, v interleaved) as allocated by new_frames(device, FrameInfo(h, w, 2,
+ * F32), n) (optical_flow_kernel_gpu.cpp:61-64). */
+int st_farneback_pairs(st_ctx* ctx, const uint8_t* const* frames_dev, int n_frames,
+                       const int32_t* pairs, int n_pairs, int h, int w, const st_fb_params* params,
+                       float* const* flow_out_dev);
+
+/* Number of pyramid levels processed minus one (k runs levels..0) and per-level geometry, as
+ * FarnebackOpticalFlowImpl::calc derives them. */
+int st_fb_levels(int h, int w, const st_fb_params* params);
+int st_fb_level_geom(int h, int w, const st_fb_params* params, int level, int* lh, int* lw,
+                     double* sigma, int* ksize);
+
+/* ---- stage-level entry points (parity tests drive each Farneback stage separately) ---------
+ * All arrays are dense device arrays.  Planar fields are (5, h, w) F32 (channel c at
+ * base + c*h*w); flow fields are (h, w, 2) F32 interleaved. */
+int st_gray_u8(st_ctx* ctx, const uint8_t* rgb_dev, int h, int w, int gray_bits, uint8_t* gray_dev);
+int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w, const st_fb_params* params,
+                    int level, float* img_dev /* (lh, lw) */);
+int st_fb_polyexp(st_ctx* ctx, const float* img_dev, int h, int w, int poly_n, double poly_sigma,
+                  float* r_dev /* (5,h,w) */);
+/* M = UpdateMatrices(R0, R1, flow).  If coarse_flow_dev != NULL the flow is first produced as
+ * resize(coarse_flow (ch, cw, 2) -> (h, w), INTER_LINEAR) * (1/pyr_scale) (the level
+ * transition of calc()); else flow_dev (h, w, 2) is used; if both are NULL the flow is zero. */
+int st_fb_update_matrices(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* flow_dev,
+                          const float* coarse_flow_dev, int ch, int cw, double pyr_scale, int h, int w,
+                          float* m_dev /* (5,h,w) */);
+/* One FarnebackUpdateFlow_Blur pass: flow_out = solve(box(M)); if update != 0 additionally
+ * m_out = UpdateMatrices(R0, R1, flow_out).  m_out must not alias m_in. */
+int st_fb_update_flow_blur(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* m_in_dev,
+                           int h, int w, int block_size, int update, float* flow_out_dev,
+                           float* m_out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANNERTOOLS_HIP_H_ */

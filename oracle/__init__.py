@@ -1,0 +1,208 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this package, and only as the checker / CPU baseline.  Nothing under
+``scannertools_amd/`` imports it: the product path fails loudly when its HIP library is
+missing instead of falling back to this code.
+
+``oracle.c`` restates the OpenCV algorithms the reference ops call (see its header for the
+reference call sites and the parity status: Histogram pinned by definition, OpticalFlow
+PARITY UNPINNED against real OpenCV output); ``shot_boundaries`` restates
+``/root/reference/scannertools/scannertools/shot_detection.py:11-28`` and is pinned by the
+fixtures under ``tests/golden/`` that were produced by importing that file.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FbParams(ctypes.Structure):
+    """Mirror of ``orc_fb_params``; defaults = the reference's
+    ``FarnebackOpticalFlow::create(3, 0.5, false, 15, 3, 5, 1.2, 0)``
+    (scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:16)."""
+    _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double),
+                ("fast_pyramids", ctypes.c_int), ("win_size", ctypes.c_int),
+                ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int),
+                ("poly_sigma", ctypes.c_double), ("flags", ctypes.c_int),
+                ("gray_bits", ctypes.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_fb_levels.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def default_params(**kw):
+    p = FbParams()
+    lib().orc_fb_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def hist_u8c3(frame, bins=16):
+    """(h,w,3) uint8 -> (3,bins) int32 (A0/A1)."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, c = frame.shape
+    assert c == 3
+    out = np.empty((3, bins), np.int32)
+    lib().orc_hist_u8c3(_p(frame), h, w, bins, _p(out))
+    return out
+
+
+def gray_u8(frame, bits=15):
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, _ = frame.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_gray_u8(_p(frame), h, w, bits, _p(out))
+    return out
+
+
+def gaussian_kernel(n, sigma):
+    k = np.empty(n, np.float32)
+    lib().orc_gaussian_kernel(n, ctypes.c_double(sigma), _p(k))
+    return k
+
+
+def gaussian_blur(img, ks, sigma):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.empty_like(img)
+    lib().orc_gaussian_blur_f32(_p(img), img.shape[0], img.shape[1], ks, ctypes.c_double(sigma), _p(out))
+    return out
+
+
+def resize_linear(img, dh, dw):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.float32)
+    lib().orc_resize_linear_f32(_p(img), img.shape[0], img.shape[1], cn, _p(out), dh, dw)
+    return out
+
+
+def poly_prepare(n=5, sigma=1.2):
+    buf = np.zeros((3, 2 * n + 1), np.float32)
+    ig = np.zeros(4, np.float64)
+    base = buf.ctypes.data
+    sz = 4
+    g = ctypes.c_void_p(base + n * sz)
+    xg = ctypes.c_void_p(base + (2 * n + 1 + n) * sz)
+    xxg = ctypes.c_void_p(base + (2 * (2 * n + 1) + n) * sz)
+    lib().orc_poly_prepare(n, ctypes.c_double(sigma), g, xg, xxg, _p(ig))
+    return buf, ig
+
+
+def polyexp(I, n=5, sigma=1.2):
+    I = np.ascontiguousarray(I, dtype=np.float32)
+    h, w = I.shape
+    R = np.empty((h, w, 5), np.float32)
+    lib().orc_polyexp(_p(I), h, w, n, ctypes.c_double(sigma), _p(R))
+    return R
+
+
+def update_matrices(R0, R1, flow):
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w, _ = R0.shape
+    M = np.empty((h, w, 5), np.float32)
+    lib().orc_update_matrices(_p(R0), _p(R1), _p(flow), _p(M), h, w, 0, h)
+    return M
+
+
+def update_flow_blur(R0, R1, M, block_size=15, update=True):
+    """Returns (flow, M') -- M' is M updated in place when ``update``."""
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    M = np.array(M, np.float32, copy=True, order="C")
+    h, w, _ = R0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    lib().orc_update_flow_blur(_p(R0), _p(R1), _p(flow), _p(M), h, w, block_size, int(bool(update)))
+    return flow, M
+
+
+def fb_levels(h, w, params=None):
+    p = params or default_params()
+    return lib().orc_fb_levels(h, w, ctypes.byref(p))
+
+
+def fb_level_geom(h, w, k, params=None):
+    p = params or default_params()
+    lh, lw, ks = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    sg = ctypes.c_double()
+    lib().orc_fb_level_geom(h, w, ctypes.byref(p), k, ctypes.byref(lh), ctypes.byref(lw),
+                            ctypes.byref(sg), ctypes.byref(ks))
+    return lh.value, lw.value, sg.value, ks.value
+
+
+def fb_pyr_image(gray, k, params=None):
+    p = params or default_params()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    lh, lw, _, _ = fb_level_geom(h, w, k, p)
+    out = np.empty((lh, lw), np.float32)
+    lib().orc_fb_pyr_image(_p(gray), h, w, ctypes.byref(p), k, _p(out))
+    return out
+
+
+def farneback(prev_gray, next_gray, params=None):
+    p = params or default_params()
+    a = np.ascontiguousarray(prev_gray, np.uint8)
+    b = np.ascontiguousarray(next_gray, np.uint8)
+    h, w = a.shape
+    flow = np.empty((h, w, 2), np.float32)
+    lib().orc_farneback(_p(a), _p(b), h, w, ctypes.byref(p), _p(flow))
+    return flow
+
+
+def optical_flow_rgb(frame0, frame1, params=None):
+    """The OpticalFlow op on two RGB frames: stencil element 0 -> element 1."""
+    p = params or default_params()
+    a = np.ascontiguousarray(frame0, np.uint8)
+    b = np.ascontiguousarray(frame1, np.uint8)
+    h, w, _ = a.shape
+    flow = np.empty((h, w, 2), np.float32)
+    lib().orc_optical_flow_rgb(_p(a), _p(b), h, w, ctypes.byref(p), _p(flow))
+    return flow
+
+
+WINDOW_SIZE = 500  # shot_detection.py:7
+
+
+def shot_boundaries(histograms):
+    """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
+    each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices
+    (row 0 of the reference's output; rows 1.. are None there)."""
+    h = np.asarray(histograms)
+    n = len(h)
+    if n == 0:
+        return []
+    hh = h.astype(np.float64)  # scipy chebyshev validates to double before max|u-v|
+    diffs = np.array([np.mean([np.max(np.abs(hh[i - 1][j] - hh[i][j])) for j in range(3)])
+                      for i in range(1, n)])
+    diffs = np.insert(diffs, 0, 0)
+    out = []
+    for i in range(1, n):
+        win = diffs[max(i - WINDOW_SIZE, 0):min(i + WINDOW_SIZE, n)]
+        if diffs[i] - np.mean(win) > 2.5 * np.std(win):
+            out.append(i)
+    return out

@@ -1,0 +1,553 @@
+/*
+ * oracle.c -- CPU restatement of the arithmetic behind scannertools' Histogram and
+ * OpticalFlow ops.  TEST INFRASTRUCTURE ONLY: nothing under scannertools_amd/ may
+ * include, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / CPU baseline.
+ *
+ * What it restates
+ * ----------------
+ * The reference ops are thin wrappers over OpenCV (un-vendored, un-pinned: "OpenCV >= 3.4.0",
+ * /root/reference/scannertools/README.md:10; the code is OpenCV-3.4/4.x era):
+ *   Histogram   scannertools_cpp/imgproc/histogram_kernel_cpu.cpp:33-42
+ *               cv::calcHist(8U, 1 channel, BINS uniform bins on [0,256)) x3 + convertTo(CV_32S)
+ *   OpticalFlow scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:15-16,36-41
+ *               cv::cvtColor(COLOR_BGR2GRAY) x2 (applied to RGB data: reference quirk) and
+ *               cv::FarnebackOpticalFlow::create(3, 0.5, false, 15, 3, 5, 1.2, 0)->calc(g0, g1, flow)
+ * OpenCV is not present in /root/reference nor in the build container, so each function
+ * below restates the published OpenCV algorithm (modules/imgproc/src/{histogram,color_rgb,
+ * smooth,filter,resize}.*, modules/video/src/optflowgf.cpp), keeping its operand order,
+ * accumulator types (float vs double), border rules and rounding, and is anchored on the
+ * reference call sites above.  Compile with -ffp-contract=off so that float expressions
+ * are evaluated exactly as written (scalar, non-FMA OpenCV build).
+ *
+ * PARITY STATUS
+ *   Histogram : pinned by definition (integer; bin = floor(v*bins/256)), cross-checked
+ *               against numpy.bincount in tests/.
+ *   OpticalFlow: PARITY UNPINNED against real OpenCV output -- the reference's own tests
+ *               only assert dtype/shape (scannertools/tests/test_all.py:162-177) and no
+ *               OpenCV build exists here to emit golden vectors.  The oracle is pinned
+ *               only by analytic known-answer tests (polynomial expansion of exact
+ *               quadratics, recovered integer translations, zero-flow identities).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+/* cvRound: round half to even (SSE cvtsd2si / lrint under the default rounding mode). */
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline int cv_floor_f(float v) { return (int)floorf(v); }
+
+/* ------------------------------------------------------------------------------------------
+ * A1  cv::calcHist, 8U uniform path (call site histogram_kernel_cpu.cpp:36-39).
+ * One channel j of an interleaved (h,w,3) U8 frame; tab[v] = floor(v * bins/256).
+ * out: 3*bins int32, channel-major (histogram_kernel_cpu.cpp:40-41 writes channel j at
+ * output_buf + j*BINS*sizeof(int)).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_hist_u8c3(const uint8_t* frame, int h, int w, int bins, int32_t* out) {
+  int tab[256];
+  double a = (double)bins / 256.0;
+  for (int v = 0; v < 256; ++v) tab[v] = (int)floor(v * a);
+  memset(out, 0, sizeof(int32_t) * 3 * (size_t)bins);
+  size_t n = (size_t)h * w;
+  for (size_t i = 0; i < n; ++i) {
+    out[0 * bins + tab[frame[3 * i + 0]]]++;
+    out[1 * bins + tab[frame[3 * i + 1]]]++;
+    out[2 * bins + tab[frame[3 * i + 2]]]++;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A2  cv::cvtColor(COLOR_BGR2GRAY), 8-bit (call sites optical_flow_kernel_cpu.cpp:38-39).
+ * blueIdx = 0: byte 0 gets the B weight, byte 2 the R weight.  The reference feeds RGB
+ * frames, so byte 0 is really R: gray = 0.114 R + 0.587 G + 0.299 B.  Keep the quirk.
+ * bits = 15 (OpenCV 4.x / late 3.4: 3735, 19235, 9798) or 14 (older: 1868, 9617, 4899).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_gray_u8(const uint8_t* src3, int h, int w, int bits, uint8_t* gray) {
+  int cb, cg, cr;
+  if (bits == 14) { cb = 1868; cg = 9617; cr = 4899; } else { bits = 15; cb = 3735; cg = 19235; cr = 9798; }
+  int rnd = 1 << (bits - 1);
+  size_t n = (size_t)h * w;
+  for (size_t i = 0; i < n; ++i)
+    gray[i] = (uint8_t)((src3[3 * i] * cb + src3[3 * i + 1] * cg + src3[3 * i + 2] * cr + rnd) >> bits);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv::getGaussianKernel(n, sigma, CV_32F): fixed table for n=3, sigma<=0; else exp() in
+ * double, stored to float, normalised by the double sum of the floats.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_gaussian_kernel(int n, double sigma, float* k) {
+  if (n == 3 && sigma <= 0) { k[0] = 0.25f; k[1] = 0.5f; k[2] = 0.25f; return; }
+  if (n == 1 && sigma <= 0) { k[0] = 1.f; return; }
+  if (n == 5 && sigma <= 0) { k[0] = 0.0625f; k[1] = 0.25f; k[2] = 0.375f; k[3] = 0.25f; k[4] = 0.0625f; return; }
+  if (n == 7 && sigma <= 0) {
+    static const float t[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    memcpy(k, t, sizeof(t)); return;
+  }
+  double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  double scale2x = -0.5 / (sx * sx);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = i - (n - 1) * 0.5;
+    k[i] = (float)exp(scale2x * x * x);
+    sum += k[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+}
+
+static inline int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) {
+    if (p < 0) p = -p; else p = 2 * (len - 1) - p;
+  }
+  return p;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv::GaussianBlur on CV_32F = sepFilter2D(row filter, then column filter), float
+ * intermediate, BORDER_REFLECT_101.  Operand order per OpenCV's filter engine:
+ *   row,  ks<=5 (SymmRowSmallFilter): c*k0 + (l1+r1)*k1 [+ (l2+r2)*k2]
+ *   row,  ks>5  (RowFilter)         : left-to-right accumulation over the taps
+ *   col,  ks==3 (SymmColumnSmallFilter): (top+bottom)*k1 + c*k0
+ *   col,  ks>3  (SymmColumnFilter)  : c*k0, then += k[j]*(S[+j] + S[-j]) for j=1..
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_gaussian_blur_f32(const float* src, int h, int w, int ks, double sigma, float* dst) {
+  float kbuf[64];
+  orc_gaussian_kernel(ks, sigma, kbuf);
+  int r = ks / 2;
+  const float* kc = kbuf + r;
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)h * w);
+  for (int y = 0; y < h; ++y) {
+    const float* S = src + (size_t)y * w;
+    float* D = tmp + (size_t)y * w;
+    for (int x = 0; x < w; ++x) {
+      float s;
+      if (ks == 3) {
+        s = S[x] * kc[0] + (S[reflect101(x - 1, w)] + S[reflect101(x + 1, w)]) * kc[1];
+      } else if (ks == 5) {
+        s = S[x] * kc[0] + (S[reflect101(x - 1, w)] + S[reflect101(x + 1, w)]) * kc[1] +
+            (S[reflect101(x - 2, w)] + S[reflect101(x + 2, w)]) * kc[2];
+      } else {
+        s = kbuf[0] * S[reflect101(x - r, w)];
+        for (int k = 1; k < ks; ++k) s += kbuf[k] * S[reflect101(x - r + k, w)];
+      }
+      D[x] = s;
+    }
+  }
+  for (int y = 0; y < h; ++y) {
+    float* D = dst + (size_t)y * w;
+    if (ks == 3) {
+      const float* S0 = tmp + (size_t)reflect101(y - 1, h) * w;
+      const float* S1 = tmp + (size_t)y * w;
+      const float* S2 = tmp + (size_t)reflect101(y + 1, h) * w;
+      for (int x = 0; x < w; ++x) D[x] = (S0[x] + S2[x]) * kc[1] + S1[x] * kc[0];
+    } else {
+      const float* Sc = tmp + (size_t)y * w;
+      for (int x = 0; x < w; ++x) D[x] = kc[0] * Sc[x];
+      for (int k = 1; k <= r; ++k) {
+        const float* Sp = tmp + (size_t)reflect101(y + k, h) * w;
+        const float* Sm = tmp + (size_t)reflect101(y - k, h) * w;
+        for (int x = 0; x < w; ++x) D[x] += kc[k] * (Sp[x] + Sm[x]);
+      }
+    }
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv::resize(..., INTER_LINEAR) for CV_32FC(cn): half-pixel centres, horizontal pass then
+ * vertical pass in float; exact-2x decimation is rerouted by OpenCV to the INTER_AREA fast
+ * path ((a+b)+(c+d))*0.25; equal sizes are a plain copy.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst, int dh, int dw) {
+  if (sh == dh && sw == dw) { memcpy(dst, src, sizeof(float) * (size_t)sh * sw * cn); return; }
+  double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  if (sw == 2 * dw && sh == 2 * dh) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x)
+        for (int c = 0; c < cn; ++c) {
+          const float* S0 = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+          const float* S1 = S0 + (size_t)sw * cn;
+          dst[((size_t)y * dw + x) * cn + c] = ((S0[0] + S0[cn]) + (S1[0] + S1[cn])) * 0.25f;
+        }
+    return;
+  }
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  float* xa = (float*)malloc(sizeof(float) * dw);
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx; xa[dx] = fx;
+  }
+  float* rows[2];
+  rows[0] = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+  rows[1] = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor_f(fy);
+    fy -= sy;
+    float b0 = 1.f - fy, b1 = fy;
+    for (int k = 0; k < 2; ++k) {
+      int yy = imin(imax(sy + k, 0), sh - 1);
+      const float* S = src + (size_t)yy * sw * cn;
+      for (int dx = 0; dx < dw; ++dx) {
+        int sx = xofs[dx];
+        float a1 = xa[dx], a0 = 1.f - a1;
+        for (int c = 0; c < cn; ++c) {
+          if (sx + 1 < sw) rows[k][dx * cn + c] = S[sx * cn + c] * a0 + S[(sx + 1) * cn + c] * a1;
+          else rows[k][dx * cn + c] = S[sx * cn + c] * 1.f;
+        }
+      }
+    }
+    float* D = dst + (size_t)dy * dw * cn;
+    for (int i = 0; i < dw * cn; ++i) D[i] = rows[0][i] * b0 + rows[1][i] * b1;
+  }
+  free(rows[0]); free(rows[1]); free(xofs); free(xa);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FarnebackPrepareGaussian (optflowgf.cpp): weights g, x*g, x^2*g for x in [-n,n] and the
+ * four entries of inv(G) that the expansion uses.
+ * g/xg/xxg point at the centre tap (index 0), valid for [-n, n].
+ * ---------------------------------------------------------------------------------------- */
+static void invert6(double A[6][6], double inv[6][6]) {
+  double a[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { a[i][j] = A[i][j]; a[i][6 + j] = (i == j); }
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+    if (p != c) for (int j = 0; j < 12; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+    double d = 1. / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= d;
+    for (int r = 0; r < 6; ++r) if (r != c) {
+      double f = a[r][c];
+      if (f != 0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) inv[i][j] = a[i][6 + j];
+}
+
+ORC_API void orc_poly_prepare(int n, double sigma, float* g, float* xg, float* xxg, double* ig /* ig11, ig03, ig33, ig55 */) {
+  if (sigma < 1.1920929e-07) sigma = n * 0.3;
+  double s = 0.;
+  for (int x = -n; x <= n; ++x) {
+    g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+    s += g[x];
+  }
+  s = 1. / s;
+  for (int x = -n; x <= n; ++x) {
+    g[x] = (float)(g[x] * s);
+    xg[x] = (float)(x * g[x]);
+    xxg[x] = (float)(x * x * g[x]);
+  }
+  double G[6][6];
+  memset(G, 0, sizeof(G));
+  for (int y = -n; y <= n; ++y)
+    for (int x = -n; x <= n; ++x) {
+      G[0][0] += g[y] * g[x];
+      G[1][1] += g[y] * g[x] * x * x;
+      G[3][3] += g[y] * g[x] * x * x * x * x;
+      G[5][5] += g[y] * g[x] * x * x * y * y;
+    }
+  G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+  G[4][4] = G[3][3];
+  G[3][4] = G[4][3] = G[5][5];
+  double inv[6][6];
+  invert6(G, inv);
+  ig[0] = inv[1][1]; ig[1] = inv[0][3]; ig[2] = inv[3][3]; ig[3] = inv[5][5];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4  FarnebackPolyExp(I, R, n, sigma).  Vertical pass in float with rows clamped,
+ * horizontal pass with replicated columns; b1/b4 accumulate double products, b2,b3,b5,b6
+ * accumulate float products widened to double (the expression types of the original).
+ * R: (h,w,5) interleaved.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_polyexp(const float* I, int h, int w, int n, double sigma, float* R) {
+  float kbuf[3 * 33];
+  float* g = kbuf + n;
+  float* xg = g + 2 * n + 1;
+  float* xxg = xg + 2 * n + 1;
+  double ig[4];
+  orc_poly_prepare(n, sigma, g, xg, xxg, ig);
+  double ig11 = ig[0], ig03 = ig[1], ig33 = ig[2], ig55 = ig[3];
+  float* rowbuf = (float*)malloc(sizeof(float) * (size_t)(w + 2 * n) * 3);
+  float* row = rowbuf + n * 3;
+  for (int y = 0; y < h; ++y) {
+    float g0 = g[0], g1, g2;
+    const float* srow0 = I + (size_t)y * w;
+    const float* srow1;
+    float* drow = R + (size_t)y * w * 5;
+    for (int x = 0; x < w; ++x) {
+      row[x * 3] = srow0[x] * g0;
+      row[x * 3 + 1] = row[x * 3 + 2] = 0.f;
+    }
+    for (int k = 1; k <= n; ++k) {
+      g0 = g[k]; g1 = xg[k]; g2 = xxg[k];
+      srow0 = I + (size_t)imax(y - k, 0) * w;
+      srow1 = I + (size_t)imin(y + k, h - 1) * w;
+      for (int x = 0; x < w; ++x) {
+        float p = srow0[x] + srow1[x];
+        float t0 = row[x * 3] + g0 * p;
+        float t1 = row[x * 3 + 2] + g2 * p;
+        p = srow1[x] - srow0[x];
+        float t2 = row[x * 3 + 1] + g1 * p;
+        row[x * 3] = t0;
+        row[x * 3 + 1] = t2;
+        row[x * 3 + 2] = t1;
+      }
+    }
+    for (int x = 0; x < n * 3; ++x) {
+      row[-1 - x] = row[2 - x];
+      row[w * 3 + x] = row[w * 3 + x - 3];
+    }
+    for (int x = 0; x < w; ++x) {
+      g0 = g[0];
+      double b1 = row[x * 3] * g0, b2 = 0, b3 = row[x * 3 + 1] * g0, b4 = 0, b5 = row[x * 3 + 2] * g0, b6 = 0;
+      for (int k = 1; k <= n; ++k) {
+        double tg = row[(x + k) * 3] + row[(x - k) * 3];
+        g0 = g[k];
+        b1 += tg * g0;
+        b4 += tg * xxg[k];
+        b2 += (row[(x + k) * 3] - row[(x - k) * 3]) * xg[k];
+        b3 += (row[(x + k) * 3 + 1] + row[(x - k) * 3 + 1]) * g0;
+        b6 += (row[(x + k) * 3 + 1] - row[(x - k) * 3 + 1]) * xg[k];
+        b5 += (row[(x + k) * 3 + 2] + row[(x - k) * 3 + 2]) * g0;
+      }
+      drow[x * 5 + 1] = (float)(b2 * ig11);
+      drow[x * 5] = (float)(b3 * ig11);
+      drow[x * 5 + 3] = (float)(b1 * ig03 + b4 * ig33);
+      drow[x * 5 + 2] = (float)(b1 * ig03 + b5 * ig33);
+      drow[x * 5 + 4] = (float)(b6 * ig55);
+    }
+  }
+  free(rowbuf);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5  FarnebackUpdateMatrices(R0, R1, flow, M, y0, y1).  R*, M: (h,w,5); flow: (h,w,2).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_update_matrices(const float* R0a, const float* R1a, const float* flowa, float* Ma,
+                                 int h, int w, int y0, int y1) {
+  enum { BORDER = 5 };
+  static const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+  size_t step1 = (size_t)w * 5;
+  for (int y = y0; y < y1; ++y) {
+    const float* flow = flowa + (size_t)y * w * 2;
+    const float* R0 = R0a + (size_t)y * w * 5;
+    float* M = Ma + (size_t)y * w * 5;
+    for (int x = 0; x < w; ++x) {
+      float dx = flow[x * 2], dy = flow[x * 2 + 1];
+      float fx = x + dx, fy = y + dy;
+      int x1 = cv_floor_f(fx), y1i = cv_floor_f(fy);
+      float r2, r3, r4, r5, r6;
+      fx -= x1; fy -= y1i;
+      if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1i < (unsigned)(h - 1)) {
+        const float* ptr = R1a + (size_t)y1i * step1 + (size_t)x1 * 5;
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * ptr[0] + a01 * ptr[5] + a10 * ptr[step1] + a11 * ptr[step1 + 5];
+        r3 = a00 * ptr[1] + a01 * ptr[6] + a10 * ptr[step1 + 1] + a11 * ptr[step1 + 6];
+        r4 = a00 * ptr[2] + a01 * ptr[7] + a10 * ptr[step1 + 2] + a11 * ptr[step1 + 7];
+        r5 = a00 * ptr[3] + a01 * ptr[8] + a10 * ptr[step1 + 3] + a11 * ptr[step1 + 8];
+        r6 = a00 * ptr[4] + a01 * ptr[9] + a10 * ptr[step1 + 4] + a11 * ptr[step1 + 9];
+        r4 = (R0[x * 5 + 2] + r4) * 0.5f;
+        r5 = (R0[x * 5 + 3] + r5) * 0.5f;
+        r6 = (R0[x * 5 + 4] + r6) * 0.25f;
+      } else {
+        r2 = r3 = 0.f;
+        r4 = R0[x * 5 + 2];
+        r5 = R0[x * 5 + 3];
+        r6 = R0[x * 5 + 4] * 0.5f;
+      }
+      r2 = (R0[x * 5] - r2) * 0.5f;
+      r3 = (R0[x * 5 + 1] - r3) * 0.5f;
+      r2 += r4 * dy + r6 * dx;
+      r3 += r6 * dy + r5 * dx;
+      if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) ||
+          (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                      (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+      }
+      M[x * 5] = r4 * r4 + r6 * r6;
+      M[x * 5 + 1] = (r4 + r5) * r6;
+      M[x * 5 + 2] = r5 * r5 + r6 * r6;
+      M[x * 5 + 3] = r4 * r2 + r6 * r3;
+      M[x * 5 + 4] = r6 * r2 + r5 * r3;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6  FarnebackUpdateFlow_Blur(R0, R1, flow, M, block_size, update_matrices): box filter of M
+ * by double running sums (vertical: += float(M[y+m] - M[y-m-1]); horizontal: running window
+ * over the replicated vsum row), 2x2 solve, then striped in-place UpdateMatrices.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_update_flow_blur(const float* R0, const float* R1, float* flowa, float* Ma,
+                                  int h, int w, int block_size, int update_matrices) {
+  int m = block_size / 2;
+  int y0 = 0, y1;
+  int min_update_stripe = imax((1 << 10) / w, block_size);
+  double scale = 1. / (block_size * block_size);
+  double* vbuf = (double*)malloc(sizeof(double) * (size_t)(w + m * 2 + 2) * 5);
+  double* vsum = vbuf + (m + 1) * 5;
+  const float* srow0 = Ma;
+  for (int x = 0; x < w * 5; ++x) vsum[x] = srow0[x] * (m + 2);
+  for (int y = 1; y < m; ++y) {
+    srow0 = Ma + (size_t)imin(y, h - 1) * w * 5;
+    for (int x = 0; x < w * 5; ++x) vsum[x] += srow0[x];
+  }
+  for (int y = 0; y < h; ++y) {
+    double g11, g12, g22, h1, h2;
+    float* flow = flowa + (size_t)y * w * 2;
+    srow0 = Ma + (size_t)imax(y - m - 1, 0) * w * 5;
+    const float* srow1 = Ma + (size_t)imin(y + m, h - 1) * w * 5;
+    for (int x = 0; x < w * 5; ++x) vsum[x] += srow1[x] - srow0[x];
+    for (int x = 0; x < (m + 1) * 5; ++x) {
+      vsum[-1 - x] = vsum[4 - x];
+      vsum[w * 5 + x] = vsum[w * 5 + x - 5];
+    }
+    g11 = vsum[0] * (m + 2);
+    g12 = vsum[1] * (m + 2);
+    g22 = vsum[2] * (m + 2);
+    h1 = vsum[3] * (m + 2);
+    h2 = vsum[4] * (m + 2);
+    for (int x = 1; x < m; ++x) {
+      g11 += vsum[x * 5];
+      g12 += vsum[x * 5 + 1];
+      g22 += vsum[x * 5 + 2];
+      h1 += vsum[x * 5 + 3];
+      h2 += vsum[x * 5 + 4];
+    }
+    for (int x = 0; x < w; ++x) {
+      g11 += vsum[(x + m) * 5] - vsum[(x - m) * 5 - 5];
+      g12 += vsum[(x + m) * 5 + 1] - vsum[(x - m) * 5 - 4];
+      g22 += vsum[(x + m) * 5 + 2] - vsum[(x - m) * 5 - 3];
+      h1 += vsum[(x + m) * 5 + 3] - vsum[(x - m) * 5 - 2];
+      h2 += vsum[(x + m) * 5 + 4] - vsum[(x - m) * 5 - 1];
+      double g11_ = g11 * scale, g12_ = g12 * scale, g22_ = g22 * scale, h1_ = h1 * scale, h2_ = h2 * scale;
+      double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+      flow[x * 2] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+      flow[x * 2 + 1] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    }
+    y1 = y == h - 1 ? h : y - block_size;
+    if (update_matrices && (y1 == h || y1 >= y0 + min_update_stripe)) {
+      orc_update_matrices(R0, R1, flowa, Ma, h, w, y0, y1);
+      y0 = y1;
+    }
+  }
+  free(vbuf);
+}
+
+/* Parameters of cv::FarnebackOpticalFlow::create(numLevels, pyrScale, fastPyramids, winSize,
+ * numIters, polyN, polySigma, flags).  Reference: (3, 0.5, false, 15, 3, 5, 1.2, 0)
+ * optical_flow_kernel_cpu.cpp:16.  Only flags == 0 and fastPyramids == false are restated. */
+typedef struct orc_fb_params {
+  int num_levels;
+  double pyr_scale;
+  int fast_pyramids;
+  int win_size;
+  int num_iters;
+  int poly_n;
+  double poly_sigma;
+  int flags;
+  int gray_bits;
+} orc_fb_params;
+
+ORC_API void orc_fb_params_default(orc_fb_params* p) {
+  p->num_levels = 3; p->pyr_scale = 0.5; p->fast_pyramids = 0; p->win_size = 15; p->num_iters = 3;
+  p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0; p->gray_bits = 15;
+}
+
+/* Number of pyramid levels actually processed is levels+1 (k = levels .. 0). */
+ORC_API int orc_fb_levels(int h, int w, const orc_fb_params* p) {
+  int k; double scale = 1;
+  for (k = 0; k < p->num_levels; ++k) {
+    scale *= p->pyr_scale;
+    if (w * scale < 32 || h * scale < 32) break;
+  }
+  return k;
+}
+
+ORC_API void orc_fb_level_geom(int h, int w, const orc_fb_params* p, int k, int* lh, int* lw, double* sigma, int* ksize) {
+  double scale = 1;
+  for (int i = 0; i < k; ++i) scale *= p->pyr_scale;
+  double sg = (1. / scale - 1) * 0.5;
+  int sz = cv_round(sg * 5) | 1;
+  sz = imax(sz, 3);
+  *lw = cv_round(w * scale); *lh = cv_round(h * scale); *sigma = sg; *ksize = sz;
+}
+
+/* One pyramid image: convertTo(F32) -> GaussianBlur(full res) -> resize to level size. */
+ORC_API void orc_fb_pyr_image(const uint8_t* gray, int h, int w, const orc_fb_params* p, int k, float* I) {
+  int lh, lw, ks; double sigma;
+  orc_fb_level_geom(h, w, p, k, &lh, &lw, &sigma, &ks);
+  size_t n = (size_t)h * w;
+  float* f = (float*)malloc(sizeof(float) * n);
+  float* b = (float*)malloc(sizeof(float) * n);
+  for (size_t i = 0; i < n; ++i) f[i] = (float)gray[i];
+  orc_gaussian_blur_f32(f, h, w, ks, sigma, b);
+  orc_resize_linear_f32(b, h, w, 1, I, lh, lw);
+  free(f); free(b);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A3  FarnebackOpticalFlowImpl::calc(prev, next, flow) for flags = 0.
+ * flow: (h,w,2) F32 interleaved (u,v): next(x+u, y+v) ~ prev(x,y).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_farneback(const uint8_t* prev, const uint8_t* next, int h, int w, const orc_fb_params* p, float* flow_out) {
+  const uint8_t* img[2] = {prev, next};
+  int levels = orc_fb_levels(h, w, p);
+  float* prev_flow = NULL; int ph = 0, pw = 0;
+  for (int k = levels; k >= 0; --k) {
+    int lh, lw, ks; double sigma;
+    orc_fb_level_geom(h, w, p, k, &lh, &lw, &sigma, &ks);
+    size_t np = (size_t)lh * lw;
+    float* flow = k > 0 ? (float*)malloc(sizeof(float) * np * 2) : flow_out;
+    if (!prev_flow) {
+      memset(flow, 0, sizeof(float) * np * 2);
+    } else {
+      orc_resize_linear_f32(prev_flow, ph, pw, 2, flow, lh, lw);
+      float mul = (float)(1. / p->pyr_scale);
+      for (size_t i = 0; i < np * 2; ++i) flow[i] = flow[i] * mul;
+    }
+    float* R[2];
+    float* I = (float*)malloc(sizeof(float) * np);
+    for (int i = 0; i < 2; ++i) {
+      R[i] = (float*)malloc(sizeof(float) * np * 5);
+      orc_fb_pyr_image(img[i], h, w, p, k, I);
+      orc_polyexp(I, lh, lw, p->poly_n, p->poly_sigma, R[i]);
+    }
+    free(I);
+    float* M = (float*)malloc(sizeof(float) * np * 5);
+    orc_update_matrices(R[0], R[1], flow, M, lh, lw, 0, lh);
+    for (int i = 0; i < p->num_iters; ++i)
+      orc_update_flow_blur(R[0], R[1], flow, M, lh, lw, p->win_size, i < p->num_iters - 1);
+    free(M); free(R[0]); free(R[1]);
+    if (prev_flow) free(prev_flow);
+    prev_flow = flow; ph = lh; pw = lw;
+  }
+}
+
+/* The op: OpticalFlowKernelCPU::execute (optical_flow_kernel_cpu.cpp:36-41):
+ * gray(frame0), gray(frame1), calc(gray0, gray1, flow). */
+ORC_API void orc_optical_flow_rgb(const uint8_t* frame0, const uint8_t* frame1, int h, int w,
+                                  const orc_fb_params* p, float* flow_out) {
+  size_t n = (size_t)h * w;
+  uint8_t* g0 = (uint8_t*)malloc(n);
+  uint8_t* g1 = (uint8_t*)malloc(n);
+  orc_gray_u8(frame0, h, w, p->gray_bits, g0);
+  orc_gray_u8(frame1, h, w, p->gray_bits, g1);
+  orc_farneback(g0, g1, h, w, p, flow_out);
+  free(g0); free(g1);
+}

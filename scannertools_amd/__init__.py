@@ -1,0 +1,10 @@
+"""scannertools hot path (Histogram -> ShotBoundaries, Farneback OpticalFlow) for MI355X.
+
+``scannertools_amd.hip``            device ops over the C ABI (include/scannertools_hip.h)
+``scannertools_amd.shot_detection`` the ShotBoundaries python op
+``scannertools_amd.types``          wire-format readers
+``scannertools_amd.engine``         in-process stand-in for the Scanner graph API of the path
+"""
+from .shot_detection import shot_boundaries, WINDOW_SIZE, BOUNDARY_BATCH  # noqa: F401
+
+__all__ = ["shot_boundaries", "WINDOW_SIZE", "BOUNDARY_BATCH"]

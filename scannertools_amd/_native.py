@@ -1,0 +1,104 @@
+"""ctypes binding of libscannertools_hip.so (the C ABI declared in include/scannertools_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C scannertools_amd/csrc``
+and lives at ``scannertools_amd/lib/libscannertools_hip.so``.  There is no fallback: if the
+library is missing, :func:`lib` raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscannertools_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ST_OK, ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_OOM, ST_ERR_UNSUPPORTED = range(5)
+K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_COUNT = range(7)
+KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update"]
+
+
+class StError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("scannertools_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class FbParams(ctypes.Structure):
+    """``st_fb_params``: arguments of cv::FarnebackOpticalFlow::create as the reference passes
+    them (scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:15-16) + the gray table width."""
+    _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double),
+                ("fast_pyramids", ctypes.c_int), ("win_size", ctypes.c_int),
+                ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int),
+                ("poly_sigma", ctypes.c_double), ("flags", ctypes.c_int),
+                ("gray_bits", ctypes.c_int)]
+
+
+# symbol -> (restype, argtypes); also the list the CPU test-suite checks against the header
+_c = ctypes
+_vp, _i, _sz, _d = _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_double
+SIGNATURES = {
+    "st_abi_version": (_i, []),
+    "st_status_string": (_c.c_char_p, [_i]),
+    "st_device_count": (_i, [_c.POINTER(_i)]),
+    "st_ctx_create": (_i, [_i, _c.POINTER(_vp)]),
+    "st_ctx_destroy": (_i, [_vp]),
+    "st_ctx_set_stream": (_i, [_vp, _vp]),
+    "st_ctx_sync": (_i, [_vp]),
+    "st_ctx_set_workspace_limit": (_i, [_vp, _sz]),
+    "st_ctx_release_workspace": (_i, [_vp]),
+    "st_ctx_last_error": (_c.c_char_p, [_vp]),
+    "st_ctx_timing_enable": (_i, [_vp, _c.c_uint]),
+    "st_ctx_timing_reset": (_i, [_vp]),
+    "st_ctx_timing_read": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_d)]),
+    "st_hist_u8c3_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp]),
+    "st_hist_u8c3_strided": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "st_fb_params_default": (None, [_c.POINTER(FbParams)]),
+    "st_farneback_pairs": (_i, [_vp, _c.POINTER(_vp), _i, _c.POINTER(_c.c_int32), _i, _i, _i,
+                                _c.POINTER(FbParams), _c.POINTER(_vp)]),
+    "st_fb_levels": (_i, [_i, _i, _c.POINTER(FbParams)]),
+    "st_fb_level_geom": (_i, [_i, _i, _c.POINTER(FbParams), _i, _c.POINTER(_i), _c.POINTER(_i),
+                              _c.POINTER(_d), _c.POINTER(_i)]),
+    "st_gray_u8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "st_fb_pyr_image": (_i, [_vp, _vp, _i, _i, _c.POINTER(FbParams), _i, _vp]),
+    "st_fb_polyexp": (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
+    "st_fb_update_matrices": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _i, _vp]),
+    "st_fb_update_flow_blur": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libscannertools_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C scannertools_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.st_abi_version() != 1:
+            raise RuntimeError("libscannertools_hip.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def default_params(**overrides):
+    p = FbParams()
+    lib().st_fb_params_default(ctypes.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown Farneback parameter %r" % k)
+        setattr(p, k, v)
+    return p

@@ -1,0 +1,206 @@
+// Context, error reporting, scratch arena and per-kernel event timing for libscannertools_hip.so.
+#include "st_internal.h"
+
+int st_set_error(st_ctx* ctx, int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->last_error = buf;
+  return status;
+}
+
+int st_enter(st_ctx* ctx) {
+  if (!ctx) return ST_ERR_INVALID;
+  ST_HIP(ctx, hipSetDevice(ctx->device));
+  return ST_OK;
+}
+
+ST_EXPORT int st_abi_version(void) { return ST_ABI_VERSION; }
+
+ST_EXPORT const char* st_status_string(int status) {
+  switch (status) {
+    case ST_OK: return "ok";
+    case ST_ERR_INVALID: return "invalid argument";
+    case ST_ERR_HIP: return "HIP runtime error";
+    case ST_ERR_OOM: return "out of device memory";
+    case ST_ERR_UNSUPPORTED: return "unsupported parameters";
+    default: return "unknown status";
+  }
+}
+
+ST_EXPORT int st_device_count(int* count) {
+  if (!count) return ST_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return ST_ERR_HIP; }
+  *count = n;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
+  if (!out_ctx) return ST_ERR_INVALID;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return ST_ERR_INVALID;
+  if (hipSetDevice(device_id) != hipSuccess) return ST_ERR_HIP;
+  st_ctx* c = new (std::nothrow) st_ctx();
+  if (!c) return ST_ERR_OOM;
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return ST_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  *out_ctx = c;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_destroy(st_ctx* ctx) {
+  if (!ctx) return ST_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& t : ctx->timing) {
+    for (auto e : t.starts) (void)hipEventDestroy(e);
+    for (auto e : t.stops) (void)hipEventDestroy(e);
+  }
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_set_stream(st_ctx* ctx, void* hip_stream) {
+  ST_TRY(st_enter(ctx));
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_sync(st_ctx* ctx) {
+  ST_TRY(st_enter(ctx));
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes) {
+  if (!ctx) return ST_ERR_INVALID;
+  ctx->ws_limit = bytes ? bytes : ((size_t)24 << 30);
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_release_workspace(st_ctx* ctx) {
+  ST_TRY(st_enter(ctx));
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) ST_HIP(ctx, hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  ctx->ws_off = 0;
+  return ST_OK;
+}
+
+ST_EXPORT const char* st_ctx_last_error(const st_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int st_ws_reserve(st_ctx* ctx, size_t total_bytes) {
+  ctx->ws_off = 0;
+  if (total_bytes <= ctx->ws_bytes) return ST_OK;
+  if (total_bytes > ctx->ws_limit)
+    return st_set_error(ctx, ST_ERR_OOM, "workspace request %zu exceeds limit %zu", total_bytes, ctx->ws_limit);
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) ST_HIP(ctx, hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  size_t want = total_bytes + total_bytes / 8;  // slack against regrowth
+  if (want > ctx->ws_limit) want = total_bytes;
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    want = total_bytes;
+    e = hipMalloc(&ctx->ws, want);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->ws = nullptr;
+    return st_set_error(ctx, ST_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  }
+  ctx->ws_bytes = want;
+  return ST_OK;
+}
+
+void st_ws_reset(st_ctx* ctx) { ctx->ws_off = 0; }
+
+void* st_ws_alloc(st_ctx* ctx, size_t bytes) {
+  size_t off = st_align_up(ctx->ws_off);
+  if (off + bytes > ctx->ws_bytes) return nullptr;
+  ctx->ws_off = off + bytes;
+  return (char*)ctx->ws + off;
+}
+
+ST_EXPORT int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask) {
+  if (!ctx) return ST_ERR_INVALID;
+  ctx->timing_mask = kernel_mask;
+  return ST_OK;
+}
+
+static int timing_fold(st_ctx* ctx, st_timing_slot& t) {
+  for (size_t i = 0; i < t.used; ++i) {
+    float ms = 0.f;
+    ST_HIP(ctx, hipEventElapsedTime(&ms, t.starts[i], t.stops[i]));
+    t.total_ms += ms;
+  }
+  t.used = 0;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_timing_reset(st_ctx* ctx) {
+  ST_TRY(st_enter(ctx));
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& t : ctx->timing) {
+    t.used = 0;
+    t.launches = 0;
+    t.total_ms = 0.0;
+  }
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_timing_read(st_ctx* ctx, int kernel_id, int* launches, double* total_ms) {
+  ST_TRY(st_enter(ctx));
+  if (kernel_id < 0 || kernel_id >= ST_K_COUNT) return ST_ERR_INVALID;
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  st_timing_slot& t = ctx->timing[kernel_id];
+  ST_TRY(timing_fold(ctx, t));
+  if (launches) *launches = t.launches;
+  if (total_ms) *total_ms = t.total_ms;
+  return ST_OK;
+}
+
+int st_time_begin(st_ctx* ctx, int id) {
+  if (!(ctx->timing_mask & (1u << id))) return ST_OK;
+  st_timing_slot& t = ctx->timing[id];
+  if (t.used == t.starts.size()) {
+    if (t.used >= 4096) {  // fold to bound the pool
+      ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ST_TRY(timing_fold(ctx, t));
+    } else {
+      hipEvent_t a, b;
+      ST_HIP(ctx, hipEventCreate(&a));
+      ST_HIP(ctx, hipEventCreate(&b));
+      t.starts.push_back(a);
+      t.stops.push_back(b);
+    }
+  }
+  ST_HIP(ctx, hipEventRecord(t.starts[t.used], ctx->stream));
+  return ST_OK;
+}
+
+int st_time_end(st_ctx* ctx, int id) {
+  if (!(ctx->timing_mask & (1u << id))) return ST_OK;
+  st_timing_slot& t = ctx->timing[id];
+  ST_HIP(ctx, hipEventRecord(t.stops[t.used], ctx->stream));
+  t.used++;
+  t.launches++;
+  return ST_OK;
+}

@@ -1,0 +1,960 @@
+// Farneback dense optical flow for gfx950.
+//
+// Replaces the arithmetic of OpticalFlowKernelCPU::execute
+// (/root/reference/scannertools/scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:36-41):
+//   cv::cvtColor(BGR2GRAY) x2  ->  k_gray
+//   cv::FarnebackOpticalFlow::calc:
+//     convertTo(F32) + GaussianBlur + resize        ->  k_pyr            (one launch per level)
+//     FarnebackPolyExp                              ->  k_polyexp        (row-marching, LDS exchange)
+//     resize(prevFlow)*2 + FarnebackUpdateMatrices  ->  k_update_matrices
+//     FarnebackUpdateFlow_Blur (x numIters)         ->  k_blur_update    (box blur + 2x2 solve with the
+//                                                                          next UpdateMatrices fused in)
+// All kernels are batched over frames / pairs through blockIdx.z.  The operand order and the
+// accumulator types (float vs double) of every expression follow the OpenCV scalar code so
+// that, built with -ffp-contract=off, every stage except the running-sum box filter is
+// bit-identical to the CPU restatement in oracle/oracle.c.
+//
+// Data layout in HBM (dense, per frame or per pair):
+//   gray  u8 (h,w)            I_k  f32 (lh,lw)
+//   R_k   f32 planar (5,lh,lw): [d/dy, d/dx, yy, xx, xy] -- SoA so that every row access is a
+//         unit-stride 4-B-per-lane stream and the bilinear gather of R1 stays coalesced
+//   M     f32 planar (5,lh,lw): [G11, G12, G22, h1, h2] (two buffers, ping-pong per iteration)
+//   flow  f32 (lh,lw,2) interleaved (u,v): the op's output format
+#include <cmath>
+#include <cstring>
+
+#include "st_internal.h"
+
+namespace {
+
+constexpr int kMaxTaps = 32;   // Gaussian pyramid kernel taps (reference needs <= 19)
+constexpr int kMaxPolyN = 7;
+
+// ---------------------------------------------------------------------------------------------
+// host-side replicas of the scalar parameter derivations in optflowgf.cpp / smooth.cpp
+// ---------------------------------------------------------------------------------------------
+inline int cv_round(double v) { return (int)lrint(v); }
+
+struct LevelGeom {
+  int lh, lw, ksize;
+  double sigma, scale;
+};
+
+int fb_levels(int h, int w, const st_fb_params& p) {
+  int k;
+  double scale = 1;
+  for (k = 0; k < p.num_levels; ++k) {
+    scale *= p.pyr_scale;
+    if (w * scale < 32 || h * scale < 32) break;
+  }
+  return k;
+}
+
+LevelGeom fb_level_geom(int h, int w, const st_fb_params& p, int k) {
+  LevelGeom g;
+  double scale = 1;
+  for (int i = 0; i < k; ++i) scale *= p.pyr_scale;
+  g.scale = scale;
+  g.sigma = (1. / scale - 1) * 0.5;
+  int sz = cv_round(g.sigma * 5) | 1;
+  g.ksize = sz > 3 ? sz : 3;
+  g.lw = cv_round(w * scale);
+  g.lh = cv_round(h * scale);
+  return g;
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F)
+void gaussian_kernel(int n, double sigma, float* k) {
+  if (n == 3 && sigma <= 0) { k[0] = 0.25f; k[1] = 0.5f; k[2] = 0.25f; return; }
+  if (n == 1 && sigma <= 0) { k[0] = 1.f; return; }
+  if (n == 5 && sigma <= 0) { k[0] = 0.0625f; k[1] = 0.25f; k[2] = 0.375f; k[3] = 0.25f; k[4] = 0.0625f; return; }
+  if (n == 7 && sigma <= 0) {
+    static const float t[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    memcpy(k, t, sizeof(t));
+    return;
+  }
+  double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  double scale2x = -0.5 / (sx * sx);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = i - (n - 1) * 0.5;
+    k[i] = (float)std::exp(scale2x * x * x);
+    sum += k[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+}
+
+struct PolyCoef {
+  float g[kMaxPolyN + 1], xg[kMaxPolyN + 1], xxg[kMaxPolyN + 1];  // taps 0..n (symmetric / antisymmetric)
+  double ig11, ig03, ig33, ig55;
+};
+
+void invert6(double A[6][6], double inv[6][6]) {
+  double a[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { a[i][j] = A[i][j]; a[i][6 + j] = (i == j); }
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+    if (p != c) for (int j = 0; j < 12; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+    double d = 1. / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= d;
+    for (int r = 0; r < 6; ++r) if (r != c) {
+      double f = a[r][c];
+      if (f != 0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) inv[i][j] = a[i][6 + j];
+}
+
+// FarnebackPrepareGaussian
+void poly_prepare(int n, double sigma, PolyCoef* pc) {
+  float gb[2 * kMaxPolyN + 1], xgb[2 * kMaxPolyN + 1], xxgb[2 * kMaxPolyN + 1];
+  float *g = gb + n, *xg = xgb + n, *xxg = xxgb + n;
+  if (sigma < 1.1920929e-07) sigma = n * 0.3;
+  double s = 0.;
+  for (int x = -n; x <= n; ++x) {
+    g[x] = (float)std::exp(-x * x / (2 * sigma * sigma));
+    s += g[x];
+  }
+  s = 1. / s;
+  for (int x = -n; x <= n; ++x) {
+    g[x] = (float)(g[x] * s);
+    xg[x] = (float)(x * g[x]);
+    xxg[x] = (float)(x * x * g[x]);
+  }
+  double G[6][6];
+  memset(G, 0, sizeof(G));
+  for (int y = -n; y <= n; ++y)
+    for (int x = -n; x <= n; ++x) {
+      G[0][0] += g[y] * g[x];
+      G[1][1] += g[y] * g[x] * x * x;
+      G[3][3] += g[y] * g[x] * x * x * x * x;
+      G[5][5] += g[y] * g[x] * x * x * y * y;
+    }
+  G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+  G[4][4] = G[3][3];
+  G[3][4] = G[4][3] = G[5][5];
+  double inv[6][6];
+  invert6(G, inv);
+  memset(pc, 0, sizeof(*pc));
+  for (int k = 0; k <= n; ++k) { pc->g[k] = g[k]; pc->xg[k] = xg[k]; pc->xxg[k] = xxg[k]; }
+  pc->ig11 = inv[1][1]; pc->ig03 = inv[0][3]; pc->ig33 = inv[3][3]; pc->ig55 = inv[5][5];
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+  return p;
+}
+__device__ __forceinline__ int d_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+// A2: 8-bit luma with OpenCV's BGR table applied to RGB bytes (reference quirk).
+// ---------------------------------------------------------------------------------------------
+struct GrayArgs {
+  const uint8_t* const* frames;  // device table (rgb)
+  uint8_t* gray;                 // n x npix
+  int npix;
+  int cb, cg, cr, rnd, shift;
+};
+
+__global__ __launch_bounds__(256) void k_gray(GrayArgs a) {
+  const uint8_t* __restrict__ src = a.frames[blockIdx.y];
+  uint8_t* __restrict__ dst = a.gray + (size_t)blockIdx.y * a.npix;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.npix; i += gridDim.x * blockDim.x) {
+    int c0 = src[3 * (size_t)i], c1 = src[3 * (size_t)i + 1], c2 = src[3 * (size_t)i + 2];
+    dst[i] = (uint8_t)((c0 * a.cb + c1 * a.cg + c2 * a.cr + a.rnd) >> a.shift);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pyramid image of level k: float(gray) -> GaussianBlur(ks, sigma) at FULL resolution ->
+// resize to (dh, dw).  Only the blurred samples the resize reads are computed: per 32x8
+// output tile, phase 1 row-filters the needed sample columns of the needed source rows
+// into LDS, phase 2 column-filters and interpolates.
+// ---------------------------------------------------------------------------------------------
+enum { PYR_COPY = 0, PYR_AREA2 = 1, PYR_LINEAR = 2 };
+constexpr int PYR_OW = 32, PYR_OH = 8;
+
+struct PyrArgs {
+  const uint8_t* gray;  // n x (sh*sw)
+  float* img;           // n x (dh*dw)
+  int sh, sw, dh, dw;
+  int ks, mode, max_rows;
+  double scale_x, scale_y;
+  float taps[kMaxTaps];
+};
+
+__device__ __forceinline__ void pyr_sample(int d, int slen, double scale, int mode, int* s0, int* s1, float* f) {
+  if (mode == PYR_COPY) { *s0 = *s1 = d; *f = 0.f; return; }
+  if (mode == PYR_AREA2) { *s0 = 2 * d; *s1 = 2 * d + 1; *f = 0.5f; return; }
+  float fx = (float)((d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  *s0 = sx; *s1 = sx + 1; *f = fx;
+}
+
+__global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float hb[];  // [max_rows][2*PYR_OW]
+  const int tid = threadIdx.x;
+  const int ox0 = blockIdx.x * PYR_OW, oy0 = blockIdx.y * PYR_OH;
+  const uint8_t* __restrict__ src = a.gray + (size_t)blockIdx.z * a.sh * a.sw;
+  float* __restrict__ dst = a.img + (size_t)blockIdx.z * a.dh * a.dw;
+  const int r = a.ks / 2;
+  const int oy_last = min(oy0 + PYR_OH, a.dh) - 1;
+
+  // source-row window of this tile (rows of the blurred image that the resize touches, +-r)
+  int ys0, ys1; float fy;
+  pyr_sample(oy0, a.sh, a.scale_y, a.mode, &ys0, &ys1, &fy);
+  int ya0 = d_clamp(ys0, 0, a.sh - 1);
+  pyr_sample(oy_last, a.sh, a.scale_y, a.mode, &ys0, &ys1, &fy);
+  int ya1 = d_clamp(ys1, 0, a.sh - 1);
+  const int ybase = ya0 - r;
+  const int nrows = ya1 + r - ybase + 1;
+
+  // phase 1: row filter at the sample columns
+  for (int idx = tid; idx < nrows * 2 * PYR_OW; idx += 256) {
+    const int j = idx / (2 * PYR_OW), c = idx - j * (2 * PYR_OW);
+    const int ox = ox0 + (c >> 1);
+    float v = 0.f;
+    if (ox < a.dw) {
+      int xs0, xs1; float fx;
+      pyr_sample(ox, a.sw, a.scale_x, a.mode, &xs0, &xs1, &fx);
+      int xs;
+      if (a.mode == PYR_LINEAR) {
+        // horizontal clamp rule of cv::resize: sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0)
+        if (xs0 < 0) { xs0 = 0; }
+        if (xs0 >= a.sw - 1) { xs0 = a.sw - 1; }
+        xs = (c & 1) ? min(xs0 + 1, a.sw - 1) : xs0;
+      } else {
+        xs = (c & 1) ? xs1 : xs0;
+      }
+      const uint8_t* S = src + (size_t)d_reflect101(ybase + j, a.sh) * a.sw;
+      if (a.ks == 3) {
+        v = (float)S[xs] * a.taps[1] +
+            ((float)S[d_reflect101(xs - 1, a.sw)] + (float)S[d_reflect101(xs + 1, a.sw)]) * a.taps[2];
+      } else if (a.ks == 5) {
+        v = (float)S[xs] * a.taps[2] +
+            ((float)S[d_reflect101(xs - 1, a.sw)] + (float)S[d_reflect101(xs + 1, a.sw)]) * a.taps[3] +
+            ((float)S[d_reflect101(xs - 2, a.sw)] + (float)S[d_reflect101(xs + 2, a.sw)]) * a.taps[4];
+      } else {
+        v = a.taps[0] * (float)S[d_reflect101(xs - r, a.sw)];
+        for (int k = 1; k < a.ks; ++k) v += a.taps[k] * (float)S[d_reflect101(xs - r + k, a.sw)];
+      }
+    }
+    hb[idx] = v;
+  }
+  __syncthreads();
+
+  // phase 2: column filter at the sample rows, then interpolate
+  const int tx = tid & (PYR_OW - 1), ty = tid / PYR_OW;
+  const int ox = ox0 + tx, oy = oy0 + ty;
+  if (ox >= a.dw || oy >= a.dh) return;
+  pyr_sample(oy, a.sh, a.scale_y, a.mode, &ys0, &ys1, &fy);
+  float bv[2][2];
+  const int nsr = (a.mode == PYR_COPY) ? 1 : 2;
+#pragma unroll
+  for (int ry = 0; ry < 2; ++ry) {
+    if (ry >= nsr) break;
+    const int ys = d_clamp(ry ? ys1 : ys0, 0, a.sh - 1);
+#pragma unroll
+    for (int rx = 0; rx < 2; ++rx) {
+      if (rx >= nsr) break;
+      const float* col = hb + 2 * tx + rx;
+      float s;
+      if (a.ks == 3) {
+        // tmp rows are indexed through reflect101 of the row index: LDS row of source row q is
+        // the first window row whose reflected index equals q; the window was filled with
+        // reflect101(ybase + j), so row (ys + t) lives at j = ys + t - ybase.
+        const int j = ys - ybase;
+        s = (col[(j - 1) * 2 * PYR_OW] + col[(j + 1) * 2 * PYR_OW]) * a.taps[2] + col[j * 2 * PYR_OW] * a.taps[1];
+      } else {
+        const int j = ys - ybase;
+        s = a.taps[r] * col[j * 2 * PYR_OW];
+        for (int k = 1; k <= r; ++k)
+          s += a.taps[r + k] * (col[(j + k) * 2 * PYR_OW] + col[(j - k) * 2 * PYR_OW]);
+      }
+      bv[ry][rx] = s;
+    }
+  }
+  float out;
+  if (a.mode == PYR_COPY) {
+    out = bv[0][0];
+  } else if (a.mode == PYR_AREA2) {
+    out = ((bv[0][0] + bv[0][1]) + (bv[1][0] + bv[1][1])) * 0.25f;
+  } else {
+    int xs0, xs1; float fx;
+    pyr_sample(ox, a.sw, a.scale_x, a.mode, &xs0, &xs1, &fx);
+    if (xs0 < 0) { fx = 0.f; xs0 = 0; }
+    if (xs0 >= a.sw - 1) { fx = 0.f; xs0 = a.sw - 1; }
+    const float a1 = fx, a0 = 1.f - fx;
+    float r0, r1;
+    if (xs0 + 1 < a.sw) {
+      r0 = bv[0][0] * a0 + bv[0][1] * a1;
+      r1 = bv[1][0] * a0 + bv[1][1] * a1;
+    } else {
+      r0 = bv[0][0] * 1.f;
+      r1 = bv[1][0] * 1.f;
+    }
+    const float b0 = 1.f - fy, b1 = fy;
+    out = r0 * b0 + r1 * b1;
+  }
+  dst[(size_t)oy * a.dw + ox] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
+// a vertical segment keeping the 2N+1 source rows of its column in registers; the three
+// vertically filtered values go through LDS for the horizontal pass.
+// ---------------------------------------------------------------------------------------------
+struct PolyArgs {
+  const float* img;  // n x (h*w)
+  float* R;          // n x 5 x (h*w)
+  int h, w, rows_per_seg;
+  PolyCoef c;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
+  __shared__ float sv[2][3][256];
+  const int tid = threadIdx.x;
+  const int h = a.h, w = a.w;
+  const size_t np = (size_t)h * w;
+  const float* __restrict__ I = a.img + (size_t)blockIdx.z * np;
+  float* __restrict__ R = a.R + (size_t)blockIdx.z * 5 * np;
+  const int x = (int)blockIdx.x * (256 - 2 * N) - N + tid;
+  const int xc = d_clamp(x, 0, w - 1);
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool writer = tid >= N && tid < 256 - N && x < w;
+
+  float ring[2 * N + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * N + 1; ++j) ring[j] = I[(size_t)d_clamp(y0 - N + j, 0, h - 1) * w + xc];
+
+  for (int y = y0; y < y1; ++y) {
+    // vertical pass (float), same association as the scalar reference
+    float r0 = ring[N] * a.c.g[0], r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int k = 1; k <= N; ++k) {
+      float p = ring[N - k] + ring[N + k];
+      float t0 = r0 + a.c.g[k] * p;
+      float t1 = r2 + a.c.xxg[k] * p;
+      p = ring[N + k] - ring[N - k];
+      float t2 = r1 + a.c.xg[k] * p;
+      r0 = t0; r1 = t2; r2 = t1;
+    }
+    float(*s)[256] = sv[y & 1];
+    s[0][tid] = r0; s[1][tid] = r1; s[2][tid] = r2;
+    // prefetch the next source row while the exchange is in flight
+    float nxt = 0.f;
+    if (y + 1 < y1) nxt = I[(size_t)d_clamp(y + 1 + N, 0, h - 1) * w + xc];
+    __syncthreads();
+    if (writer) {
+      float g0 = a.c.g[0];
+      double b1 = s[0][tid] * g0, b2 = 0, b3 = s[1][tid] * g0, b4 = 0, b5 = s[2][tid] * g0, b6 = 0;
+#pragma unroll
+      for (int k = 1; k <= N; ++k) {
+        const float p0 = s[0][tid + k], m0 = s[0][tid - k];
+        const float p1 = s[1][tid + k], m1 = s[1][tid - k];
+        const float p2 = s[2][tid + k], m2 = s[2][tid - k];
+        double tg = p0 + m0;
+        g0 = a.c.g[k];
+        b1 += tg * g0;
+        b4 += tg * a.c.xxg[k];
+        b2 += (p0 - m0) * a.c.xg[k];
+        b3 += (p1 + m1) * g0;
+        b6 += (p1 - m1) * a.c.xg[k];
+        b5 += (p2 + m2) * g0;
+      }
+      const size_t o = (size_t)y * w + x;
+      R[o] = (float)(b3 * a.c.ig11);
+      R[np + o] = (float)(b2 * a.c.ig11);
+      R[2 * np + o] = (float)(b1 * a.c.ig03 + b5 * a.c.ig33);
+      R[3 * np + o] = (float)(b1 * a.c.ig03 + b4 * a.c.ig33);
+      R[4 * np + o] = (float)(b6 * a.c.ig55);
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + 1];
+    ring[2 * N] = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A5: FarnebackUpdateMatrices for one pixel.  R0/R1 planar with plane stride np.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
+                                                   size_t np, int h, int w, int x, int y, float dx, float dy,
+                                                   float m[5]) {
+  const size_t o = (size_t)y * w + x;
+  float fx = x + dx, fy = y + dy;
+  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  float r2, r3, r4, r5, r6;
+  fx -= x1; fy -= y1;
+  const float q0 = R0[o], q1 = R0[np + o], q2 = R0[2 * np + o], q3 = R0[3 * np + o], q4 = R0[4 * np + o];
+  if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const float* p = R1 + (size_t)y1 * w + x1;
+    r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    p += np;
+    r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    p += np;
+    r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    p += np;
+    r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    p += np;
+    r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    r4 = (q2 + r4) * 0.5f;
+    r5 = (q3 + r5) * 0.5f;
+    r6 = (q4 + r6) * 0.25f;
+  } else {
+    r2 = r3 = 0.f;
+    r4 = q2;
+    r5 = q3;
+    r6 = q4 * 0.5f;
+  }
+  r2 = (q0 - r2) * 0.5f;
+  r3 = (q1 - r3) * 0.5f;
+  r2 += r4 * dy + r6 * dx;
+  r3 += r6 * dy + r5 * dx;
+  constexpr int BORDER = 5;
+  if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+    // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}, selected with a compare rather than a
+    // local array index (keeps it out of scratch)
+    auto bsel = [](int i) -> float { return i < 2 ? 0.14f : 0.4472f; };
+    const float scale = (x < BORDER ? bsel(x) : 1.f) * (x >= w - BORDER ? bsel(w - x - 1) : 1.f) *
+                        (y < BORDER ? bsel(y) : 1.f) * (y >= h - BORDER ? bsel(h - y - 1) : 1.f);
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+  }
+  m[0] = r4 * r4 + r6 * r6;
+  m[1] = (r4 + r5) * r6;
+  m[2] = r5 * r5 + r6 * r6;
+  m[3] = r4 * r2 + r6 * r3;
+  m[4] = r6 * r2 + r5 * r3;
+}
+
+// Initial matrices of a level; the flow is zero (coarsest level), a given field, or the
+// previous level's flow resized with INTER_LINEAR and multiplied by 1/pyr_scale.
+struct UMArgs {
+  const float* R;            // frame-indexed planar expansions of this level: frame f at R + f*5*np
+  const int* pairs;          // device (n_pairs x 2) frame slots, or null => R0 = R, R1 = R1_direct
+  const float* R1_direct;
+  const float* flow;         // (h,w,2) per pair or null
+  const float* coarse;       // (ch,cw,2) per pair or null
+  float* M;                  // per pair 5 x np
+  int h, w, ch, cw;
+  double scale_x, scale_y;   // cw/w, ch/h as cv::resize computes them (1/inv_scale)
+  float mul;                 // 1/pyr_scale
+};
+
+__device__ __forceinline__ float2 ld_flow(const float* f, int idx) {
+  return *reinterpret_cast<const float2*>(f + 2 * (size_t)idx);
+}
+
+__global__ __launch_bounds__(256) void k_update_matrices(UMArgs a) {
+  const int h = a.h, w = a.w;
+  const size_t np = (size_t)h * w;
+  const int pr = blockIdx.y;
+  const float* R0;
+  const float* R1;
+  if (a.pairs) {
+    R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * np;
+    R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * np;
+  } else {
+    R0 = a.R;
+    R1 = a.R1_direct;
+  }
+  float* __restrict__ M = a.M + (size_t)pr * 5 * np;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+    float dx = 0.f, dy = 0.f;
+    if (a.coarse) {
+      const float* C = a.coarse + (size_t)pr * 2 * a.ch * a.cw;
+      // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
+      float fx = (float)((x + 0.5) * a.scale_x - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0.f; sx = 0; }
+      if (sx >= a.cw - 1) { fx = 0.f; sx = a.cw - 1; }
+      float fy = (float)((y + 0.5) * a.scale_y - 0.5);
+      int sy = (int)floorf(fy);
+      fy -= sy;
+      const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
+      const float a1 = fx, a0 = 1.f - fx, b0 = 1.f - fy, b1 = fy;
+      float2 ta, tb;
+      if (sx + 1 < a.cw) {
+        float2 p = ld_flow(C, ya * a.cw + sx), q = ld_flow(C, ya * a.cw + sx + 1);
+        ta.x = p.x * a0 + q.x * a1; ta.y = p.y * a0 + q.y * a1;
+        p = ld_flow(C, yb * a.cw + sx); q = ld_flow(C, yb * a.cw + sx + 1);
+        tb.x = p.x * a0 + q.x * a1; tb.y = p.y * a0 + q.y * a1;
+      } else {
+        float2 p = ld_flow(C, ya * a.cw + sx);
+        ta.x = p.x * 1.f; ta.y = p.y * 1.f;
+        p = ld_flow(C, yb * a.cw + sx);
+        tb.x = p.x * 1.f; tb.y = p.y * 1.f;
+      }
+      dx = (ta.x * b0 + tb.x * b1) * a.mul;
+      dy = (ta.y * b0 + tb.y * b1) * a.mul;
+    } else if (a.flow) {
+      float2 f = ld_flow(a.flow + (size_t)pr * 2 * np, (int)i);
+      dx = f.x; dy = f.y;
+    }
+    float m[5];
+    update_matrices_px(R0, R1, np, h, w, x, y, dx, dy, m);
+    M[i] = m[0]; M[np + i] = m[1]; M[2 * np + i] = m[2]; M[3 * np + i] = m[3]; M[4 * np + i] = m[4];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A6 (+A5 fused): box blur of M (double running column sums in registers, row exchange through
+// LDS, direct horizontal window sum in double), 2x2 solve, then either the flow store (last
+// iteration) or UpdateMatrices with the fresh flow into the other M buffer.
+// ---------------------------------------------------------------------------------------------
+struct BlurArgs {
+  const float* R;        // frame-indexed expansions (see UMArgs), or direct R0/R1
+  const int* pairs;
+  const float* R1_direct;
+  const float* Min;      // per pair 5 x np
+  float* Mout;           // per pair 5 x np (update) -- never aliases Min
+  float* flow;           // per pair (h,w,2) contiguous, or
+  float* const* flow_ptrs;  // device table of per-pair output frames (used when non-null)
+  int h, w, rows_per_seg, m;  // m = block_size/2
+  int update, write_flow;
+  double scale;          // 1/(block_size^2)
+};
+
+constexpr int BLUR_T = 256;
+
+__global__ __launch_bounds__(BLUR_T) void k_blur_update(BlurArgs a) {
+  __shared__ double sv[2][5][BLUR_T];
+  const int tid = threadIdx.x;
+  const int h = a.h, w = a.w, m = a.m;
+  const size_t np = (size_t)h * w;
+  const int pr = blockIdx.z;
+  const float* __restrict__ Min = a.Min + (size_t)pr * 5 * np;
+  const int x = (int)blockIdx.x * (BLUR_T - 2 * m) - m + tid;
+  const int xc = d_clamp(x, 0, w - 1);
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool writer = tid >= m && tid < BLUR_T - m && x < w;
+
+  const float* R0 = nullptr;
+  const float* R1 = nullptr;
+  float* Mout = nullptr;
+  if (a.update) {
+    if (a.pairs) {
+      R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * np;
+      R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * np;
+    } else {
+      R0 = a.R;
+      R1 = a.R1_direct;
+    }
+    Mout = a.Mout + (size_t)pr * 5 * np;
+  }
+  float* flow = nullptr;
+  if (a.write_flow) flow = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow + (size_t)pr * 2 * np;
+
+  // window sum for row y0: rows y0-m .. y0+m with replicated borders
+  double vs[5] = {0, 0, 0, 0, 0};
+  if (y0 == 0) {
+    // the top segment reproduces the reference's initialisation order exactly:
+    // float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = (double)(Min[c * np + xc] * (float)(m + 2));
+    for (int yy = 1; yy < m; ++yy) {
+      const size_t o = (size_t)min(yy, h - 1) * w + xc;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)Min[c * np + o];
+    }
+    const size_t oa = (size_t)min(m, h - 1) * w + xc;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float d = Min[c * np + oa] - Min[c * np + xc];
+      vs[c] += d;
+    }
+  } else {
+    for (int dy = -m; dy <= m; ++dy) {
+      const size_t o = (size_t)d_clamp(y0 + dy, 0, h - 1) * w + xc;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)Min[c * np + o];
+    }
+  }
+
+  for (int y = y0; y < y1; ++y) {
+    double(*s)[BLUR_T] = sv[y & 1];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s[c][tid] = vs[c];
+    // slide the window for the next row: += float(M[y+1+m] - M[y-m])
+    if (y + 1 < y1) {
+      const size_t oa = (size_t)d_clamp(y + 1 + m, 0, h - 1) * w + xc;
+      const size_t ob = (size_t)d_clamp(y - m, 0, h - 1) * w + xc;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float d = Min[c * np + oa] - Min[c * np + ob];
+        vs[c] += d;
+      }
+    }
+    __syncthreads();
+    if (writer) {
+      double g[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        double t = s[c][tid - m];
+        for (int k = -m + 1; k <= m; ++k) t += s[c][tid + k];
+        g[c] = t * a.scale;
+      }
+      const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+      const float u = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+      const float v = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+      const size_t o = (size_t)y * w + x;
+      if (flow) *reinterpret_cast<float2*>(flow + 2 * o) = make_float2(u, v);
+      if (a.update) {
+        float mm[5];
+        update_matrices_px(R0, R1, np, h, w, x, y, u, v, mm);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Mout[c * np + o] = mm[c];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+int check_params(st_ctx* ctx, const st_fb_params& p, int h, int w) {
+  if (h <= 0 || w <= 0) return st_set_error(ctx, ST_ERR_INVALID, "farneback: bad frame size %dx%d", w, h);
+  if (p.flags != 0) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: flags=%d (only 0 implemented)", p.flags);
+  if (p.fast_pyramids) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: fastPyramids not implemented");
+  if (!(p.pyr_scale > 0 && p.pyr_scale < 1)) return st_set_error(ctx, ST_ERR_INVALID, "farneback: pyr_scale must be in (0,1)");
+  if (p.poly_n != 5 && p.poly_n != 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: poly_n=%d (5 or 7)", p.poly_n);
+  if (p.win_size < 1 || p.win_size > 63 || !(p.win_size & 1))
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: win_size=%d (odd, <= 63)", p.win_size);
+  if (p.num_iters < 1 || p.num_levels < 0) return st_set_error(ctx, ST_ERR_INVALID, "farneback: bad iteration/level count");
+  if (p.gray_bits != 14 && p.gray_bits != 15) return st_set_error(ctx, ST_ERR_INVALID, "farneback: gray_bits must be 14 or 15");
+  int levels = fb_levels(h, w, p);
+  for (int k = 0; k <= levels; ++k) {
+    LevelGeom g = fb_level_geom(h, w, p, k);
+    if (g.ksize > kMaxTaps - 1) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: pyramid kernel size %d too large", g.ksize);
+    if (g.lh < 1 || g.lw < 1) return st_set_error(ctx, ST_ERR_INVALID, "farneback: empty pyramid level");
+  }
+  return ST_OK;
+}
+
+int rows_per_segment(st_ctx* ctx, int h, int strips, int batch, int halo) {
+  // enough workgroups to fill the chip (>= 8 per CU) without making the per-segment halo dominate
+  long long target = (long long)ctx->num_cus * 8;
+  long long per = (long long)strips * batch;
+  long long segs = (target + per - 1) / per;
+  if (segs < 1) segs = 1;
+  int rows = (int)((h + segs - 1) / segs);
+  int min_rows = 4 * halo;
+  if (rows < min_rows) rows = min_rows;
+  if (rows > h) rows = h;
+  return rows;
+}
+
+int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int h, int w, int bits, uint8_t* gray) {
+  GrayArgs a;
+  a.frames = frames_table_dev;
+  a.gray = gray;
+  a.npix = h * w;
+  if (bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }
+  a.shift = bits;
+  a.rnd = 1 << (bits - 1);
+  int bx = (a.npix + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  st_timed t(ctx, ST_K_GRAY);
+  hipLaunchKernelGGL(k_gray, dim3(bx, n), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const LevelGeom& g, float* img) {
+  PyrArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gray = gray; a.img = img;
+  a.sh = h; a.sw = w; a.dh = g.lh; a.dw = g.lw; a.ks = g.ksize;
+  gaussian_kernel(g.ksize, g.sigma, a.taps);
+  const double inv_sx = (double)g.lw / w, inv_sy = (double)g.lh / h;
+  a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
+  if (g.lh == h && g.lw == w) a.mode = PYR_COPY;
+  else if (w == 2 * g.lw && h == 2 * g.lh) a.mode = PYR_AREA2;
+  else a.mode = PYR_LINEAR;
+  const int r = g.ksize / 2;
+  a.max_rows = (int)std::ceil((PYR_OH - 1) * a.scale_y) + 3 + 2 * r + 1;
+  size_t lds = sizeof(float) * (size_t)a.max_rows * 2 * PYR_OW;
+  if (lds > 64 * 1024) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: pyramid tile needs %zu B of LDS", lds);
+  dim3 grid((g.lw + PYR_OW - 1) / PYR_OW, (g.lh + PYR_OH - 1) / PYR_OH, n);
+  st_timed t(ctx, ST_K_PYR);
+  hipLaunchKernelGGL(k_pyr, grid, dim3(256), lds, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R) {
+  PolyArgs a;
+  a.img = img; a.R = R; a.h = h; a.w = w;
+  poly_prepare(poly_n, poly_sigma, &a.c);
+  const int strips = (w + (256 - 2 * poly_n) - 1) / (256 - 2 * poly_n);
+  a.rows_per_seg = rows_per_segment(ctx, h, strips, n, 2 * poly_n + 1);
+  dim3 grid(strips, (h + a.rows_per_seg - 1) / a.rows_per_seg, n);
+  st_timed t(ctx, ST_K_POLYEXP);
+  if (poly_n == 5) hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_polyexp<7>, grid, dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
+  const size_t np = (size_t)a.h * a.w;
+  int bx = (int)((np + 255) / 256);
+  if (bx > 4096) bx = 4096;
+  st_timed t(ctx, ST_K_UPDATE_MATRICES);
+  hipLaunchKernelGGL(k_update_matrices, dim3(bx, n_pairs), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
+  const int strips = (a.w + (BLUR_T - 2 * a.m) - 1) / (BLUR_T - 2 * a.m);
+  a.rows_per_seg = rows_per_segment(ctx, a.h, strips, n_pairs, 2 * a.m + 1);
+  dim3 grid(strips, (a.h + a.rows_per_seg - 1) / a.rows_per_seg, n_pairs);
+  st_timed t(ctx, ST_K_BLUR_UPDATE);
+  hipLaunchKernelGGL(k_blur_update, grid, dim3(BLUR_T), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+// Scratch needed to process `nf` distinct frames and `npairs` pairs in one pass.
+size_t pass_bytes(int h, int w, const st_fb_params& p, int nf, int npairs) {
+  const int levels = fb_levels(h, w, p);
+  size_t np0 = (size_t)h * w;
+  size_t maxCoarse = 0;
+  for (int k = 0; k <= levels; ++k) {
+    LevelGeom g = fb_level_geom(h, w, p, k);
+    size_t npk = (size_t)g.lh * g.lw;
+    if (k >= 1 && npk > maxCoarse) maxCoarse = npk;
+  }
+  size_t b = 0;
+  b += st_align_up(np0 * nf);                        // gray
+  b += st_align_up(sizeof(float) * np0 * nf);        // I (reused per level)
+  for (int k = 0; k <= levels; ++k) {
+    LevelGeom g = fb_level_geom(h, w, p, k);
+    b += st_align_up(sizeof(float) * 5 * (size_t)g.lh * g.lw * nf);  // R_k
+  }
+  b += 2 * st_align_up(sizeof(float) * 5 * np0 * npairs);            // M ping/pong
+  b += 2 * st_align_up(sizeof(float) * 2 * (maxCoarse ? maxCoarse : 1) * npairs);  // coarse flows
+  b += st_align_up(sizeof(void*) * nf) + st_align_up(sizeof(int) * 2 * npairs) + st_align_up(sizeof(void*) * npairs);
+  return b + 4096;
+}
+
+int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int32_t* pairs, int npairs, int h, int w,
+                   const st_fb_params& p, float* const* outs) {
+  const int levels = fb_levels(h, w, p);
+  const size_t np0 = (size_t)h * w;
+  ST_TRY(st_ws_reserve(ctx, pass_bytes(h, w, p, nf, npairs)));
+  uint8_t* gray = (uint8_t*)st_ws_alloc(ctx, np0 * nf);
+  float* img = (float*)st_ws_alloc(ctx, sizeof(float) * np0 * nf);
+  std::vector<float*> R(levels + 1);
+  std::vector<LevelGeom> geom(levels + 1);
+  size_t maxCoarse = 1;
+  for (int k = 0; k <= levels; ++k) {
+    geom[k] = fb_level_geom(h, w, p, k);
+    size_t npk = (size_t)geom[k].lh * geom[k].lw;
+    if (k >= 1 && npk > maxCoarse) maxCoarse = npk;
+    R[k] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * npk * nf);
+  }
+  float* M[2];
+  M[0] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * np0 * npairs);
+  M[1] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * np0 * npairs);
+  float* cflow[2];
+  cflow[0] = (float*)st_ws_alloc(ctx, sizeof(float) * 2 * maxCoarse * npairs);
+  cflow[1] = (float*)st_ws_alloc(ctx, sizeof(float) * 2 * maxCoarse * npairs);
+  const uint8_t** d_frames = (const uint8_t**)st_ws_alloc(ctx, sizeof(void*) * nf);
+  int* d_pairs = (int*)st_ws_alloc(ctx, sizeof(int) * 2 * npairs);
+  float** d_outs = (float**)st_ws_alloc(ctx, sizeof(void*) * npairs);
+  if (!gray || !img || !M[0] || !M[1] || !cflow[0] || !cflow[1] || !d_frames || !d_pairs || !d_outs || !R[levels])
+    return st_set_error(ctx, ST_ERR_OOM, "farneback: scratch plan exhausted");
+  ST_HIP(ctx, hipMemcpyAsync(d_frames, frames, sizeof(void*) * nf, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_outs, outs, sizeof(void*) * npairs, hipMemcpyHostToDevice, ctx->stream));
+
+  // per-frame stages: each distinct frame once
+  ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray));
+  for (int k = levels; k >= 0; --k) {
+    ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
+    ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
+  }
+  // per-pair stages, coarse to fine
+  int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
+  for (int k = levels; k >= 0; --k) {
+    const int lh = geom[k].lh, lw = geom[k].lw;
+    UMArgs u;
+    memset(&u, 0, sizeof(u));
+    u.R = R[k]; u.pairs = d_pairs; u.M = M[0]; u.h = lh; u.w = lw;
+    if (k < levels) {
+      u.coarse = cflow[cur];
+      u.ch = geom[k + 1].lh; u.cw = geom[k + 1].lw;
+      u.scale_x = 1. / ((double)lw / u.cw);
+      u.scale_y = 1. / ((double)lh / u.ch);
+      u.mul = (float)(1. / p.pyr_scale);
+    }
+    ST_TRY(launch_update_matrices(ctx, u, npairs));
+    int mi = 0;
+    for (int it = 0; it < p.num_iters; ++it) {
+      const bool last = it == p.num_iters - 1;
+      BlurArgs b;
+      memset(&b, 0, sizeof(b));
+      b.R = R[k]; b.pairs = d_pairs; b.Min = M[mi]; b.Mout = M[mi ^ 1];
+      b.h = lh; b.w = lw; b.m = p.win_size / 2;
+      b.update = !last; b.write_flow = last;
+      b.scale = 1. / ((double)p.win_size * p.win_size);
+      if (last) {
+        if (k == 0) b.flow_ptrs = d_outs; else b.flow = cflow[cur ^ 1];
+      }
+      ST_TRY(launch_blur(ctx, b, npairs));
+      mi ^= 1;
+    }
+    cur ^= 1;
+  }
+  return ST_OK;
+}
+
+}  // namespace
+
+ST_EXPORT void st_fb_params_default(st_fb_params* p) {
+  if (!p) return;
+  p->num_levels = 3; p->pyr_scale = 0.5; p->fast_pyramids = 0; p->win_size = 15; p->num_iters = 3;
+  p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0; p->gray_bits = 15;
+}
+
+ST_EXPORT int st_fb_levels(int h, int w, const st_fb_params* params) {
+  if (!params || h <= 0 || w <= 0) return -1;
+  return fb_levels(h, w, *params);
+}
+
+ST_EXPORT int st_fb_level_geom(int h, int w, const st_fb_params* params, int level, int* lh, int* lw, double* sigma,
+                               int* ksize) {
+  if (!params || h <= 0 || w <= 0 || level < 0) return ST_ERR_INVALID;
+  LevelGeom g = fb_level_geom(h, w, *params, level);
+  if (lh) *lh = g.lh;
+  if (lw) *lw = g.lw;
+  if (sigma) *sigma = g.sigma;
+  if (ksize) *ksize = g.ksize;
+  return ST_OK;
+}
+
+ST_EXPORT int st_farneback_pairs(st_ctx* ctx, const uint8_t* const* frames_dev, int n_frames, const int32_t* pairs,
+                                 int n_pairs, int h, int w, const st_fb_params* params, float* const* flow_out_dev) {
+  ST_TRY(st_enter(ctx));
+  st_fb_params p;
+  if (params) p = *params; else st_fb_params_default(&p);
+  if (n_pairs < 0 || n_frames < 0) return st_set_error(ctx, ST_ERR_INVALID, "farneback: negative count");
+  ST_TRY(check_params(ctx, p, h, w));
+  if (n_pairs == 0) return ST_OK;
+  if (!frames_dev || !pairs || !flow_out_dev) return st_set_error(ctx, ST_ERR_INVALID, "farneback: null table");
+  for (int i = 0; i < n_pairs; ++i) {
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= n_frames || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= n_frames)
+      return st_set_error(ctx, ST_ERR_INVALID, "farneback: pair %d indexes outside [0,%d)", i, n_frames);
+    if (!flow_out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "farneback: output %d is null", i);
+  }
+  // Split into passes that fit the scratch limit.  A pass covers a run of pairs and the distinct
+  // frames they touch (remapped to dense slots), so frames shared by consecutive pairs are
+  // expanded once per pass.
+  int start = 0;
+  std::vector<int> slot(n_frames);
+  while (start < n_pairs) {
+    int count = n_pairs - start;
+    std::vector<const uint8_t*> pf;
+    std::vector<int32_t> pp;
+    for (;;) {
+      std::fill(slot.begin(), slot.end(), -1);
+      pf.clear(); pp.clear();
+      for (int i = start; i < start + count; ++i)
+        for (int e = 0; e < 2; ++e) {
+          int f = pairs[2 * i + e];
+          if (slot[f] < 0) {
+            if (!frames_dev[f]) return st_set_error(ctx, ST_ERR_INVALID, "farneback: frame %d is null", f);
+            slot[f] = (int)pf.size();
+            pf.push_back(frames_dev[f]);
+          }
+          pp.push_back(slot[f]);
+        }
+      if (pass_bytes(h, w, p, (int)pf.size(), count) <= ctx->ws_limit || count == 1) break;
+      count = (count + 1) / 2;
+    }
+    ST_TRY(farneback_pass(ctx, pf.data(), (int)pf.size(), pp.data(), count, h, w, p, flow_out_dev + start));
+    start += count;
+  }
+  return ST_OK;
+}
+
+// ---- stage-level entry points ----------------------------------------------------------------
+ST_EXPORT int st_gray_u8(st_ctx* ctx, const uint8_t* rgb_dev, int h, int w, int gray_bits, uint8_t* gray_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!rgb_dev || !gray_dev || h <= 0 || w <= 0 || (gray_bits != 14 && gray_bits != 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "gray: bad arguments");
+  ST_TRY(st_ws_reserve(ctx, 4096));
+  const uint8_t** t = (const uint8_t**)st_ws_alloc(ctx, sizeof(void*));
+  ST_HIP(ctx, hipMemcpyAsync(t, &rgb_dev, sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  return launch_gray(ctx, t, 1, h, w, gray_bits, gray_dev);
+}
+
+ST_EXPORT int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w, const st_fb_params* params, int level,
+                              float* img_dev) {
+  ST_TRY(st_enter(ctx));
+  st_fb_params p;
+  if (params) p = *params; else st_fb_params_default(&p);
+  if (!gray_dev || !img_dev || level < 0) return st_set_error(ctx, ST_ERR_INVALID, "pyr: bad arguments");
+  ST_TRY(check_params(ctx, p, h, w));
+  LevelGeom g = fb_level_geom(h, w, p, level);
+  if (g.ksize > kMaxTaps - 1 || g.lh < 1 || g.lw < 1) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "pyr: level %d unsupported", level);
+  return launch_pyr(ctx, gray_dev, 1, h, w, g, img_dev);
+}
+
+ST_EXPORT int st_fb_polyexp(st_ctx* ctx, const float* img_dev, int h, int w, int poly_n, double poly_sigma, float* r_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!img_dev || !r_dev || h <= 0 || w <= 0) return st_set_error(ctx, ST_ERR_INVALID, "polyexp: bad arguments");
+  if (poly_n != 5 && poly_n != 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: poly_n=%d (5 or 7)", poly_n);
+  return launch_polyexp(ctx, img_dev, 1, h, w, poly_n, poly_sigma, r_dev);
+}
+
+ST_EXPORT int st_fb_update_matrices(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* flow_dev,
+                                    const float* coarse_flow_dev, int ch, int cw, double pyr_scale, int h, int w,
+                                    float* m_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!r0_dev || !r1_dev || !m_dev || h <= 0 || w <= 0) return st_set_error(ctx, ST_ERR_INVALID, "update_matrices: bad arguments");
+  UMArgs u;
+  memset(&u, 0, sizeof(u));
+  u.R = r0_dev; u.R1_direct = r1_dev; u.M = m_dev; u.h = h; u.w = w;
+  if (coarse_flow_dev) {
+    if (ch <= 0 || cw <= 0 || !(pyr_scale > 0)) return st_set_error(ctx, ST_ERR_INVALID, "update_matrices: bad coarse geometry");
+    u.coarse = coarse_flow_dev; u.ch = ch; u.cw = cw;
+    u.scale_x = 1. / ((double)w / cw);
+    u.scale_y = 1. / ((double)h / ch);
+    u.mul = (float)(1. / pyr_scale);
+  } else {
+    u.flow = flow_dev;
+  }
+  return launch_update_matrices(ctx, u, 1);
+}
+
+ST_EXPORT int st_fb_update_flow_blur(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* m_in_dev, int h,
+                                     int w, int block_size, int update, float* flow_out_dev, float* m_out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!m_in_dev || !flow_out_dev || h <= 0 || w <= 0) return st_set_error(ctx, ST_ERR_INVALID, "update_flow_blur: bad arguments");
+  if (block_size < 1 || block_size > 63 || !(block_size & 1)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "update_flow_blur: block_size=%d", block_size);
+  if (update && (!r0_dev || !r1_dev || !m_out_dev || m_out_dev == m_in_dev))
+    return st_set_error(ctx, ST_ERR_INVALID, "update_flow_blur: update needs R0, R1 and a distinct m_out");
+  BlurArgs b;
+  memset(&b, 0, sizeof(b));
+  b.R = r0_dev; b.R1_direct = r1_dev; b.Min = m_in_dev; b.Mout = m_out_dev; b.flow = flow_out_dev;
+  b.h = h; b.w = w; b.m = block_size / 2; b.update = update ? 1 : 0; b.write_flow = 1;
+  b.scale = 1. / ((double)block_size * block_size);
+  return launch_blur(ctx, b, 1);
+}

@@ -1,0 +1,173 @@
+// Per-channel histogram of interleaved U8x3 frames.
+//
+// Replaces the arithmetic of HistogramKernelCPU::execute
+// (/root/reference/scannertools/scannertools_cpp/imgproc/histogram_kernel_cpu.cpp:25-45):
+// three cv::calcHist passes per frame become ONE pass over the frame's bytes.
+//
+// HBM-bound integer work: each frame byte is read exactly once with 16-B-per-lane coalesced
+// loads; counts go to wave-private 3x256 LDS sub-histograms (ds_add_u32, no return value),
+// are summed across the workgroup's waves, folded to `bins` and committed with one global
+// atomic per non-empty bin per workgroup.  Algorithmic bytes per frame = 3*w*h + 3*bins*4.
+#include "st_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+struct FrameSrc {
+  const uint8_t* const* ptrs;  // device table of frame pointers, or null
+  const uint8_t* base;         // strided stream
+  size_t stride;
+};
+
+__device__ __forceinline__ void lds_inc(unsigned* p) {
+  __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Count the 16 bytes of q; c0/c1/c2 are the sub-histogram offsets (channel*256) of bytes
+// 0,1,2 (mod 3) of this vector.
+__device__ __forceinline__ void count16(unsigned* h, uint4 q, unsigned c0, unsigned c1, unsigned c2) {
+  lds_inc(h + c0 + (q.x & 0xff));
+  lds_inc(h + c1 + ((q.x >> 8) & 0xff));
+  lds_inc(h + c2 + ((q.x >> 16) & 0xff));
+  lds_inc(h + c0 + (q.x >> 24));
+  lds_inc(h + c1 + (q.y & 0xff));
+  lds_inc(h + c2 + ((q.y >> 8) & 0xff));
+  lds_inc(h + c0 + ((q.y >> 16) & 0xff));
+  lds_inc(h + c1 + (q.y >> 24));
+  lds_inc(h + c2 + (q.z & 0xff));
+  lds_inc(h + c0 + ((q.z >> 8) & 0xff));
+  lds_inc(h + c1 + ((q.z >> 16) & 0xff));
+  lds_inc(h + c2 + (q.z >> 24));
+  lds_inc(h + c0 + (q.w & 0xff));
+  lds_inc(h + c1 + ((q.w >> 8) & 0xff));
+  lds_inc(h + c2 + ((q.w >> 16) & 0xff));
+  lds_inc(h + c0 + (q.w >> 24));
+}
+
+__global__ __launch_bounds__(kThreads) void k_hist_u8c3(FrameSrc src, long long nbytes, int chunks, int bins,
+                                                        int32_t* __restrict__ out) {
+  __shared__ unsigned sh[kWaves * 768];
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const uint8_t* p = src.ptrs ? src.ptrs[frame] : src.base + (size_t)frame * src.stride;
+
+  for (int i = tid; i < kWaves * 768; i += kThreads) sh[i] = 0;
+  __syncthreads();
+  unsigned* my = sh + (tid >> 6) * 768;
+
+  // [0, head) and [tail, nbytes) are the unaligned ends; [head, tail) is read as uint4.
+  long long head = (long long)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > nbytes) head = nbytes;
+  const long long nvec = (nbytes - head) >> 4;
+  const long long tail = head + (nvec << 4);
+  const uint4* vp = reinterpret_cast<const uint4*>(p + head);
+
+  const long long per = (nvec + chunks - 1) / chunks;
+  const long long v0 = (long long)chunk * per;
+  long long v1 = v0 + per;
+  if (v1 > nvec) v1 = nvec;
+
+  // Channel of byte j of vector i is (head + 16 i + j) % 3 = (head + i + j) % 3.  A thread's
+  // vector index advances by 256 = 1 (mod 3) per step, so three steps cycle the phase.
+  long long i = v0 + tid;
+  unsigned ph = (unsigned)((head + i) % 3);
+  const unsigned o0 = ph * 256, o1 = ((ph + 1) % 3) * 256, o2 = ((ph + 2) % 3) * 256;
+  for (; i + 2 * kThreads < v1; i += 3 * kThreads) {
+    uint4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads];
+    count16(my, a, o0, o1, o2);
+    count16(my, b, o1, o2, o0);
+    count16(my, c, o2, o0, o1);
+  }
+  if (i < v1) {
+    uint4 a = vp[i];
+    count16(my, a, o0, o1, o2);
+    if (i + kThreads < v1) {
+      uint4 b = vp[i + kThreads];
+      count16(my, b, o1, o2, o0);
+    }
+  }
+  if (chunk == 0) {
+    for (long long b = tid; b < head; b += kThreads) lds_inc(my + (unsigned)(b % 3) * 256 + p[b]);
+    for (long long b = tail + tid; b < nbytes; b += kThreads) lds_inc(my + (unsigned)(b % 3) * 256 + p[b]);
+  }
+  __syncthreads();
+
+  int32_t* o = out + (size_t)frame * 3 * bins;
+  if (bins == 256) {
+    for (int b = tid; b < 768; b += kThreads) {
+      unsigned s = sh[b] + sh[768 + b] + sh[2 * 768 + b] + sh[3 * 768 + b];
+      if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + b, s);
+    }
+  } else {
+    // fold the four copies into copy 0, then one thread per output bin sums its value range
+    for (int b = tid; b < 768; b += kThreads) sh[b] += sh[768 + b] + sh[2 * 768 + b] + sh[3 * 768 + b];
+    __syncthreads();
+    for (int ob = tid; ob < 3 * bins; ob += kThreads) {
+      const int ch = ob / bins, bin = ob - ch * bins;
+      // values v with floor(v*bins/256) == bin: v in [ceil(256*bin/bins), ceil(256*(bin+1)/bins))
+      const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
+      unsigned s = 0;
+      for (int v = lo; v < hi; ++v) s += sh[ch * 256 + v];
+      if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, s);
+    }
+  }
+}
+
+int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
+  const long long nbytes = 3LL * h * w;
+  const long long nvec = nbytes / 16;
+  long long target = (long long)ctx->num_cus * 16;
+  long long chunks = (target + n - 1) / n;
+  long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  ST_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * 3 * (size_t)bins * n, ctx->stream));
+  // grid.y is limited to 65535 frames per launch
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    int nf = n - f0 < 65535 ? n - f0 : 65535;
+    FrameSrc s = src;
+    if (s.ptrs) s.ptrs += f0; else s.base += (size_t)f0 * s.stride;
+    st_timed t(ctx, ST_K_HIST);
+    hipLaunchKernelGGL(k_hist_u8c3, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+                       nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+
+int hist_check(st_ctx* ctx, int n, int h, int w, int bins, const void* out) {
+  if (n < 0 || h <= 0 || w <= 0 || bins < 1 || bins > 256 || (n > 0 && !out))
+    return st_set_error(ctx, ST_ERR_INVALID, "histogram: bad arguments (n=%d h=%d w=%d bins=%d)", n, h, w, bins);
+  return ST_OK;
+}
+
+}  // namespace
+
+ST_EXPORT int st_hist_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int bins,
+                                 int32_t* out_dev) {
+  ST_TRY(st_enter(ctx));
+  ST_TRY(hist_check(ctx, n, h, w, bins, out_dev));
+  if (n == 0) return ST_OK;
+  if (!frames_dev) return st_set_error(ctx, ST_ERR_INVALID, "histogram: null frame table");
+  for (int i = 0; i < n; ++i)
+    if (!frames_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "histogram: frame %d is null", i);
+  ST_TRY(st_ws_reserve(ctx, st_align_up(sizeof(void*) * (size_t)n)));
+  const uint8_t** table = (const uint8_t**)st_ws_alloc(ctx, sizeof(void*) * (size_t)n);
+  ST_HIP(ctx, hipMemcpyAsync(table, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  FrameSrc src{table, nullptr, 0};
+  return hist_launch(ctx, src, n, h, w, bins, out_dev);
+}
+
+ST_EXPORT int st_hist_u8c3_strided(st_ctx* ctx, const uint8_t* base_dev, size_t frame_stride_bytes, int n, int h,
+                                   int w, int bins, int32_t* out_dev) {
+  ST_TRY(st_enter(ctx));
+  ST_TRY(hist_check(ctx, n, h, w, bins, out_dev));
+  if (n == 0) return ST_OK;
+  if (!base_dev || frame_stride_bytes < (size_t)3 * h * w)
+    return st_set_error(ctx, ST_ERR_INVALID, "histogram: bad base/stride");
+  FrameSrc src{nullptr, base_dev, frame_stride_bytes};
+  return hist_launch(ctx, src, n, h, w, bins, out_dev);
+}

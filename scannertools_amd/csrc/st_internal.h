@@ -1,0 +1,76 @@
+// Internal declarations shared by the translation units of libscannertools_hip.so.
+#ifndef ST_INTERNAL_H_
+#define ST_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "scannertools_hip.h"
+
+#define ST_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct st_timing_slot {
+  std::vector<hipEvent_t> starts, stops;  // pooled events, one pair per recorded launch
+  size_t used = 0;
+  int launches = 0;
+  double total_ms = 0.0;
+};
+
+struct st_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // bump-allocated scratch
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  size_t ws_limit = (size_t)24 << 30;
+  size_t ws_off = 0;
+  // small device table for pointer arrays
+  unsigned timing_mask = 0;
+  st_timing_slot timing[ST_K_COUNT];
+  std::string last_error;
+  int num_cus = 256;
+};
+
+int st_set_error(st_ctx* ctx, int status, const char* fmt, ...);
+
+#define ST_HIP(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return st_set_error((ctx), ST_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                          hipGetErrorString(_e), __FILE__, __LINE__);                       \
+  } while (0)
+
+#define ST_TRY(expr)              \
+  do {                            \
+    int _s = (expr);              \
+    if (_s != ST_OK) return _s;   \
+  } while (0)
+
+// Enter an API call: null check + select device.
+int st_enter(st_ctx* ctx);
+
+// Scratch: reset at the start of a call, then bump-allocate (256-B aligned).  Grows the
+// backing allocation when needed (synchronising the stream first).
+int st_ws_reserve(st_ctx* ctx, size_t total_bytes);
+void st_ws_reset(st_ctx* ctx);
+void* st_ws_alloc(st_ctx* ctx, size_t bytes);  // nullptr if the reservation is exhausted
+inline size_t st_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Timing brackets for kernel class `id` (no-ops unless enabled in timing_mask).
+int st_time_begin(st_ctx* ctx, int id);
+int st_time_end(st_ctx* ctx, int id);
+
+struct st_timed {
+  st_ctx* ctx;
+  int id;
+  st_timed(st_ctx* c, int k) : ctx(c), id(k) { st_time_begin(ctx, id); }
+  ~st_timed() { st_time_end(ctx, id); }
+};
+
+#endif  // ST_INTERNAL_H_

@@ -1,0 +1,255 @@
+"""Device-side ops: thin Python over the C ABI (include/scannertools_hip.h).
+
+PyTorch is used only for device memory and streams: inputs/outputs are ``torch`` CUDA tensors
+whose ``data_ptr()`` is handed to the library, and kernels are enqueued on torch's current
+stream of the context's device.  All arithmetic happens in the HIP kernels under ``csrc/``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import FbParams, StError, default_params  # noqa: F401
+
+
+def _require_cuda(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA tensor (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+class HipContext:
+    """One ``st_ctx``: per-kernel-instance state (stream binding, scratch).  Mirrors the role of
+    a Scanner kernel instance's private GPU state (optical_flow_kernel_gpu.cpp:101-107)."""
+
+    def __init__(self, device=0, workspace_limit=None):
+        self._L = _native.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipContext needs a GPU: torch.cuda.is_available() is False")
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        h = ctypes.c_void_p()
+        st = self._L.st_ctx_create(self.device.index, ctypes.byref(h))
+        if st != 0:
+            raise StError(st, "st_ctx_create(%d) failed" % self.device.index)
+        self._h = h
+        self._bound_stream = None
+        if workspace_limit:
+            self._check(self._L.st_ctx_set_workspace_limit(self._h, int(workspace_limit)))
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.st_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st):
+        if st != 0:
+            raise StError(st, (self._L.st_ctx_last_error(self._h) or b"").decode() or
+                          self._L.st_status_string(st).decode())
+
+    def _bind(self):
+        """Enqueue on torch's current stream so that torch ops and events order with ours."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound_stream:
+            self._check(self._L.st_ctx_set_stream(self._h, ctypes.c_void_p(s)))
+            self._bound_stream = s
+
+    def sync(self):
+        self._check(self._L.st_ctx_sync(self._h))
+
+    def release_workspace(self):
+        self._check(self._L.st_ctx_release_workspace(self._h))
+
+    def timing_enable(self, kernel_ids):
+        mask = 0
+        for k in kernel_ids:
+            mask |= 1 << k
+        self._check(self._L.st_ctx_timing_enable(self._h, mask))
+
+    def timing_reset(self):
+        self._check(self._L.st_ctx_timing_reset(self._h))
+
+    def timing_read(self, kernel_id):
+        n, ms = ctypes.c_int(), ctypes.c_double()
+        self._check(self._L.st_ctx_timing_read(self._h, kernel_id, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    # -- Histogram --------------------------------------------------------------------------
+    def histogram(self, frames, bins=16, out=None):
+        """Per-channel histograms of U8 RGB frames.
+
+        frames: CUDA uint8 tensor (n,h,w,3) (one contiguous stream) or a list of (h,w,3)
+        tensors (one buffer per Scanner element).  Returns int32 (n,3,bins): row i is the
+        192-byte element the reference's Histogram op emits for bins=16
+        (histogram_kernel_cpu.cpp:20,40-44)."""
+        self._bind()
+        if isinstance(frames, (list, tuple)):
+            n = len(frames)
+            if n == 0:
+                return torch.zeros((0, 3, bins), dtype=torch.int32, device=self.device)
+            for f in frames:
+                _require_cuda(f, torch.uint8, "frame")
+            h, w, c = frames[0].shape
+            if any(tuple(f.shape) != (h, w, 3) for f in frames):
+                raise ValueError("all frames must be (h,w,3) with equal shape")
+            if out is None:
+                out = torch.empty((n, 3, bins), dtype=torch.int32, device=self.device)
+            table = (ctypes.c_void_p * n)(*[f.data_ptr() for f in frames])
+            self._check(self._L.st_hist_u8c3_batch(self._h, table, n, h, w, bins, ctypes.c_void_p(out.data_ptr())))
+            return out
+        _require_cuda(frames, torch.uint8, "frames")
+        if frames.dim() != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be (n,h,w,3)")
+        n, h, w, _ = frames.shape
+        if out is None:
+            out = torch.empty((n, 3, bins), dtype=torch.int32, device=self.device)
+        if n == 0:
+            return out
+        self._check(self._L.st_hist_u8c3_strided(self._h, ctypes.c_void_p(frames.data_ptr()), 3 * h * w, n, h, w,
+                                                 bins, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    # -- OpticalFlow ------------------------------------------------------------------------
+    def optical_flow(self, frames, pairs=None, params=None, out=None):
+        """Farneback flow for a batch of frame pairs.
+
+        frames: CUDA uint8 (n,h,w,3) tensor or list of (h,w,3) tensors.  pairs: (p,2) int
+        array-like of indices; default = consecutive pairs (i, i+1), i.e. stencil {0,1} over a
+        contiguous run (optical_flow_kernel_cpu.cpp:51-54).  Flow p goes from frame pairs[p][0]
+        to frame pairs[p][1].  Returns float32 (p,h,w,2)."""
+        self._bind()
+        if isinstance(frames, (list, tuple)):
+            fl = list(frames)
+        else:
+            _require_cuda(frames, torch.uint8, "frames")
+            if frames.dim() != 4 or frames.shape[3] != 3:
+                raise ValueError("frames must be (n,h,w,3)")
+            fl = [frames[i] for i in range(frames.shape[0])]
+        n = len(fl)
+        for f in fl:
+            _require_cuda(f, torch.uint8, "frame")
+        if n:
+            h, w, _ = fl[0].shape
+            if any(tuple(f.shape) != (h, w, 3) for f in fl):
+                raise ValueError("all frames must be (h,w,3) with equal shape")
+        if pairs is None:
+            pairs = [(i, i + 1) for i in range(max(n - 1, 0))]
+        pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        p = len(pairs)
+        if n == 0:
+            if p:
+                raise ValueError("pairs given but no frames")
+            return torch.zeros((0, 0, 0, 2), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((p, h, w, 2), dtype=torch.float32, device=self.device)
+        else:
+            _require_cuda(out, torch.float32, "out")
+            if tuple(out.shape) != (p, h, w, 2):
+                raise ValueError("out must be (%d,%d,%d,2)" % (p, h, w))
+        if p == 0:
+            return out
+        prm = params if params is not None else default_params()
+        ftab = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fl])
+        otab = (ctypes.c_void_p * p)(*[out[i].data_ptr() for i in range(p)])
+        self._check(self._L.st_farneback_pairs(
+            self._h, ftab, n, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p, h, w, ctypes.byref(prm), otab))
+        return out
+
+    # -- stage-level entry points (used by the parity tests) ----------------------------------
+    def gray(self, rgb, bits=15):
+        self._bind()
+        _require_cuda(rgb, torch.uint8, "rgb")
+        h, w, _ = rgb.shape
+        out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        self._check(self._L.st_gray_u8(self._h, ctypes.c_void_p(rgb.data_ptr()), h, w, bits,
+                                       ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def pyr_image(self, gray, level, params=None):
+        self._bind()
+        _require_cuda(gray, torch.uint8, "gray")
+        prm = params if params is not None else default_params()
+        h, w = gray.shape
+        lh, lw = ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.st_fb_level_geom(h, w, ctypes.byref(prm), level, ctypes.byref(lh), ctypes.byref(lw),
+                                             None, None))
+        out = torch.empty((lh.value, lw.value), dtype=torch.float32, device=self.device)
+        self._check(self._L.st_fb_pyr_image(self._h, ctypes.c_void_p(gray.data_ptr()), h, w, ctypes.byref(prm), level,
+                                            ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def polyexp(self, img, poly_n=5, poly_sigma=1.2):
+        """(h,w) f32 -> planar (5,h,w) f32."""
+        self._bind()
+        _require_cuda(img, torch.float32, "img")
+        h, w = img.shape
+        out = torch.empty((5, h, w), dtype=torch.float32, device=self.device)
+        self._check(self._L.st_fb_polyexp(self._h, ctypes.c_void_p(img.data_ptr()), h, w, poly_n, poly_sigma,
+                                          ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def update_matrices(self, r0, r1, flow=None, coarse_flow=None, pyr_scale=0.5):
+        """Planar (5,h,w) R0,R1 (+ flow (h,w,2) or coarse flow (ch,cw,2)) -> planar M (5,h,w)."""
+        self._bind()
+        _require_cuda(r0, torch.float32, "r0")
+        _require_cuda(r1, torch.float32, "r1")
+        _, h, w = r0.shape
+        out = torch.empty((5, h, w), dtype=torch.float32, device=self.device)
+        fp = cp = None
+        ch = cw = 0
+        if coarse_flow is not None:
+            _require_cuda(coarse_flow, torch.float32, "coarse_flow")
+            ch, cw, _ = coarse_flow.shape
+            cp = ctypes.c_void_p(coarse_flow.data_ptr())
+        elif flow is not None:
+            _require_cuda(flow, torch.float32, "flow")
+            fp = ctypes.c_void_p(flow.data_ptr())
+        self._check(self._L.st_fb_update_matrices(self._h, ctypes.c_void_p(r0.data_ptr()), ctypes.c_void_p(r1.data_ptr()),
+                                                  fp, cp, ch, cw, pyr_scale, h, w, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def update_flow_blur(self, r0, r1, m, block_size=15, update=True):
+        """One FarnebackUpdateFlow_Blur pass.  Returns (flow (h,w,2), M' (5,h,w) or None)."""
+        self._bind()
+        _require_cuda(m, torch.float32, "m")
+        _, h, w = m.shape
+        flow = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
+        mout = torch.empty_like(m) if update else None
+        self._check(self._L.st_fb_update_flow_blur(
+            self._h, ctypes.c_void_p(r0.data_ptr()) if r0 is not None else None,
+            ctypes.c_void_p(r1.data_ptr()) if r1 is not None else None, ctypes.c_void_p(m.data_ptr()), h, w,
+            block_size, 1 if update else 0, ctypes.c_void_p(flow.data_ptr()),
+            ctypes.c_void_p(mout.data_ptr()) if update else None))
+        return flow, mout
+
+
+def fb_levels(h, w, params=None):
+    prm = params if params is not None else default_params()
+    return _native.lib().st_fb_levels(h, w, ctypes.byref(prm))
+
+
+def fb_level_geom(h, w, level, params=None):
+    prm = params if params is not None else default_params()
+    lh, lw, ks = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    sg = ctypes.c_double()
+    st = _native.lib().st_fb_level_geom(h, w, ctypes.byref(prm), level, ctypes.byref(lh), ctypes.byref(lw),
+                                        ctypes.byref(sg), ctypes.byref(ks))
+    if st != 0:
+        raise StError(st, "st_fb_level_geom")
+    return lh.value, lw.value, sg.value, ks.value

@@ -1,0 +1,56 @@
+"""ShotBoundaries: host-side tail of the Histogram -> ShotBoundaries path.
+
+Mirrors ``/root/reference/scannertools/scannertools/shot_detection.py:11-28``: same op name,
+same arguments, same output contract (row 0 = list of boundary indices, rows 1.. = None), same
+constants.  The reference op is a Python/numpy op that Scanner runs on the host with the whole
+stream as one batch; so is this one.  The per-pair histogram distances are computed in one
+vectorised pass instead of 3(n-1) scipy calls; the windowed outlier test keeps the reference's
+``np.mean`` / ``np.std`` calls on the same slices so that every comparison is bit-identical.
+"""
+from typing import Any, Sequence
+
+import numpy as np
+
+WINDOW_SIZE = 500          # shot_detection.py:7
+BOUNDARY_BATCH = 10000000  # shot_detection.py:8
+
+try:  # inside a real Scanner deployment the op registers itself exactly like the reference's
+    import scannerpy
+    from scannerpy.types import Histogram
+
+    _register = scannerpy.register_python_op(name='ShotBoundaries', batch=BOUNDARY_BATCH)
+except ImportError:  # standalone: plain function, driven by scannertools_amd.engine
+    Histogram = Any
+
+    def _register(fn):
+        return fn
+
+
+def histogram_diffs(histograms) -> np.ndarray:
+    """diffs[0] = 0; diffs[i] = mean over the 3 channels of the Chebyshev (L-inf) distance
+    between frame i-1's and frame i's channel histograms (shot_detection.py:14-18)."""
+    h = np.asarray(histograms)
+    n = len(h)
+    if n == 0:
+        return np.zeros(0)
+    if h.ndim != 3 or h.shape[1] != 3:
+        raise ValueError("histograms must be a sequence of 3 x bins arrays")
+    h = h.astype(np.int64)
+    d = np.abs(h[1:] - h[:-1]).max(axis=2)  # (n-1, 3) exact integers
+    diffs = np.mean(d, axis=1) if n > 1 else np.zeros(0)
+    return np.insert(diffs, 0, 0)
+
+
+@_register
+def shot_boundaries(config, histograms: Sequence[Histogram]) -> Sequence[Any]:
+    diffs = histogram_diffs(histograms)
+    n = len(diffs)
+
+    # Do simple outlier detection to find boundaries between shots (shot_detection.py:21-26)
+    boundaries = []
+    for i in range(1, n):
+        window = diffs[max(i - WINDOW_SIZE, 0):min(i + WINDOW_SIZE, n)]
+        if diffs[i] - np.mean(window) > 2.5 * np.std(window):
+            boundaries.append(i)
+
+    return [boundaries] + [None for _ in range(len(histograms) - 1)]

@@ -1,0 +1,259 @@
+"""GPU parity: Farneback OpticalFlow (HIP, through the C ABI) vs the CPU oracle.
+
+Stage tests compare each kernel with the oracle's restatement of the same OpenCV routine on
+identical inputs.  The library is built with -ffp-contract=off and follows the scalar operand
+order, so every stage whose arithmetic is per-pixel (gray, pyramid, polynomial expansion,
+UpdateMatrices) must be BIT-EXACT.  The box filter uses running double sums restarted per
+vertical segment (the reference accumulates float-rounded differences from the top of the
+image), so blur-dependent outputs are compared within a tolerance:
+  stage   UpdateFlow_Blur : |d flow| <= 1e-4 px, |d M'| <= 1e-4 * max|M'|
+  end-to-end flow         : relative L2 <= 1e-4 and max-abs <= 5e-3 px on textured pairs
+(north-star bound: relative L2 <= 1e-3, max-abs <= 1e-2 px).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from scannertools_amd.hip import default_params
+from util import interleaved5, planar5, random_frames, smooth_texture, texture_stream, translated_rgb_pair
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-4
+MAX_ABS_TOL = 5e-3
+
+SIZES = [(48, 64), (97, 131), (240, 320), (203, 317)]
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+# ---------------------------------------------------------------- A2 gray
+@pytest.mark.parametrize("bits", [14, 15])
+def test_gray_bit_exact(hip_ctx, bits):
+    f = random_frames(bits, 1, 101, 173)[0]
+    got = hip_ctx.gray(cu(f), bits).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.gray_u8(f, bits))
+
+
+def test_gray_known_answers(hip_ctx):
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]], np.uint8)
+    for bits, cb, cg, cr in ((15, 3735, 19235, 9798), (14, 1868, 9617, 4899)):
+        got = hip_ctx.gray(cu(px), bits).cpu().numpy()[0]
+        rnd = 1 << (bits - 1)
+        # channel-swap quirk: the R byte gets the B coefficient (0.114)
+        assert got[0] == (255 * cb + rnd) >> bits
+        assert got[1] == (255 * cg + rnd) >> bits
+        assert got[2] == (255 * cr + rnd) >> bits
+        assert got[3] == 255 and got[4] == 0
+
+
+# ---------------------------------------------------------------- pyramid
+@pytest.mark.parametrize("h,w", [(240, 320), (203, 317), (270, 480), (135, 241)])
+def test_pyramid_levels_bit_exact(hip_ctx, h, w):
+    gray = (smooth_texture(h + w, h, w) + np.random.default_rng(1).integers(0, 8, (h, w))).clip(0, 255).astype(np.uint8)
+    p = default_params()
+    levels = oracle.fb_levels(h, w)
+    for k in range(levels + 1):
+        got = hip_ctx.pyr_image(cu(gray), k, p).cpu().numpy()
+        ref = oracle.fb_pyr_image(gray, k)
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got, ref, err_msg="level %d" % k)
+
+
+def test_pyramid_1080p_geometry_and_parity(hip_ctx):
+    h, w = 1080, 1920
+    assert oracle.fb_levels(h, w) == 3
+    gray = np.random.default_rng(0).integers(0, 256, (h, w), dtype=np.uint8)
+    for k, shape in enumerate([(1080, 1920), (540, 960), (270, 480), (135, 240)]):
+        got = hip_ctx.pyr_image(cu(gray), k).cpu().numpy()
+        assert got.shape == shape
+        np.testing.assert_array_equal(got, oracle.fb_pyr_image(gray, k))
+
+
+# ---------------------------------------------------------------- A4 polyexp
+@pytest.mark.parametrize("h,w", SIZES + [(12, 300), (300, 9)])
+def test_polyexp_bit_exact(hip_ctx, h, w):
+    I = (smooth_texture(h * w, h, w) * 1.0).astype(np.float32)
+    got = hip_ctx.polyexp(cu(I)).cpu().numpy()
+    ref = planar5(oracle.polyexp(I))
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_polyexp_exact_quadratic(hip_ctx):
+    h, w = 64, 80
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    a, bx, by, cxx, cyy, cxy = 3.0, 0.5, -0.25, 0.01, 0.02, -0.015
+    I = (a + bx * (x - 40) + by * (y - 30) + cxx * (x - 40) ** 2 + cyy * (y - 30) ** 2 + cxy * (x - 40) * (y - 30))
+    R = hip_ctx.polyexp(cu(I.astype(np.float32))).cpu().numpy()
+    yy, xx = 20, 25
+    exp = [by + 2 * cyy * (yy - 30) + cxy * (xx - 40), bx + 2 * cxx * (xx - 40) + cxy * (yy - 30), cyy, cxx, cxy]
+    np.testing.assert_allclose(R[:, yy, xx], exp, atol=2e-6)
+
+
+def test_polyexp_n7(hip_ctx):
+    I = smooth_texture(3, 90, 120).astype(np.float32)
+    got = hip_ctx.polyexp(cu(I), 7, 1.5).cpu().numpy()
+    np.testing.assert_array_equal(got, planar5(oracle.polyexp(I, 7, 1.5)))
+
+
+# ---------------------------------------------------------------- A5 UpdateMatrices
+def _expansions(seed, h, w, tx=2, ty=-1):
+    f0, f1 = translated_rgb_pair(seed, h, w, tx, ty)
+    g0, g1 = oracle.gray_u8(f0), oracle.gray_u8(f1)
+    R0 = oracle.polyexp(g0.astype(np.float32))
+    R1 = oracle.polyexp(g1.astype(np.float32))
+    return R0, R1
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_update_matrices_bit_exact(hip_ctx, h, w):
+    R0, R1 = _expansions(h, h, w)
+    rng = np.random.default_rng(w)
+    flow = (rng.standard_normal((h, w, 2)) * 3).astype(np.float32)
+    flow[0, 0] = (-50, -50)      # far outside -> else-branch
+    flow[-1, -1] = (0, 0)        # last row/col quirk
+    got = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1)), flow=cu(flow)).cpu().numpy()
+    np.testing.assert_array_equal(got, planar5(oracle.update_matrices(R0, R1, flow)))
+    # zero flow
+    got0 = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1))).cpu().numpy()
+    np.testing.assert_array_equal(got0, planar5(oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))))
+
+
+@pytest.mark.parametrize("h,w,ch,cw", [(96, 128, 48, 64), (97, 131, 48, 66), (203, 317, 102, 158)])
+def test_update_matrices_with_flow_upsample_bit_exact(hip_ctx, h, w, ch, cw):
+    R0, R1 = _expansions(h + 1, h, w)
+    coarse = (np.random.default_rng(ch).standard_normal((ch, cw, 2)) * 2).astype(np.float32)
+    up = oracle.resize_linear(coarse, h, w) * np.float32(2.0)
+    got = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1)), coarse_flow=cu(coarse), pyr_scale=0.5).cpu().numpy()
+    np.testing.assert_array_equal(got, planar5(oracle.update_matrices(R0, R1, up)))
+
+
+def test_update_matrices_identical_frames_quirk(hip_ctx):
+    """R0 == R1 and zero flow: h1 = h2 = 0 inside, non-zero on the last row / column (A5 quirk)."""
+    h, w = 60, 70
+    R0, _ = _expansions(9, h, w)
+    M = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R0))).cpu().numpy()
+    assert np.abs(M[3:, :-1, :-1]).max() == 0
+    assert np.abs(M[3:, -1, :]).max() > 0 and np.abs(M[3:, :, -1]).max() > 0
+
+
+# ---------------------------------------------------------------- A6 UpdateFlow_Blur
+@pytest.mark.parametrize("h,w", SIZES + [(20, 500), (600, 24)])
+@pytest.mark.parametrize("update", [True, False])
+def test_update_flow_blur_parity(hip_ctx, h, w, update):
+    R0, R1 = _expansions(h + 2, h, w)
+    M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
+    ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 15, update)
+    flow, Mn = hip_ctx.update_flow_blur(cu(planar5(R0)), cu(planar5(R1)), cu(planar5(M)), 15, update)
+    flow = flow.cpu().numpy()
+    assert np.abs(flow - ref_flow).max() <= 1e-4
+    if update:
+        Mn = interleaved5(Mn.cpu().numpy())
+        assert np.abs(Mn - ref_M).max() <= 1e-4 * np.abs(ref_M).max()
+    else:
+        assert Mn is None
+
+
+def test_update_flow_blur_other_window(hip_ctx):
+    h, w = 80, 90
+    R0, R1 = _expansions(4, h, w)
+    M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
+    for bs in (5, 21):
+        ref_flow, _ = oracle.update_flow_blur(R0, R1, M, bs, False)
+        flow, _ = hip_ctx.update_flow_blur(None, None, cu(planar5(M)), bs, False)
+        assert np.abs(flow.cpu().numpy() - ref_flow).max() <= 1e-4
+
+
+# ---------------------------------------------------------------- A3 end to end
+def _check_flow(got, ref):
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert rel_l2(got, ref) <= REL_L2_TOL, rel_l2(got, ref)
+    assert np.abs(got - ref).max() <= MAX_ABS_TOL, np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("h,w", [(240, 320), (203, 317), (480, 640), (48, 64)])
+def test_flow_matches_oracle(hip_ctx, h, w):
+    f0, f1 = translated_rgb_pair(h, h, w, 3, -2)
+    got = hip_ctx.optical_flow(cu(np.stack([f0, f1]))).cpu().numpy()
+    assert got.shape == (1, h, w, 2)
+    _check_flow(got[0], oracle.optical_flow_rgb(f0, f1))
+
+
+def test_flow_recovers_translation(hip_ctx):
+    h, w, tx, ty = 240, 320, 3, -2
+    f0, f1 = translated_rgb_pair(11, h, w, tx, ty)
+    fl = hip_ctx.optical_flow(cu(np.stack([f0, f1]))).cpu().numpy()[0]
+    inner = fl[40:-40, 40:-40]
+    assert abs(np.median(inner[..., 0]) - tx) < 0.01 and abs(np.median(inner[..., 1]) - ty) < 0.01
+    assert np.abs(inner - [tx, ty]).mean() < 0.01
+
+
+def test_flow_identical_frames(hip_ctx):
+    f0, _ = translated_rgb_pair(5, 240, 320, 0, 0)
+    fl = hip_ctx.optical_flow(cu(np.stack([f0, f0]))).cpu().numpy()[0]
+    assert np.abs(fl[:100, :150]).max() < 1e-3          # far from the right/bottom border quirk
+    _check_flow(fl, oracle.optical_flow_rgb(f0, f0))
+
+
+def test_flow_stream_batch_pairs_and_direction(hip_ctx):
+    """Batched stencil {0,1} over a stream, arbitrary pairs, CPU-kernel direction."""
+    h, w = 120, 160
+    frames, _ = texture_stream(2, 6, h, w)
+    d = cu(frames)
+    got = hip_ctx.optical_flow(d).cpu().numpy()
+    assert got.shape == (5, h, w, 2)
+    for i in range(5):
+        _check_flow(got[i], oracle.optical_flow_rgb(frames[i], frames[i + 1]))
+    # arbitrary, repeated and reversed pairs; list-of-buffers input
+    pairs = [(4, 1), (1, 4), (0, 0), (2, 5)]
+    got2 = hip_ctx.optical_flow([d[i] for i in range(6)], pairs).cpu().numpy()
+    for k, (a, b) in enumerate(pairs):
+        _check_flow(got2[k], oracle.optical_flow_rgb(frames[a], frames[b]))
+    assert np.abs(got2[0] - got2[1]).max() > 0.1  # direction matters
+
+
+def test_flow_batch_equals_single(hip_ctx):
+    """Scheduling (segment heights, batching) must not change results bit-for-bit within the HIP path."""
+    h, w = 135, 240
+    frames, _ = texture_stream(3, 4, h, w)
+    d = cu(frames)
+    batch = hip_ctx.optical_flow(d)
+    single = torch.stack([hip_ctx.optical_flow(d[i:i + 2])[0] for i in range(3)])
+    assert rel_l2(batch.cpu().numpy(), single.cpu().numpy()) < 1e-6
+
+
+def test_flow_other_params(hip_ctx):
+    h, w = 160, 200
+    f0, f1 = translated_rgb_pair(8, h, w, -2, 1)
+    for kw in (dict(num_levels=1), dict(num_levels=5), dict(win_size=9, num_iters=2), dict(gray_bits=14),
+               dict(pyr_scale=0.7, num_levels=2), dict(poly_n=7, poly_sigma=1.5)):
+        ref = oracle.optical_flow_rgb(f0, f1, oracle.default_params(**kw))
+        got = hip_ctx.optical_flow(cu(np.stack([f0, f1])), params=default_params(**kw)).cpu().numpy()[0]
+        _check_flow(got, ref)
+
+
+def test_flow_1080p_pair(hip_ctx):
+    h, w = 1080, 1920
+    f0, f1 = translated_rgb_pair(21, h, w, 4, 3)
+    got = hip_ctx.optical_flow(cu(np.stack([f0, f1]))).cpu().numpy()[0]
+    _check_flow(got, oracle.optical_flow_rgb(f0, f1))
+    inner = got[100:-100, 100:-100]
+    assert abs(np.median(inner[..., 0]) - 4) < 0.01 and abs(np.median(inner[..., 1]) - 3) < 0.01
+
+
+def test_flow_rejects_unsupported(hip_ctx):
+    from scannertools_amd.hip import StError
+    f = torch.zeros((2, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    for kw in (dict(flags=256), dict(fast_pyramids=1), dict(poly_n=6), dict(win_size=14), dict(pyr_scale=1.5)):
+        with pytest.raises(StError):
+            hip_ctx.optical_flow(f, params=default_params(**kw))
+    with pytest.raises(StError):
+        hip_ctx.optical_flow(f, pairs=[(0, 2)])
+    assert tuple(hip_ctx.optical_flow(f, pairs=np.zeros((0, 2), np.int32)).shape) == (0, 64, 64, 2)
