@@ -53,8 +53,11 @@ int st_device_count(int* count);
  * optical_flow_kernel_gpu.cpp:101-107). */
 int st_ctx_create(int device_id, st_ctx** out_ctx);
 int st_ctx_destroy(st_ctx* ctx);
-/* Borrow an external hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+/* Borrow an external hipStream_t (e.g. torch's current stream).  NULL is the HIP default
+ * (null) stream, which is what torch's default stream is.  st_ctx_reset_stream() returns to
+ * the context's own non-blocking stream.  Both drain the previously bound stream first. */
 int st_ctx_set_stream(st_ctx* ctx, void* hip_stream);
+int st_ctx_reset_stream(st_ctx* ctx);
 int st_ctx_sync(st_ctx* ctx);
 /* Cap on scratch the context may hold (bytes; 0 = default 24 GiB).  Large pair batches are
  * processed in passes that fit. */

@@ -76,7 +76,14 @@ ST_EXPORT int st_ctx_destroy(st_ctx* ctx) {
 ST_EXPORT int st_ctx_set_stream(st_ctx* ctx, void* hip_stream) {
   ST_TRY(st_enter(ctx));
   ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;
+  return ST_OK;
+}
+
+ST_EXPORT int st_ctx_reset_stream(st_ctx* ctx) {
+  ST_TRY(st_enter(ctx));
+  ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = ctx->own_stream;
   return ST_OK;
 }
 

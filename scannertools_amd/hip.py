@@ -36,7 +36,7 @@ class HipContext:
         if st != 0:
             raise StError(st, "st_ctx_create(%d) failed" % self.device.index)
         self._h = h
-        self._bound_stream = None
+        self._bound_stream = -1
         if workspace_limit:
             self._check(self._L.st_ctx_set_workspace_limit(self._h, int(workspace_limit)))
 

@@ -29,7 +29,7 @@ def test_hist_odd_bin_counts(hip_ctx, bins):
     got = hip_ctx.histogram(torch.from_numpy(frames).cuda(), bins).cpu().numpy()
     np.testing.assert_array_equal(got, _oracle_batch(frames, bins))
     # definition check, independent of the oracle: bin = floor(v*bins/256)
-    ref = np.stack([[np.bincount((f[..., c].astype(np.int64) * bins) >> 8, minlength=bins) for c in range(3)]
+    ref = np.stack([[np.bincount(((f[..., c].astype(np.int64) * bins) >> 8).ravel(), minlength=bins) for c in range(3)]
                     for f in frames])
     np.testing.assert_array_equal(got, ref)
 
