@@ -21,6 +21,7 @@
 //   M     f32 planar (5,lh,lw): [G11, G12, G22, h1, h2] (two buffers, ping-pong per iteration)
 //   flow  f32 (lh,lw,2) interleaved (u,v): the op's output format
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "st_internal.h"
@@ -389,9 +390,9 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
 // A5: FarnebackUpdateMatrices for one pixel.  R0/R1 planar with plane stride np.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
-                                                   size_t np, int h, int w, int x, int y, float dx, float dy,
+                                                   int np, int h, int w, int x, int y, float dx, float dy,
                                                    float m[5]) {
-  const size_t o = (size_t)y * w + x;
+  const int o = y * w + x;
   float fx = x + dx, fy = y + dy;
   const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
   float r2, r3, r4, r5, r6;
@@ -399,16 +400,12 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
   const float q0 = R0[o], q1 = R0[np + o], q2 = R0[2 * np + o], q3 = R0[3 * np + o], q4 = R0[4 * np + o];
   if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    const float* p = R1 + (size_t)y1 * w + x1;
-    r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-    p += np;
-    r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-    p += np;
-    r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-    p += np;
-    r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-    p += np;
-    r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+    const int gi = y1 * w + x1;
+    r2 = a00 * R1[gi] + a01 * R1[gi + 1] + a10 * R1[gi + w] + a11 * R1[gi + w + 1];
+    r3 = a00 * R1[np + gi] + a01 * R1[np + gi + 1] + a10 * R1[np + gi + w] + a11 * R1[np + gi + w + 1];
+    r4 = a00 * R1[2 * np + gi] + a01 * R1[2 * np + gi + 1] + a10 * R1[2 * np + gi + w] + a11 * R1[2 * np + gi + w + 1];
+    r5 = a00 * R1[3 * np + gi] + a01 * R1[3 * np + gi + 1] + a10 * R1[3 * np + gi + w] + a11 * R1[3 * np + gi + w + 1];
+    r6 = a00 * R1[4 * np + gi] + a01 * R1[4 * np + gi + 1] + a10 * R1[4 * np + gi + w] + a11 * R1[4 * np + gi + w + 1];
     r4 = (q2 + r4) * 0.5f;
     r5 = (q3 + r5) * 0.5f;
     r6 = (q4 + r6) * 0.25f;
@@ -624,6 +621,199 @@ __global__ __launch_bounds__(BLUR_T) void k_blur_update(BlurArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fast path of A6(+A5) for block_size = 2*M+1 with M <= 8 (the reference uses 15, M = 7).
+//
+// One workgroup owns a 256-column strip (240 outputs + 8 halo columns each side) of one pair
+// and marches down a vertical segment in batches of RB = 5 rows with two barriers per batch:
+//   phase 1  thread = column.  The 2M+1 source rows of the vertical window live in a register
+//            ring (statically indexed: the batch loop is unrolled over the ring period), so each
+//            M value is read from HBM exactly once; the running column sum is kept in double
+//            exactly like the reference (+= float(M[y+m] - M[y-m-1])).  The five sums of each
+//            batch row go to LDS (float).
+//   phase 2  thread = (row, 5-pixel segment).  Sliding-window horizontal sum in double over the
+//            LDS row (19 reads for 5 outputs instead of 75), 2x2 solve, flow -> LDS.
+//   phase 3  thread = column again: coalesced flow store (last iteration) or UpdateMatrices
+//            (R0 stream, bilinear R1 gather, M' stream) with the fresh flow.
+// LDS: 25.6 KB sums + 10 KB flow per workgroup -> 4 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int B2_T = 256, B2_HALO = 8, B2_OUT = B2_T - 2 * B2_HALO, B2_RB = 5, B2_SEG = 5;
+constexpr int B2_NSEG = B2_OUT / B2_SEG;  // 48 segments per row
+
+template <int M, bool RING>
+__global__ __launch_bounds__(B2_T, RING ? 3 : 4) void k_blur_update_v2(BlurArgs a) {
+  constexpr int W = 2 * M + 1;
+  static_assert(W % B2_RB == 0 && M <= B2_HALO, "ring period must be a multiple of the batch");
+  __shared__ float V[B2_RB][5][B2_T];
+  __shared__ float2 F[B2_RB][B2_T];
+  const int tid = threadIdx.x;
+  const int h = a.h, w = a.w;
+  const int np = h * w;  // 32-bit element offsets: one VGPR per address, SGPR base
+  const int pr = blockIdx.z;
+  const float* __restrict__ Min = a.Min + (size_t)pr * 5 * (size_t)np;
+  const int x = (int)blockIdx.x * B2_OUT - B2_HALO + tid;
+  const int xc = d_clamp(x, 0, w - 1);
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
+
+  const float* R0 = nullptr;
+  const float* R1 = nullptr;
+  float* Mout = nullptr;
+  if (a.update) {
+    if (a.pairs) {
+      R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
+      R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
+    } else {
+      R0 = a.R;
+      R1 = a.R1_direct;
+    }
+    Mout = a.Mout + (size_t)pr * 5 * (size_t)np;
+  }
+  float* flow = nullptr;
+  if (a.write_flow) flow = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow + (size_t)pr * 2 * (size_t)np;
+
+  // ring slot s holds source row y0 - M + s (clamped) at entry; vs = window sum of row y0
+  float ring[RING ? W : 1][5];
+  double vs[5];
+  if (!RING) {
+    // no register ring: the row leaving the window is re-read (served by L2 / Infinity Cache / HBM)
+    if (y0 == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] = (double)(Min[c * np + xc] * (float)(M + 2));
+      for (int yy = 1; yy < M; ++yy) {
+        const int o = min(yy, h - 1) * w + xc;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) vs[c] += (double)Min[c * np + o];
+      }
+      const int oa = min(M, h - 1) * w + xc;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float d = Min[c * np + oa] - Min[c * np + xc];
+        vs[c] += d;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] = 0;
+      for (int dy = -M; dy <= M; ++dy) {
+        const int o = d_clamp(y0 + dy, 0, h - 1) * w + xc;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) vs[c] += (double)Min[c * np + o];
+      }
+    }
+  } else {
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    const int o = d_clamp(y0 - M + s, 0, h - 1) * w + xc;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) ring[s][c] = Min[c * np + o];
+  }
+  if (y0 == 0) {
+    // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
+    // (ring slots M..2M hold rows 0..M here; slots 0..M-1 hold row 0 as well)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = (double)(ring[M][c] * (float)(M + 2));
+#pragma unroll
+    for (int yy = 1; yy < M; ++yy)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[M + yy][c];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float d = ring[2 * M][c] - ring[M][c];
+      vs[c] += d;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+    for (int s = 0; s < W; ++s)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
+  }
+  }
+
+  for (int yb = y0; yb < y1; yb += W) {
+#pragma unroll
+    for (int b = 0; b < W / B2_RB; ++b) {
+      const int ybb = yb + b * B2_RB;
+      if (ybb < y1) {  // workgroup-uniform
+        // ---- phase 1: vertical window ----
+        float nw[B2_RB][5], od[RING ? 1 : B2_RB][5];
+#pragma unroll
+        for (int r = 0; r < B2_RB; ++r) {
+          const int o = d_clamp(ybb + r + M + 1, 0, h - 1) * w + xc;
+#pragma unroll
+          for (int c = 0; c < 5; ++c) nw[r][c] = Min[c * np + o];
+          if (!RING) {
+            const int oo = d_clamp(ybb + r - M, 0, h - 1) * w + xc;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) od[r][c] = Min[c * np + oo];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < B2_RB; ++r) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            V[r][c][tid] = (float)vs[c];
+            const float old = RING ? ring[RING ? b * B2_RB + r : 0][c] : od[RING ? 0 : r][c];
+            const float d = nw[r][c] - old;
+            vs[c] += d;
+            if (RING) ring[RING ? b * B2_RB + r : 0][c] = nw[r][c];
+          }
+        }
+        __syncthreads();
+        // ---- phase 2: horizontal window + solve ----
+        if (tid < B2_RB * B2_NSEG) {
+          const int r = tid / B2_NSEG, sg = tid - r * B2_NSEG;
+          const int j0 = B2_HALO + sg * B2_SEG;
+          // five running window sums (one per channel) slide together along the segment
+          double t[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const float* vp = &V[r][c][j0 - M];
+            double acc = vp[0];
+#pragma unroll
+            for (int i = 1; i < W; ++i) acc += (double)vp[i];
+            t[c] = acc;
+            __builtin_amdgcn_sched_barrier(0);  // keep one channel's 15 LDS reads live at a time
+          }
+#pragma unroll
+          for (int i = 0; i < B2_SEG; ++i) {
+            if (i > 0) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c) t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
+            }
+            const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
+            const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();
+        // ---- phase 3: flow store / UpdateMatrices ----
+        if (writer) {
+#pragma unroll 1
+          for (int r = 0; r < B2_RB; ++r) {
+            const int y = ybb + r;
+            if (y < y1) {
+              const float2 f = F[r][tid];
+              const int o = y * w + x;
+              if (flow) *reinterpret_cast<float2*>(flow + 2 * o) = f;
+              if (a.update) {
+                float mm[5];
+                update_matrices_px(R0, R1, np, h, w, x, y, f.x, f.y, mm);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) Mout[c * np + o] = mm[c];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
 int check_params(st_ctx* ctx, const st_fb_params& p, int h, int w) {
@@ -721,6 +911,20 @@ int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
 }
 
 int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
+  if (a.m == 7 && !getenv("ST_BLUR_GENERIC")) {
+    const int strips = (a.w + B2_OUT - 1) / B2_OUT;
+    // segments are whole ring periods (15 rows) so that the static ring indexing stays aligned
+    int rows = rows_per_segment(ctx, a.h, strips, n_pairs, 2 * a.m + 1);
+    rows = (rows + 14) / 15 * 15;
+    a.rows_per_seg = rows;
+    dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
+    static const int variant = getenv("ST_BLUR_VARIANT") ? atoi(getenv("ST_BLUR_VARIANT")) : 0;
+    st_timed t(ctx, ST_K_BLUR_UPDATE);
+    if (variant == 1) hipLaunchKernelGGL((k_blur_update_v2<7, false>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_blur_update_v2<7, true>), grid, dim3(B2_T), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+    return ST_OK;
+  }
   const int strips = (a.w + (BLUR_T - 2 * a.m) - 1) / (BLUR_T - 2 * a.m);
   a.rows_per_seg = rows_per_segment(ctx, a.h, strips, n_pairs, 2 * a.m + 1);
   dim3 grid(strips, (a.h + a.rows_per_seg - 1) / a.rows_per_seg, n_pairs);
