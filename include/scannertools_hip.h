@@ -157,6 +157,14 @@ int st_fb_update_flow_blur(st_ctx* ctx, const float* r0_dev, const float* r1_dev
                            int h, int w, int block_size, int update, float* flow_out_dev,
                            float* m_out_dev);
 
+/* One whole iteration as the production path runs it (block_size 15 only):
+ *   flow_out = solve(box(UpdateMatrices(R0, R1, flow_in)))  without materialising M.
+ * flow_in: flow_in_dev (h,w,2), or resize(coarse_flow (ch,cw,2))*(1/pyr_scale), or zero when both
+ * are NULL.  Equals st_fb_update_matrices followed by st_fb_update_flow_blur(update = 0). */
+int st_fb_flow_iteration(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* flow_in_dev,
+                         const float* coarse_flow_dev, int ch, int cw, double pyr_scale, int h, int w,
+                         int block_size, float* flow_out_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscannertools_hip.so")
+LIB_PATH = os.environ.get("ST_HIP_LIB") or os.path.join(_HERE, "lib", "libscannertools_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ST_OK, ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_OOM, ST_ERR_UNSUPPORTED = range(5)
@@ -64,6 +64,7 @@ SIGNATURES = {
     "st_fb_polyexp": (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     "st_fb_update_matrices": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _i, _vp]),
     "st_fb_update_flow_blur": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "st_fb_flow_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _i, _i, _vp]),
 }
 
 _LIB = None

@@ -28,6 +28,12 @@
 
 namespace {
 
+// compile-time diagnostics switch (never set in product builds): 1 aligned instead of gathered R1
+// reads, 2 no 2x2 solve, 4 no R1 loads, 8 no phase 2 at all
+#ifndef ST_ABLATE
+#define ST_ABLATE 0
+#endif
+
 constexpr int kMaxTaps = 32;   // Gaussian pyramid kernel taps (reference needs <= 19)
 constexpr int kMaxPolyN = 7;
 
@@ -186,7 +192,7 @@ struct PyrArgs {
   const uint8_t* gray;  // n x (sh*sw)
   float* img;           // n x (dh*dw)
   int sh, sw, dh, dw;
-  int ks, mode, max_rows;
+  int ks, mode, max_rows, max_cols;
   double scale_x, scale_y;
   float taps[kMaxTaps];
 };
@@ -200,16 +206,30 @@ __device__ __forceinline__ void pyr_sample(int d, int slen, double scale, int mo
   *s0 = sx; *s1 = sx + 1; *f = fx;
 }
 
+// clamped sample columns of output column d (horizontal clamp rule of cv::resize for LINEAR)
+__device__ __forceinline__ void pyr_xcols(int d, const PyrArgs& a, int* c0, int* c1) {
+  int xs0, xs1; float fx;
+  pyr_sample(d, a.sw, a.scale_x, a.mode, &xs0, &xs1, &fx);
+  if (a.mode == PYR_LINEAR) {
+    if (xs0 < 0) xs0 = 0;
+    if (xs0 >= a.sw - 1) xs0 = a.sw - 1;
+    xs1 = min(xs0 + 1, a.sw - 1);
+  }
+  *c0 = xs0; *c1 = xs1;
+}
+
 __global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float hb[];  // [max_rows][2*PYR_OW]
+  extern __shared__ __attribute__((aligned(16))) float hb[];  // [max_rows][2*PYR_OW] then the u8 source tile
   const int tid = threadIdx.x;
   const int ox0 = blockIdx.x * PYR_OW, oy0 = blockIdx.y * PYR_OH;
   const uint8_t* __restrict__ src = a.gray + (size_t)blockIdx.z * a.sh * a.sw;
   float* __restrict__ dst = a.img + (size_t)blockIdx.z * a.dh * a.dw;
   const int r = a.ks / 2;
   const int oy_last = min(oy0 + PYR_OH, a.dh) - 1;
+  const int ox_last = min(ox0 + PYR_OW, a.dw) - 1;
+  uint8_t* tile = reinterpret_cast<uint8_t*>(hb + (size_t)a.max_rows * 2 * PYR_OW);
 
-  // source-row window of this tile (rows of the blurred image that the resize touches, +-r)
+  // source window of this tile: rows/cols of the blurred image that the resize touches, +-r
   int ys0, ys1; float fy;
   pyr_sample(oy0, a.sh, a.scale_y, a.mode, &ys0, &ys1, &fy);
   int ya0 = d_clamp(ys0, 0, a.sh - 1);
@@ -217,6 +237,19 @@ __global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
   int ya1 = d_clamp(ys1, 0, a.sh - 1);
   const int ybase = ya0 - r;
   const int nrows = ya1 + r - ybase + 1;
+  int xa0, xa1, tmp;
+  pyr_xcols(ox0, a, &xa0, &tmp);
+  pyr_xcols(ox_last, a, &tmp, &xa1);
+  const int xbase = xa0 - r;
+  const int ncols = xa1 + r - xbase + 1;
+  const int pitch = a.max_cols;
+
+  // phase 0: stage the u8 source window (borders already reflected) in LDS, coalesced along rows
+  for (int idx = tid; idx < nrows * ncols; idx += 256) {
+    const int j = idx / ncols, i = idx - j * ncols;
+    tile[j * pitch + i] = src[(size_t)d_reflect101(ybase + j, a.sh) * a.sw + d_reflect101(xbase + i, a.sw)];
+  }
+  __syncthreads();
 
   // phase 1: row filter at the sample columns
   for (int idx = tid; idx < nrows * 2 * PYR_OW; idx += 256) {
@@ -224,28 +257,16 @@ __global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
     const int ox = ox0 + (c >> 1);
     float v = 0.f;
     if (ox < a.dw) {
-      int xs0, xs1; float fx;
-      pyr_sample(ox, a.sw, a.scale_x, a.mode, &xs0, &xs1, &fx);
-      int xs;
-      if (a.mode == PYR_LINEAR) {
-        // horizontal clamp rule of cv::resize: sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0)
-        if (xs0 < 0) { xs0 = 0; }
-        if (xs0 >= a.sw - 1) { xs0 = a.sw - 1; }
-        xs = (c & 1) ? min(xs0 + 1, a.sw - 1) : xs0;
-      } else {
-        xs = (c & 1) ? xs1 : xs0;
-      }
-      const uint8_t* S = src + (size_t)d_reflect101(ybase + j, a.sh) * a.sw;
+      int c0, c1;
+      pyr_xcols(ox, a, &c0, &c1);
+      const uint8_t* S = tile + j * pitch + ((c & 1) ? c1 : c0) - xbase;  // S[k - r] = tap k
       if (a.ks == 3) {
-        v = (float)S[xs] * a.taps[1] +
-            ((float)S[d_reflect101(xs - 1, a.sw)] + (float)S[d_reflect101(xs + 1, a.sw)]) * a.taps[2];
+        v = (float)S[0] * a.taps[1] + ((float)S[-1] + (float)S[1]) * a.taps[2];
       } else if (a.ks == 5) {
-        v = (float)S[xs] * a.taps[2] +
-            ((float)S[d_reflect101(xs - 1, a.sw)] + (float)S[d_reflect101(xs + 1, a.sw)]) * a.taps[3] +
-            ((float)S[d_reflect101(xs - 2, a.sw)] + (float)S[d_reflect101(xs + 2, a.sw)]) * a.taps[4];
+        v = (float)S[0] * a.taps[2] + ((float)S[-1] + (float)S[1]) * a.taps[3] + ((float)S[-2] + (float)S[2]) * a.taps[4];
       } else {
-        v = a.taps[0] * (float)S[d_reflect101(xs - r, a.sw)];
-        for (int k = 1; k < a.ks; ++k) v += a.taps[k] * (float)S[d_reflect101(xs - r + k, a.sw)];
+        v = a.taps[0] * (float)S[-r];
+        for (int k = 1; k < a.ks; ++k) v += a.taps[k] * (float)S[k - r];
       }
     }
     hb[idx] = v;
@@ -309,6 +330,55 @@ __global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Level 0 of the pyramid (no resize, 3x3 kernel): a pure u8 -> f32 stream.  Each thread owns
+// four adjacent columns (one aligned dword of gray per row, float4 store) and marches down a
+// segment keeping the three row-filtered rows of the column filter in registers.
+// Requires w % 4 == 0 and h >= 2; other shapes take the generic k_pyr path.
+// ---------------------------------------------------------------------------------------------
+struct Pyr0Args {
+  const uint8_t* gray;  // n x (h*w)
+  float* img;           // n x (h*w)
+  int h, w, rows_per_seg;
+  float k0, k1;         // centre / side tap
+};
+
+__device__ __forceinline__ void pyr0_hrow(const uint8_t* __restrict__ g, int w, int x0, float k0, float k1, float hb[4]) {
+  const unsigned q = *reinterpret_cast<const unsigned*>(g + x0);
+  const float c0 = (float)(q & 0xff), c1 = (float)((q >> 8) & 0xff), c2 = (float)((q >> 16) & 0xff), c3 = (float)(q >> 24);
+  const float l = (float)g[x0 == 0 ? 1 : x0 - 1];
+  const float r = (float)g[x0 + 4 >= w ? w - 2 : x0 + 4];
+  hb[0] = c0 * k0 + (l + c1) * k1;
+  hb[1] = c1 * k0 + (c0 + c2) * k1;
+  hb[2] = c2 * k0 + (c1 + c3) * k1;
+  hb[3] = c3 * k0 + (c2 + r) * k1;
+}
+
+__global__ __launch_bounds__(256) void k_pyr0(Pyr0Args a) {
+  const int h = a.h, w = a.w;
+  const int x0 = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (x0 >= w) return;
+  const size_t np = (size_t)h * w;
+  const uint8_t* __restrict__ g = a.gray + (size_t)blockIdx.z * np;
+  float* __restrict__ o = a.img + (size_t)blockIdx.z * np;
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  float hm[4], hc[4], hp[4];
+  pyr0_hrow(g + (size_t)d_reflect101(y0 - 1, h) * w, w, x0, a.k0, a.k1, hm);
+  pyr0_hrow(g + (size_t)y0 * w, w, x0, a.k0, a.k1, hc);
+  for (int y = y0; y < y1; ++y) {
+    pyr0_hrow(g + (size_t)d_reflect101(y + 1, h) * w, w, x0, a.k0, a.k1, hp);
+    float4 v;
+    v.x = (hm[0] + hp[0]) * a.k1 + hc[0] * a.k0;
+    v.y = (hm[1] + hp[1]) * a.k1 + hc[1] * a.k0;
+    v.z = (hm[2] + hp[2]) * a.k1 + hc[2] * a.k0;
+    v.w = (hm[3] + hp[3]) * a.k1 + hc[3] * a.k0;
+    *reinterpret_cast<float4*>(o + (size_t)y * w + x0) = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hm[i] = hc[i]; hc[i] = hp[i]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
 // vertically filtered values go through LDS for the horizontal pass.
@@ -320,69 +390,84 @@ struct PolyArgs {
   PolyCoef c;
 };
 
+constexpr int PE_RB = 4;  // rows per barrier
+
 template <int N>
 __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
-  __shared__ float sv[2][3][256];
+  __shared__ float sv[2][PE_RB][3][256];
   const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
-  const size_t np = (size_t)h * w;
-  const float* __restrict__ I = a.img + (size_t)blockIdx.z * np;
-  float* __restrict__ R = a.R + (size_t)blockIdx.z * 5 * np;
+  const int np = h * w;
+  const float* __restrict__ I = a.img + (size_t)blockIdx.z * (size_t)np;
+  float* __restrict__ R = a.R + (size_t)blockIdx.z * 5 * (size_t)np;
   const int x = (int)blockIdx.x * (256 - 2 * N) - N + tid;
   const int xc = d_clamp(x, 0, w - 1);
   const int y0 = blockIdx.y * a.rows_per_seg;
   const int y1 = min(h, y0 + a.rows_per_seg);
   const bool writer = tid >= N && tid < 256 - N && x < w;
 
-  float ring[2 * N + 1];
+  // ring[j] = source row (y - N + j) of this column for the batch starting at row y
+  float ring[2 * N + PE_RB];
 #pragma unroll
-  for (int j = 0; j < 2 * N + 1; ++j) ring[j] = I[(size_t)d_clamp(y0 - N + j, 0, h - 1) * w + xc];
+  for (int j = 0; j < 2 * N + PE_RB; ++j) ring[j] = I[d_clamp(y0 - N + j, 0, h - 1) * w + xc];
 
-  for (int y = y0; y < y1; ++y) {
+  int buf = 0;
+  for (int y = y0; y < y1; y += PE_RB) {
     // vertical pass (float), same association as the scalar reference
-    float r0 = ring[N] * a.c.g[0], r1 = 0.f, r2 = 0.f;
 #pragma unroll
-    for (int k = 1; k <= N; ++k) {
-      float p = ring[N - k] + ring[N + k];
-      float t0 = r0 + a.c.g[k] * p;
-      float t1 = r2 + a.c.xxg[k] * p;
-      p = ring[N + k] - ring[N - k];
-      float t2 = r1 + a.c.xg[k] * p;
-      r0 = t0; r1 = t2; r2 = t1;
-    }
-    float(*s)[256] = sv[y & 1];
-    s[0][tid] = r0; s[1][tid] = r1; s[2][tid] = r2;
-    // prefetch the next source row while the exchange is in flight
-    float nxt = 0.f;
-    if (y + 1 < y1) nxt = I[(size_t)d_clamp(y + 1 + N, 0, h - 1) * w + xc];
-    __syncthreads();
-    if (writer) {
-      float g0 = a.c.g[0];
-      double b1 = s[0][tid] * g0, b2 = 0, b3 = s[1][tid] * g0, b4 = 0, b5 = s[2][tid] * g0, b6 = 0;
+    for (int r = 0; r < PE_RB; ++r) {
+      float r0 = ring[r + N] * a.c.g[0], r1 = 0.f, r2 = 0.f;
 #pragma unroll
       for (int k = 1; k <= N; ++k) {
-        const float p0 = s[0][tid + k], m0 = s[0][tid - k];
-        const float p1 = s[1][tid + k], m1 = s[1][tid - k];
-        const float p2 = s[2][tid + k], m2 = s[2][tid - k];
-        double tg = p0 + m0;
-        g0 = a.c.g[k];
-        b1 += tg * g0;
-        b4 += tg * a.c.xxg[k];
-        b2 += (p0 - m0) * a.c.xg[k];
-        b3 += (p1 + m1) * g0;
-        b6 += (p1 - m1) * a.c.xg[k];
-        b5 += (p2 + m2) * g0;
+        float p = ring[r + N - k] + ring[r + N + k];
+        float t0 = r0 + a.c.g[k] * p;
+        float t1 = r2 + a.c.xxg[k] * p;
+        p = ring[r + N + k] - ring[r + N - k];
+        float t2 = r1 + a.c.xg[k] * p;
+        r0 = t0; r1 = t2; r2 = t1;
       }
-      const size_t o = (size_t)y * w + x;
-      R[o] = (float)(b3 * a.c.ig11);
-      R[np + o] = (float)(b2 * a.c.ig11);
-      R[2 * np + o] = (float)(b1 * a.c.ig03 + b5 * a.c.ig33);
-      R[3 * np + o] = (float)(b1 * a.c.ig03 + b4 * a.c.ig33);
-      R[4 * np + o] = (float)(b6 * a.c.ig55);
+      sv[buf][r][0][tid] = r0; sv[buf][r][1][tid] = r1; sv[buf][r][2][tid] = r2;
+    }
+    // prefetch the next batch's new source rows while the exchange is in flight
+    float nxt[PE_RB];
+#pragma unroll
+    for (int r = 0; r < PE_RB; ++r) nxt[r] = I[d_clamp(y + PE_RB + N + r, 0, h - 1) * w + xc];
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+      for (int r = 0; r < PE_RB; ++r) {
+        if (y + r < y1) {
+          const float(*s)[256] = sv[buf][r];
+          float g0 = a.c.g[0];
+          double b1 = s[0][tid] * g0, b2 = 0, b3 = s[1][tid] * g0, b4 = 0, b5 = s[2][tid] * g0, b6 = 0;
+#pragma unroll
+          for (int k = 1; k <= N; ++k) {
+            const float p0 = s[0][tid + k], m0 = s[0][tid - k];
+            const float p1 = s[1][tid + k], m1 = s[1][tid - k];
+            const float p2 = s[2][tid + k], m2 = s[2][tid - k];
+            double tg = p0 + m0;
+            g0 = a.c.g[k];
+            b1 += tg * g0;
+            b4 += tg * a.c.xxg[k];
+            b2 += (p0 - m0) * a.c.xg[k];
+            b3 += (p1 + m1) * g0;
+            b6 += (p1 - m1) * a.c.xg[k];
+            b5 += (p2 + m2) * g0;
+          }
+          const int o = (y + r) * w + x;
+          R[o] = (float)(b3 * a.c.ig11);
+          R[np + o] = (float)(b2 * a.c.ig11);
+          R[2 * np + o] = (float)(b1 * a.c.ig03 + b5 * a.c.ig33);
+          R[3 * np + o] = (float)(b1 * a.c.ig03 + b4 * a.c.ig33);
+          R[4 * np + o] = (float)(b6 * a.c.ig55);
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + 1];
-    ring[2 * N] = nxt;
+    for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + PE_RB];
+#pragma unroll
+    for (int r = 0; r < PE_RB; ++r) ring[2 * N + r] = nxt[r];
+    buf ^= 1;
   }
 }
 
@@ -423,6 +508,81 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
   if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
     // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}, selected with a compare rather than a
     // local array index (keeps it out of scratch)
+    auto bsel = [](int i) -> float { return i < 2 ? 0.14f : 0.4472f; };
+    const float scale = (x < BORDER ? bsel(x) : 1.f) * (x >= w - BORDER ? bsel(w - x - 1) : 1.f) *
+                        (y < BORDER ? bsel(y) : 1.f) * (y >= h - BORDER ? bsel(h - y - 1) : 1.f);
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+  }
+  m[0] = r4 * r4 + r6 * r6;
+  m[1] = (r4 + r5) * r6;
+  m[2] = r5 * r5 + r6 * r6;
+  m[3] = r4 * r2 + r6 * r3;
+  m[4] = r6 * r2 + r5 * r3;
+}
+
+// UpdateMatrices split in two so that a thread can put the loads of several rows in flight
+// before consuming any (memory-level parallelism): um_issue computes the gather address and
+// issues the 5 R0 loads and the 10 8-byte R1 loads (two horizontally adjacent floats each);
+// um_finish does the arithmetic, bit-identical to update_matrices_px.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct UmLoads {
+  float q[5];
+  f2u t[5], b[5];  // (R1[gi], R1[gi+1]) and (R1[gi+w], R1[gi+w+1]) per channel
+  float fx, fy;
+  bool inb;
+};
+
+__device__ __forceinline__ void um_issue(const float* __restrict__ R0, const float* __restrict__ R1, int np, int h,
+                                         int w, int x, int y, float2 f, UmLoads& L) {
+  float fx = x + f.x, fy = y + f.y;
+  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  fx -= x1; fy -= y1;
+  L.fx = fx; L.fy = fy;
+  L.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+  int gi = L.inb ? y1 * w + x1 : 0;  // out of range: harmless in-plane address, result unused
+  const int wo = L.inb ? w : 0;
+  const int o = y * w + x;
+  if (ST_ABLATE & 1) gi = L.inb ? (o < np - w - 1 ? o : 0) : 0;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    L.q[c] = R0[c * np + o];
+    if (ST_ABLATE & 4) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = L.q[c]; continue; }
+#ifdef ST_GATHER_DWORD
+    L.t[c].x = R1[c * np + gi]; L.t[c].y = R1[c * np + gi + 1];
+    L.b[c].x = R1[c * np + gi + wo]; L.b[c].y = R1[c * np + gi + wo + 1];
+#else
+    L.t[c] = *reinterpret_cast<const f2u*>(R1 + c * np + gi);
+    L.b[c] = *reinterpret_cast<const f2u*>(R1 + c * np + gi + wo);
+#endif
+  }
+}
+
+__device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x, int y, float2 f, float m[5]) {
+  const float dx = f.x, dy = f.y, fx = L.fx, fy = L.fy;
+  float r2, r3, r4, r5, r6;
+  if (L.inb) {
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    r2 = a00 * L.t[0].x + a01 * L.t[0].y + a10 * L.b[0].x + a11 * L.b[0].y;
+    r3 = a00 * L.t[1].x + a01 * L.t[1].y + a10 * L.b[1].x + a11 * L.b[1].y;
+    r4 = a00 * L.t[2].x + a01 * L.t[2].y + a10 * L.b[2].x + a11 * L.b[2].y;
+    r5 = a00 * L.t[3].x + a01 * L.t[3].y + a10 * L.b[3].x + a11 * L.b[3].y;
+    r6 = a00 * L.t[4].x + a01 * L.t[4].y + a10 * L.b[4].x + a11 * L.b[4].y;
+    r4 = (L.q[2] + r4) * 0.5f;
+    r5 = (L.q[3] + r5) * 0.5f;
+    r6 = (L.q[4] + r6) * 0.25f;
+  } else {
+    r2 = r3 = 0.f;
+    r4 = L.q[2];
+    r5 = L.q[3];
+    r6 = L.q[4] * 0.5f;
+  }
+  r2 = (L.q[0] - r2) * 0.5f;
+  r3 = (L.q[1] - r3) * 0.5f;
+  r2 += r4 * dy + r6 * dx;
+  r3 += r6 * dy + r5 * dx;
+  constexpr int BORDER = 5;
+  if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
     auto bsel = [](int i) -> float { return i < 2 ? 0.14f : 0.4472f; };
     const float scale = (x < BORDER ? bsel(x) : 1.f) * (x >= w - BORDER ? bsel(w - x - 1) : 1.f) *
                         (y < BORDER ? bsel(y) : 1.f) * (y >= h - BORDER ? bsel(h - y - 1) : 1.f);
@@ -639,8 +799,8 @@ __global__ __launch_bounds__(BLUR_T) void k_blur_update(BlurArgs a) {
 constexpr int B2_T = 256, B2_HALO = 8, B2_OUT = B2_T - 2 * B2_HALO, B2_RB = 5, B2_SEG = 5;
 constexpr int B2_NSEG = B2_OUT / B2_SEG;  // 48 segments per row
 
-template <int M, bool RING>
-__global__ __launch_bounds__(B2_T, RING ? 3 : 4) void k_blur_update_v2(BlurArgs a) {
+template <int M, bool RING, int U3, int WAVES>
+__global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
   constexpr int W = 2 * M + 1;
   static_assert(W % B2_RB == 0 && M <= B2_HALO, "ring period must be a multiple of the batch");
   __shared__ float V[B2_RB][5][B2_T];
@@ -792,7 +952,7 @@ __global__ __launch_bounds__(B2_T, RING ? 3 : 4) void k_blur_update_v2(BlurArgs 
         __syncthreads();
         // ---- phase 3: flow store / UpdateMatrices ----
         if (writer) {
-#pragma unroll 1
+#pragma unroll U3
           for (int r = 0; r < B2_RB; ++r) {
             const int y = ybb + r;
             if (y < y1) {
@@ -806,6 +966,221 @@ __global__ __launch_bounds__(B2_T, RING ? 3 : 4) void k_blur_update_v2(BlurArgs 
                 for (int c = 0; c < 5; ++c) Mout[c * np + o] = mm[c];
               }
             }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One full Farneback iteration without materialising M:
+//     flow_out = solve(box_15x15(UpdateMatrices(R0, R1, flow_in)))
+// Same three-phase structure as k_blur_update_v2, but the row that enters the vertical window is
+// COMPUTED in phase 1 from (flow_in, R0, R1) instead of being loaded, and phase 3 only stores the
+// new flow.  HBM traffic per pixel and iteration: flow in 8 + R0 20 + R1 20 (gather) + flow out 8
+// = 56 B, against 60 (UpdateMatrices) + 20 + 8 for the unfused pair of stages; M (20 B/px written
+// and read back every iteration in the reference's formulation) never exists in memory.
+// flow_in is (a) zero (coarsest level, first iteration), (b) resize(coarse flow)*(1/pyr_scale)
+// evaluated on the fly (first iteration of a finer level) or (c) the previous iteration's flow.
+// The values of M are bit-identical to the materialised ones, so results do not change.
+// ---------------------------------------------------------------------------------------------
+struct IterArgs {
+  const float* R;           // frame-indexed planar expansions of this level, or direct R0
+  const int* pairs;         // device (n_pairs x 2) frame slots, or null => R0 = R, R1 = R1_direct
+  const float* R1_direct;
+  const float* flow_in;     // per pair (h,w,2) or null
+  const float* coarse;      // per pair (ch,cw,2) or null
+  float* flow_out;          // per pair (h,w,2), or
+  float* const* flow_ptrs;  // device table of per-pair output frames (used when non-null)
+  int h, w, ch, cw, rows_per_seg;
+  double scale_x, scale_y;  // coarse/fine size ratios as cv::resize computes them
+  float mul;                // 1/pyr_scale
+  double scale;             // 1/(block_size^2)
+};
+
+__device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
+                                               const float* __restrict__ C, int x, int y) {
+  if (C) {
+    // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
+    float fx = (float)((x + 0.5) * a.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= a.cw - 1) { fx = 0.f; sx = a.cw - 1; }
+    float fy = (float)((y + 0.5) * a.scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
+    const float a1 = fx, a0 = 1.f - fx, b0 = 1.f - fy, b1 = fy;
+    float2 ta, tb;
+    if (sx + 1 < a.cw) {
+      float2 p = ld_flow(C, ya * a.cw + sx), q = ld_flow(C, ya * a.cw + sx + 1);
+      ta.x = p.x * a0 + q.x * a1; ta.y = p.y * a0 + q.y * a1;
+      p = ld_flow(C, yb * a.cw + sx); q = ld_flow(C, yb * a.cw + sx + 1);
+      tb.x = p.x * a0 + q.x * a1; tb.y = p.y * a0 + q.y * a1;
+    } else {
+      float2 p = ld_flow(C, ya * a.cw + sx);
+      ta.x = p.x * 1.f; ta.y = p.y * 1.f;
+      p = ld_flow(C, yb * a.cw + sx);
+      tb.x = p.x * 1.f; tb.y = p.y * 1.f;
+    }
+    return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
+  }
+  if (fin) return ld_flow(fin, y * a.w + x);
+  return make_float2(0.f, 0.f);
+}
+
+template <int M, int RB, typename VT>
+__global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
+  constexpr int W = 2 * M + 1;
+  constexpr int NSEG = B2_OUT / RB;  // phase-2 segments per row (RB pixels each)
+  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % RB == 0 && RB * NSEG <= B2_T, "bad batch geometry");
+  __shared__ VT V[RB][5][B2_T];
+  __shared__ float2 F[RB][B2_T];
+  const int tid = threadIdx.x;
+  const int h = a.h, w = a.w;
+  const int np = h * w;
+  const int pr = blockIdx.z;
+  const int x = (int)blockIdx.x * B2_OUT - B2_HALO + tid;
+  const int xc = d_clamp(x, 0, w - 1);
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
+
+  const float* __restrict__ R0;
+  const float* __restrict__ R1;
+  if (a.pairs) {
+    R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
+    R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
+  } else {
+    R0 = a.R;
+    R1 = a.R1_direct;
+  }
+  const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
+  const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
+  float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
+
+  // ring slot s holds M of source row y0 - M + s (clamped) at entry; vs = window sum of row y0
+  float ring[W][5];
+#pragma unroll
+  for (int s0 = 0; s0 < W; s0 += 3) {
+    UmLoads Li[3];
+    float2 f[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
+      f[i] = iter_flow_at(a, fin, C, xc, yy);
+      um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) um_finish(Li[i], h, w, xc, d_clamp(y0 - M + s0 + i, 0, h - 1), f[i], ring[s0 + i]);
+    __builtin_amdgcn_sched_barrier(0);  // bound the loads kept in flight
+  }
+  double vs[5];
+  if (y0 == 0) {
+    // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = (double)(ring[M][c] * (float)(M + 2));
+#pragma unroll
+    for (int yy = 1; yy < M; ++yy)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[M + yy][c];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float d = ring[2 * M][c] - ring[M][c];
+      vs[c] += d;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+    for (int s = 0; s < W; ++s)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
+  }
+
+  // Software pipeline: the gathers of batch b+1 are issued at the end of phase 1 of batch b and
+  // stay in flight across both barriers and phases 2/3; the flows they need were fetched one
+  // batch earlier still.
+  float2 fl[RB], fn[RB];
+  UmLoads L[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    fl[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+    um_issue(R0, R1, np, h, w, xc, d_clamp(y0 + r + M + 1, 0, h - 1), fl[r], L[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+
+  for (int yb = y0; yb < y1; yb += W) {
+#pragma unroll
+    for (int b = 0; b < W / RB; ++b) {
+      const int ybb = yb + b * RB;
+      if (ybb < y1) {  // workgroup-uniform
+        // ---- phase 1: finish the rows entering the window, slide the column sums ----
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          float m[5];
+          um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            V[r][c][tid] = (VT)vs[c];
+            const float d = m[c] - ring[b * RB + r][c];
+            vs[c] += d;
+            ring[b * RB + r][c] = m[c];
+          }
+        }
+        // issue the next batch's loads, prefetch the flows of the batch after it
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          fl[r] = fn[r];
+          um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        __syncthreads();
+        // ---- phase 2: horizontal window + solve ----
+        if (tid < RB * NSEG && !(ST_ABLATE & 8)) {
+          const int r = tid / NSEG, sg = tid - r * NSEG;
+          const int j0 = B2_HALO + sg * RB;
+          if (ST_ABLATE & 16) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+              F[r][j0 + i] = make_float2(V[r][0][j0 + i] + V[r][1][j0 + i] + V[r][2][j0 + i], V[r][3][j0 + i] + V[r][4][j0 + i]);
+          } else {
+          double t[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const VT* vp = &V[r][c][j0 - M];
+            double acc = vp[0];
+#pragma unroll
+            for (int i = 1; i < W; ++i) acc += (double)vp[i];
+            t[c] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            if (i > 0) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c) t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
+            }
+            const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
+            const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
+            if (ST_ABLATE & 2) { F[r][j0 + i] = make_float2((float)(g11 + g12 + g22), (float)(h1 + h2)); continue; }
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          }
+        }
+        __syncthreads();
+        // ---- phase 3: coalesced flow store ----
+        if (writer) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const int y = ybb + r;
+            if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
           }
         }
       }
@@ -872,12 +1247,26 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
   gaussian_kernel(g.ksize, g.sigma, a.taps);
   const double inv_sx = (double)g.lw / w, inv_sy = (double)g.lh / h;
   a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
+  if (g.lh == h && g.lw == w && g.ksize == 3 && w % 4 == 0 && h >= 2 && w >= 8 && !getenv("ST_PYR_GENERIC")) {
+    Pyr0Args z;
+    z.gray = gray; z.img = img; z.h = h; z.w = w; z.k0 = a.taps[1]; z.k1 = a.taps[2];
+    const int bx = (w / 4 + 255) / 256;
+    long long segs = ((long long)ctx->num_cus * 8 + (long long)bx * n - 1) / ((long long)bx * n);
+    int rows = (int)((h + segs - 1) / segs);
+    if (rows < 32) rows = h < 32 ? h : 32;
+    z.rows_per_seg = rows;
+    st_timed t(ctx, ST_K_PYR);
+    hipLaunchKernelGGL(k_pyr0, dim3(bx, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, z);
+    ST_HIP(ctx, hipGetLastError());
+    return ST_OK;
+  }
   if (g.lh == h && g.lw == w) a.mode = PYR_COPY;
   else if (w == 2 * g.lw && h == 2 * g.lh) a.mode = PYR_AREA2;
   else a.mode = PYR_LINEAR;
   const int r = g.ksize / 2;
   a.max_rows = (int)std::ceil((PYR_OH - 1) * a.scale_y) + 3 + 2 * r + 1;
-  size_t lds = sizeof(float) * (size_t)a.max_rows * 2 * PYR_OW;
+  a.max_cols = ((int)std::ceil((PYR_OW - 1) * a.scale_x) + 3 + 2 * r + 1 + 3) / 4 * 4;
+  size_t lds = sizeof(float) * (size_t)a.max_rows * 2 * PYR_OW + (size_t)a.max_rows * a.max_cols;
   if (lds > 64 * 1024) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: pyramid tile needs %zu B of LDS", lds);
   dim3 grid((g.lw + PYR_OW - 1) / PYR_OW, (g.lh + PYR_OH - 1) / PYR_OH, n);
   st_timed t(ctx, ST_K_PYR);
@@ -914,14 +1303,22 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
   if (a.m == 7 && !getenv("ST_BLUR_GENERIC")) {
     const int strips = (a.w + B2_OUT - 1) / B2_OUT;
     // segments are whole ring periods (15 rows) so that the static ring indexing stays aligned
-    int rows = rows_per_segment(ctx, a.h, strips, n_pairs, 2 * a.m + 1);
+    // >= 4 workgroups per CU if the level is big enough; never below one ring period
+    long long segs = ((long long)ctx->num_cus * 4 + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
+    int rows = (int)((a.h + segs - 1) / segs);
     rows = (rows + 14) / 15 * 15;
+    if (rows < 15) rows = 15;
+    if (rows > 135 && a.h > 135) rows = 135;
     a.rows_per_seg = rows;
     dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
     static const int variant = getenv("ST_BLUR_VARIANT") ? atoi(getenv("ST_BLUR_VARIANT")) : 0;
     st_timed t(ctx, ST_K_BLUR_UPDATE);
-    if (variant == 1) hipLaunchKernelGGL((k_blur_update_v2<7, false>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_blur_update_v2<7, true>), grid, dim3(B2_T), 0, ctx->stream, a);
+    if (variant == 1) hipLaunchKernelGGL((k_blur_update_v2<7, false, 1, 4>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (variant == 3) hipLaunchKernelGGL((k_blur_update_v2<7, true, 2, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (variant == 4) hipLaunchKernelGGL((k_blur_update_v2<7, false, 5, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (variant == 5) hipLaunchKernelGGL((k_blur_update_v2<7, false, 2, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (variant == 6) hipLaunchKernelGGL((k_blur_update_v2<7, true, 1, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_blur_update_v2<7, true, 5, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
@@ -930,6 +1327,26 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
   dim3 grid(strips, (a.h + a.rows_per_seg - 1) / a.rows_per_seg, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
   hipLaunchKernelGGL(k_blur_update, grid, dim3(BLUR_T), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
+  const int strips = (a.w + B2_OUT - 1) / B2_OUT;
+  // aim for two full rounds of resident workgroups (2 per CU at 256 VGPRs); whole ring periods
+  long long target = (long long)ctx->num_cus * 4;
+  long long segs = (target + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
+  int rows = (int)((a.h + segs - 1) / segs);
+  rows = (rows + 14) / 15 * 15;
+  if (rows < 15) rows = 15;
+  a.rows_per_seg = rows;
+  dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
+  st_timed t(ctx, ST_K_BLUR_UPDATE);
+  static const int rb = getenv("ST_ITER_RB") ? atoi(getenv("ST_ITER_RB")) : 3;
+  static const int vdouble = getenv("ST_ITER_VDOUBLE") ? atoi(getenv("ST_ITER_VDOUBLE")) : 0;
+  if (rb == 5) hipLaunchKernelGGL((k_flow_iter<7, 5, float>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (vdouble) hipLaunchKernelGGL((k_flow_iter<7, 3, double>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter<7, 3, float>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
@@ -995,34 +1412,86 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
   }
   // per-pair stages, coarse to fine
+  if (p.win_size == 15 && !getenv("ST_UNFUSED")) {
+    // fused iterations (k_flow_iter): M is never materialised; the M scratch doubles as the
+    // two ping-pong flow fields of a level
+    float* fbuf[2] = {M[0], M[1]};
+    int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
+    for (int k = levels; k >= 0; --k) {
+      const int lh = geom[k].lh, lw = geom[k].lw;
+      for (int it = 0; it < p.num_iters; ++it) {
+        const bool last = it == p.num_iters - 1;
+        IterArgs q;
+        memset(&q, 0, sizeof(q));
+        q.R = R[k]; q.pairs = d_pairs; q.h = lh; q.w = lw;
+        q.scale = 1. / ((double)p.win_size * p.win_size);
+        if (it == 0) {
+          if (k < levels) {
+            q.coarse = cflow[cur];
+            q.ch = geom[k + 1].lh; q.cw = geom[k + 1].lw;
+            q.scale_x = 1. / ((double)lw / q.cw);
+            q.scale_y = 1. / ((double)lh / q.ch);
+            q.mul = (float)(1. / p.pyr_scale);
+          }
+        } else {
+          q.flow_in = fbuf[(it - 1) & 1];
+        }
+        if (last) {
+          if (k == 0) q.flow_ptrs = d_outs; else q.flow_out = cflow[cur ^ 1];
+        } else {
+          q.flow_out = fbuf[it & 1];
+        }
+        ST_TRY(launch_flow_iter(ctx, q, npairs));
+      }
+      cur ^= 1;
+    }
+    return ST_OK;
+  }
+  // per-pair stages, coarse to fine.  Within a level the pairs are processed in groups of G:
+  // a group's UpdateMatrices + numIters blur passes run back to back so that its R0/R1/M
+  // working set (166 MB per 1080p pair at level 0) can stay in the 256 MB Infinity Cache
+  // between passes instead of streaming from HBM each time.
+  static const int group_env = getenv("ST_PAIR_GROUP") ? atoi(getenv("ST_PAIR_GROUP")) : 0;
   int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
   for (int k = levels; k >= 0; --k) {
     const int lh = geom[k].lh, lw = geom[k].lw;
-    UMArgs u;
-    memset(&u, 0, sizeof(u));
-    u.R = R[k]; u.pairs = d_pairs; u.M = M[0]; u.h = lh; u.w = lw;
-    if (k < levels) {
-      u.coarse = cflow[cur];
-      u.ch = geom[k + 1].lh; u.cw = geom[k + 1].lw;
-      u.scale_x = 1. / ((double)lw / u.cw);
-      u.scale_y = 1. / ((double)lh / u.ch);
-      u.mul = (float)(1. / p.pyr_scale);
+    const size_t npk = (size_t)lh * lw;
+    int G = npairs;
+    if (group_env > 0) {
+      // groups sized so that (G+1) expansions + 2G matrices fit ~200 MB
+      const double per_pair = 60.0 * npk, per_frame = 20.0 * npk;
+      int fit = (int)((200e6 * group_env - per_frame) / per_pair);
+      G = fit < 1 ? 1 : (fit > npairs ? npairs : fit);
     }
-    ST_TRY(launch_update_matrices(ctx, u, npairs));
-    int mi = 0;
-    for (int it = 0; it < p.num_iters; ++it) {
-      const bool last = it == p.num_iters - 1;
-      BlurArgs b;
-      memset(&b, 0, sizeof(b));
-      b.R = R[k]; b.pairs = d_pairs; b.Min = M[mi]; b.Mout = M[mi ^ 1];
-      b.h = lh; b.w = lw; b.m = p.win_size / 2;
-      b.update = !last; b.write_flow = last;
-      b.scale = 1. / ((double)p.win_size * p.win_size);
-      if (last) {
-        if (k == 0) b.flow_ptrs = d_outs; else b.flow = cflow[cur ^ 1];
+    for (int g0 = 0; g0 < npairs; g0 += G) {
+      const int gn = npairs - g0 < G ? npairs - g0 : G;
+      UMArgs u;
+      memset(&u, 0, sizeof(u));
+      u.R = R[k]; u.pairs = d_pairs + 2 * g0; u.M = M[0] + (size_t)g0 * 5 * npk; u.h = lh; u.w = lw;
+      if (k < levels) {
+        u.ch = geom[k + 1].lh; u.cw = geom[k + 1].lw;
+        u.coarse = cflow[cur] + (size_t)g0 * 2 * u.ch * u.cw;
+        u.scale_x = 1. / ((double)lw / u.cw);
+        u.scale_y = 1. / ((double)lh / u.ch);
+        u.mul = (float)(1. / p.pyr_scale);
       }
-      ST_TRY(launch_blur(ctx, b, npairs));
-      mi ^= 1;
+      ST_TRY(launch_update_matrices(ctx, u, gn));
+      int mi = 0;
+      for (int it = 0; it < p.num_iters; ++it) {
+        const bool last = it == p.num_iters - 1;
+        BlurArgs b;
+        memset(&b, 0, sizeof(b));
+        b.R = R[k]; b.pairs = d_pairs + 2 * g0;
+        b.Min = M[mi] + (size_t)g0 * 5 * npk; b.Mout = M[mi ^ 1] + (size_t)g0 * 5 * npk;
+        b.h = lh; b.w = lw; b.m = p.win_size / 2;
+        b.update = !last; b.write_flow = last;
+        b.scale = 1. / ((double)p.win_size * p.win_size);
+        if (last) {
+          if (k == 0) b.flow_ptrs = d_outs + g0; else b.flow = cflow[cur ^ 1] + (size_t)g0 * 2 * npk;
+        }
+        ST_TRY(launch_blur(ctx, b, gn));
+        mi ^= 1;
+      }
     }
     cur ^= 1;
   }
@@ -1146,6 +1615,30 @@ ST_EXPORT int st_fb_update_matrices(st_ctx* ctx, const float* r0_dev, const floa
     u.flow = flow_dev;
   }
   return launch_update_matrices(ctx, u, 1);
+}
+
+ST_EXPORT int st_fb_flow_iteration(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* flow_in_dev,
+                                    const float* coarse_flow_dev, int ch, int cw, double pyr_scale, int h, int w,
+                                    int block_size, float* flow_out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!r0_dev || !r1_dev || !flow_out_dev || h <= 0 || w <= 0)
+    return st_set_error(ctx, ST_ERR_INVALID, "flow_iteration: bad arguments");
+  if (block_size != 15) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "flow_iteration: block_size=%d (15 only)", block_size);
+  if (flow_out_dev == flow_in_dev) return st_set_error(ctx, ST_ERR_INVALID, "flow_iteration: in-place not allowed");
+  IterArgs q;
+  memset(&q, 0, sizeof(q));
+  q.R = r0_dev; q.R1_direct = r1_dev; q.h = h; q.w = w; q.flow_out = flow_out_dev;
+  q.scale = 1. / ((double)block_size * block_size);
+  if (coarse_flow_dev) {
+    if (ch <= 0 || cw <= 0 || !(pyr_scale > 0)) return st_set_error(ctx, ST_ERR_INVALID, "flow_iteration: bad coarse geometry");
+    q.coarse = coarse_flow_dev; q.ch = ch; q.cw = cw;
+    q.scale_x = 1. / ((double)w / cw);
+    q.scale_y = 1. / ((double)h / ch);
+    q.mul = (float)(1. / pyr_scale);
+  } else {
+    q.flow_in = flow_in_dev;
+  }
+  return launch_flow_iter(ctx, q, 1);
 }
 
 ST_EXPORT int st_fb_update_flow_blur(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* m_in_dev, int h,

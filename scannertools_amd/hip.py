@@ -239,6 +239,28 @@ class HipContext:
         return flow, mout
 
 
+    def flow_iteration(self, r0, r1, flow_in=None, coarse_flow=None, pyr_scale=0.5, block_size=15):
+        """One fused iteration (UpdateMatrices + box blur + solve) as the production path runs it."""
+        self._bind()
+        _require_cuda(r0, torch.float32, "r0")
+        _require_cuda(r1, torch.float32, "r1")
+        _, h, w = r0.shape
+        out = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
+        fp = cp = None
+        ch = cw = 0
+        if coarse_flow is not None:
+            _require_cuda(coarse_flow, torch.float32, "coarse_flow")
+            ch, cw, _ = coarse_flow.shape
+            cp = ctypes.c_void_p(coarse_flow.data_ptr())
+        elif flow_in is not None:
+            _require_cuda(flow_in, torch.float32, "flow_in")
+            fp = ctypes.c_void_p(flow_in.data_ptr())
+        self._check(self._L.st_fb_flow_iteration(self._h, ctypes.c_void_p(r0.data_ptr()), ctypes.c_void_p(r1.data_ptr()),
+                                                 fp, cp, ch, cw, pyr_scale, h, w, block_size,
+                                                 ctypes.c_void_p(out.data_ptr())))
+        return out
+
+
 def fb_levels(h, w, params=None):
     prm = params if params is not None else default_params()
     return _native.lib().st_fb_levels(h, w, ctypes.byref(prm))

@@ -171,6 +171,32 @@ def test_update_flow_blur_other_window(hip_ctx):
         assert np.abs(flow.cpu().numpy() - ref_flow).max() <= 1e-4
 
 
+# ---------------------------------------------------------------- fused iteration (production kernel)
+@pytest.mark.parametrize("h,w", SIZES + [(20, 500), (600, 24), (135, 240)])
+def test_flow_iteration_parity(hip_ctx, h, w):
+    """k_flow_iter == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources."""
+    R0, R1 = _expansions(h + 3, h, w)
+    r0, r1 = cu(planar5(R0)), cu(planar5(R1))
+    rng = np.random.default_rng(h)
+    # (a) zero flow
+    M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
+    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
+    assert np.abs(hip_ctx.flow_iteration(r0, r1).cpu().numpy() - ref).max() <= 1e-4
+    # (b) a given flow field
+    fin = (rng.standard_normal((h, w, 2)) * 2).astype(np.float32)
+    M = oracle.update_matrices(R0, R1, fin)
+    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
+    assert np.abs(hip_ctx.flow_iteration(r0, r1, flow_in=cu(fin)).cpu().numpy() - ref).max() <= 1e-4
+    # (c) up-sampled coarse flow
+    ch, cw = (h + 1) // 2, (w + 1) // 2
+    coarse = (rng.standard_normal((ch, cw, 2)) * 2).astype(np.float32)
+    up = oracle.resize_linear(coarse, h, w) * np.float32(2.0)
+    M = oracle.update_matrices(R0, R1, up)
+    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
+    got = hip_ctx.flow_iteration(r0, r1, coarse_flow=cu(coarse), pyr_scale=0.5).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4
+
+
 # ---------------------------------------------------------------- A3 end to end
 def _check_flow(got, ref):
     assert got.shape == ref.shape and got.dtype == np.float32
