@@ -13,9 +13,10 @@ contiguous shard with no data-path collective ("weak" scaling: per-GPU batch fix
 torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the time.
 
 The JSON line also carries
-  roofline     : for the dominant kernel (k_blur_update: box blur + 2x2 solve + fused
-                 UpdateMatrices), algorithmic bytes / HIP-event time measured live over the timed
-                 region on the stream the kernels run on; peak = 8 TB/s HBM3E spec.
+  roofline     : for the dominant kernel (k_flow_iter: UpdateMatrices + 15x15 box blur + 2x2
+                 solve, one launch per Farneback iteration), algorithmic bytes / HIP-event time
+                 measured live over the timed region on the stream the kernels run on;
+                 peak = 8 TB/s HBM3E spec.
   histogram    : frames/s and roofline of the Histogram kernel alone (same run, own timed loop).
   cpu_baseline : the CPU oracle (oracle/oracle.c, a port of the OpenCV algorithms the reference
                  calls) timed on this host's cores on a bounded sample of the same stream.
@@ -158,11 +159,15 @@ def main():
     frames_total = B * args.steps * world
     fps = frames_total / dt
 
-    # dominant-kernel roofline: per level, (num_iters-1) fused launches move 80 B/px
-    # (M in, R0, R1, M' out) and the last one 28 B/px (M in, flow out)  [SURVEY.md 8d]
+    # dominant-kernel roofline.  k_flow_iter runs numIters times per level and covers the stages
+    # UpdateMatrices (60 B/px + 8 B/px of coarse flow on the finer levels), the two fused
+    # blur+UpdateMatrices passes (80 B/px each) and the final blur (28 B/px) of the
+    # stream-amortised model of SURVEY.md 8d: 248*sum(P_k) + 8*(sum(P_k) - P_0) bytes per pair.
+    # (The kernel itself moves less: M is never materialised -- see DESIGN.md.)
     geom = fb_geometry(h, w)
     sum_p = sum(lh * lw for lh, lw in geom)
-    blur_bytes_per_step = (2 * 80 + 28) * sum_p * B
+    p0 = geom[0][0] * geom[0][1]
+    blur_bytes_per_step = (248 * sum_p + 8 * (sum_p - p0)) * B
     blur_gbs = blur_bytes_per_step * args.steps / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
     flow_model_bytes = 284 * sum_p  # stream-amortised algorithmic bytes per flow frame
 
@@ -204,7 +209,7 @@ def main():
                 "sharding": "contiguous frame shards per GPU + 1 halo frame, no collective",
             },
             "roofline": {
-                "kernel": "k_blur_update",
+                "kernel": "k_flow_iter",
                 "bound": "hbm",
                 "achieved": blur_gbs,
                 "peak": HBM_PEAK_GBS,

@@ -379,6 +379,108 @@ __global__ __launch_bounds__(256) void k_pyr0(Pyr0Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pyramid levels with an exact power-of-two decimation S (sw == S*dw, sh == S*dh): the two
+// blurred samples per axis that cv::resize combines are at S*d + OFF and S*d + OFF + 1
+// (OFF = 0 for S == 2, where OpenCV takes the INTER_AREA 2x2 mean; OFF = S/2 - 1 with weights
+// 1/2, 1/2 for S >= 4).  Each thread owns one output column and marches down the output rows
+// keeping the KS+1 row-filtered source rows of the column filter in registers; every new source
+// row costs KS+1 byte loads (served by L1, neighbours overlap).  No LDS, no barriers.
+// ---------------------------------------------------------------------------------------------
+struct PyrDecArgs {
+  const uint8_t* gray;  // n x (sh*sw)
+  float* img;           // n x (dh*dw)
+  int sh, sw, dh, dw, rows_per_seg;
+  float taps[kMaxTaps];
+};
+
+template <int KS>
+__device__ __forceinline__ float pyr_rowfilter(const float* __restrict__ b, const float* __restrict__ k) {
+  // b[0..KS-1]: source values left to right
+  constexpr int r = KS / 2;
+  if (KS == 3) return b[1] * k[1] + (b[0] + b[2]) * k[2];
+  if (KS == 5) return b[2] * k[2] + (b[1] + b[3]) * k[3] + (b[0] + b[4]) * k[4];
+  float v = k[0] * b[0];
+#pragma unroll
+  for (int i = 1; i < KS; ++i) v += k[i] * b[i];
+  (void)r;
+  return v;
+}
+
+template <int KS>
+__device__ __forceinline__ float pyr_colfilter(const float* __restrict__ c, const float* __restrict__ k) {
+  // c[0..KS-1]: row-filtered values top to bottom
+  constexpr int r = KS / 2;
+  if (KS == 3) return (c[0] + c[2]) * k[2] + c[1] * k[1];
+  float s = k[r] * c[r];
+#pragma unroll
+  for (int i = 1; i <= r; ++i) s += k[r + i] * (c[r + i] + c[r - i]);
+  return s;
+}
+
+template <int S, int KS>
+__global__ __launch_bounds__(256) void k_pyr_dec(PyrDecArgs a) {
+  constexpr int r = KS / 2;
+  constexpr int OFF = S == 2 ? 0 : S / 2 - 1;
+  static_assert(KS + 1 > S, "window must overlap between output rows");
+  const int dx = blockIdx.x * 256 + threadIdx.x;
+  if (dx >= a.dw) return;
+  const int sw = a.sw, sh = a.sh;
+  const uint8_t* __restrict__ src = a.gray + (size_t)blockIdx.z * sh * sw;
+  float* __restrict__ dst = a.img + (size_t)blockIdx.z * a.dh * a.dw;
+  const int xA = S * dx + OFF;
+  const int xl = xA - r;  // leftmost source column of the two row filters
+  const bool edge = xl < 0 || xl + KS >= sw;
+  const int dy0 = blockIdx.y * a.rows_per_seg;
+  const int dy1 = min(a.dh, dy0 + a.rows_per_seg);
+
+  auto hrow = [&](int y, float& hA, float& hB) {
+    const uint8_t* __restrict__ g = src + (size_t)d_reflect101(y, sh) * sw;
+    float b[KS + 1];
+    if (!edge) {
+#pragma unroll
+      for (int i = 0; i <= KS; ++i) b[i] = (float)g[xl + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i <= KS; ++i) b[i] = (float)g[d_reflect101(xl + i, sw)];
+    }
+    hA = pyr_rowfilter<KS>(b, a.taps);
+    hB = pyr_rowfilter<KS>(b + 1, a.taps);
+  };
+
+  // ring[j] = row-filtered source row (S*dy + OFF - r + j), j = 0..KS.  One source row enters
+  // per loop trip (the ring shifts by one register); an output row is emitted every S trips once
+  // the ring is full.  The loop is deliberately not unrolled: it bounds the loads in flight.
+  float hA[KS + 1], hB[KS + 1];
+#pragma unroll
+  for (int j = 0; j <= KS; ++j) hA[j] = hB[j] = 0.f;
+  const int ys0 = S * dy0 + OFF - r;
+  const int nsrc = KS + 1 + S * (dy1 - dy0 - 1);
+  int dy = dy0, until = KS + 1;
+#pragma unroll 1
+  for (int t = 0; t < nsrc; ++t) {
+    float nA, nB;
+    hrow(ys0 + t, nA, nB);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) { hA[j] = hA[j + 1]; hB[j] = hB[j + 1]; }
+    hA[KS] = nA; hB[KS] = nB;
+    if (t + 1 == until) {
+      until += S;
+      const float b00 = pyr_colfilter<KS>(hA, a.taps), b01 = pyr_colfilter<KS>(hB, a.taps);
+      const float b10 = pyr_colfilter<KS>(hA + 1, a.taps), b11 = pyr_colfilter<KS>(hB + 1, a.taps);
+      float out;
+      if (S == 2) {
+        out = ((b00 + b01) + (b10 + b11)) * 0.25f;
+      } else {
+        const float r0 = b00 * 0.5f + b01 * 0.5f, r1 = b10 * 0.5f + b11 * 0.5f;
+        out = r0 * 0.5f + r1 * 0.5f;
+      }
+      dst[(size_t)dy * a.dw + dx] = out;
+      ++dy;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
 // vertically filtered values go through LDS for the horizontal pass.
@@ -1259,6 +1361,31 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
     hipLaunchKernelGGL(k_pyr0, dim3(bx, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, z);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
+  }
+  {
+    // exact power-of-two decimation with the reference's kernel sizes: dedicated marching kernel
+    int S = 0;
+    if (w == 2 * g.lw && h == 2 * g.lh && g.ksize == 3) S = 2;
+    else if (w == 4 * g.lw && h == 4 * g.lh && g.ksize == 9) S = 4;
+    else if (w == 8 * g.lw && h == 8 * g.lh && g.ksize == 19) S = 8;
+    if (S && !getenv("ST_PYR_GENERIC")) {
+      PyrDecArgs z;
+      z.gray = gray; z.img = img; z.sh = h; z.sw = w; z.dh = g.lh; z.dw = g.lw;
+      memcpy(z.taps, a.taps, sizeof(z.taps));
+      const int bx = (g.lw + 255) / 256;
+      long long segs = ((long long)ctx->num_cus * 8 + (long long)bx * n - 1) / ((long long)bx * n);
+      int rows = (int)((g.lh + segs - 1) / segs);
+      const int min_rows = S == 8 ? 4 : 8;
+      if (rows < min_rows) rows = g.lh < min_rows ? g.lh : min_rows;
+      z.rows_per_seg = rows;
+      dim3 grid(bx, (g.lh + rows - 1) / rows, n);
+      st_timed t(ctx, ST_K_PYR);
+      if (S == 2) hipLaunchKernelGGL((k_pyr_dec<2, 3>), grid, dim3(256), 0, ctx->stream, z);
+      else if (S == 4) hipLaunchKernelGGL((k_pyr_dec<4, 9>), grid, dim3(256), 0, ctx->stream, z);
+      else hipLaunchKernelGGL((k_pyr_dec<8, 19>), grid, dim3(256), 0, ctx->stream, z);
+      ST_HIP(ctx, hipGetLastError());
+      return ST_OK;
+    }
   }
   if (g.lh == h && g.lw == w) a.mode = PYR_COPY;
   else if (w == 2 * g.lw && h == 2 * g.lh) a.mode = PYR_AREA2;
