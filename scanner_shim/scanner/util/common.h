@@ -1,0 +1,73 @@
+// Minimal stand-in for the parts of Scanner's public C++ API that the imgproc kernels of
+// scannertools use (scanner-research/scanner is not vendored under /root/reference and is not
+// installed here).  The surface is reconstructed from every use in the reference tree
+// (SURVEY.md section 8b).  A build against real Scanner puts its include directory first on the
+// include path; these headers are only reached when it is absent.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace scanner {
+
+using i8 = int8_t;   using u8 = uint8_t;
+using i16 = int16_t; using u16 = uint16_t;
+using i32 = int32_t; using u32 = uint32_t;
+using i64 = int64_t; using u64 = uint64_t;
+using f32 = float;   using f64 = double;
+
+enum class DeviceType { CPU = 0, GPU = 1 };
+
+struct DeviceHandle {
+  DeviceType type;
+  i32 id;
+  bool operator==(const DeviceHandle& o) const { return type == o.type && id == o.id; }
+  bool operator!=(const DeviceHandle& o) const { return !(*this == o); }
+};
+static const DeviceHandle CPU_DEVICE = {DeviceType::CPU, 0};
+
+// Result message used by validate(): RESULT_ERROR(&valid_, "fmt", ...)
+// (reference use: scannertools_cpp/imgproc/blur_kernel_cpu.cpp:29-33,44)
+struct Result {
+  bool ok = true;
+  std::string message;
+  bool success() const { return ok; }
+  void set_success(bool s) { ok = s; }
+  const std::string& msg() const { return message; }
+  void set_msg(const std::string& m) { message = m; }
+};
+
+inline void result_error(Result* r, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  r->set_success(false);
+  r->set_msg(buf);
+}
+#define RESULT_ERROR(result__, ...) ::scanner::result_error((result__), __VA_ARGS__)
+
+// glog-style fatal logging as the reference kernels use it (LOG(FATAL) << ..., LOG_IF(FATAL, c))
+struct FatalStream {
+  std::string text;
+  bool active;
+  explicit FatalStream(bool a) : active(a) {}
+  template <typename T> FatalStream& operator<<(const T& v) { if (active) append(v); return *this; }
+  void append(const char* s) { text += s; }
+  void append(const std::string& s) { text += s; }
+  template <typename T> void append(const T& v) { text += std::to_string(v); }
+  ~FatalStream() {
+    if (active) { fprintf(stderr, "FATAL: %s\n", text.c_str()); abort(); }
+  }
+};
+#ifndef LOG
+#define FATAL 3
+#define LOG(severity) ::scanner::FatalStream(true)
+#define LOG_IF(severity, cond) ::scanner::FatalStream(static_cast<bool>(cond))
+#endif
+
+}  // namespace scanner

@@ -1,0 +1,355 @@
+// Implementation of the Scanner API stand-in (see scanner/util/common.h) plus a mini engine that
+// drives registered kernels the way Scanner's evaluator does for this path:
+// one kernel instance, rows fed in batches, stencil windows assembled with edge clamping, one
+// output element per input row, engine-owned output memory.  Exposed to Python through a small
+// C API (stshim_*) so that the parity tests exercise Python front-end -> engine -> Scanner-style
+// kernel class -> C ABI -> HIP.  None of this is needed inside a real Scanner deployment.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "scanner/api/kernel.h"
+#include "scanner/api/op.h"
+
+namespace scanner {
+
+// ---- buffers ---------------------------------------------------------------------------------
+namespace {
+struct Block {
+  DeviceHandle device;
+  size_t size;
+  i64 refs;
+};
+std::mutex g_mem_mutex;
+std::map<uintptr_t, Block> g_blocks;  // base address -> block
+
+std::map<uintptr_t, Block>::iterator find_block(const u8* p) {
+  auto it = g_blocks.upper_bound((uintptr_t)p);
+  if (it == g_blocks.begin()) return g_blocks.end();
+  --it;
+  if ((uintptr_t)p < it->first + std::max<size_t>(it->second.size, 1)) return it;
+  return g_blocks.end();
+}
+
+u8* raw_alloc(DeviceHandle device, size_t size) {
+  void* p = nullptr;
+  if (size == 0) size = 1;
+  if (device.type == DeviceType::GPU) {
+    LOG_IF(FATAL, hipSetDevice(device.id) != hipSuccess) << "hipSetDevice failed";
+    LOG_IF(FATAL, hipMalloc(&p, size) != hipSuccess) << "hipMalloc failed";
+  } else {
+    p = malloc(size);
+    LOG_IF(FATAL, p == nullptr) << "malloc failed";
+  }
+  return (u8*)p;
+}
+
+void raw_free(DeviceHandle device, u8* p) {
+  if (device.type == DeviceType::GPU) {
+    (void)hipSetDevice(device.id);
+    (void)hipFree(p);
+  } else {
+    free(p);
+  }
+}
+}  // namespace
+
+u8* new_block_buffer(DeviceHandle device, size_t size, i32 refs) {
+  u8* p = raw_alloc(device, size);
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  g_blocks[(uintptr_t)p] = Block{device, size, refs};
+  return p;
+}
+
+u8* new_buffer(DeviceHandle device, size_t size) { return new_block_buffer(device, size, 1); }
+
+void add_buffer_refs(DeviceHandle /*device*/, u8* buffer, size_t refs) {
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  auto it = find_block(buffer);
+  LOG_IF(FATAL, it == g_blocks.end()) << "add_buffer_ref on unknown buffer";
+  it->second.refs += (i64)refs;
+}
+
+void add_buffer_ref(DeviceHandle device, u8* buffer) { add_buffer_refs(device, buffer, 1); }
+
+void delete_buffer(DeviceHandle /*device*/, u8* buffer) {
+  Block blk{};
+  u8* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    auto it = find_block(buffer);
+    LOG_IF(FATAL, it == g_blocks.end()) << "delete_buffer on unknown buffer";
+    if (--it->second.refs > 0) return;
+    blk = it->second;
+    base = (u8*)it->first;
+    g_blocks.erase(it);
+  }
+  raw_free(blk.device, base);
+}
+
+void memcpy_buffer(u8* dest, DeviceHandle dest_device, const u8* src, DeviceHandle src_device, size_t size) {
+  if (dest_device.type == DeviceType::CPU && src_device.type == DeviceType::CPU) {
+    memcpy(dest, src, size);
+    return;
+  }
+  hipMemcpyKind kind = dest_device.type == DeviceType::CPU   ? hipMemcpyDeviceToHost
+                       : src_device.type == DeviceType::CPU ? hipMemcpyHostToDevice
+                                                            : hipMemcpyDeviceToDevice;
+  LOG_IF(FATAL, hipMemcpy(dest, src, size, kind) != hipSuccess) << "hipMemcpy failed";
+}
+
+size_t shim_live_buffers(DeviceType type) {
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  size_t n = 0;
+  for (auto& kv : g_blocks) n += kv.second.device.type == type;
+  return n;
+}
+
+Frame* new_frame(DeviceHandle device, FrameInfo info) { return new Frame(info, new_buffer(device, info.size())); }
+
+std::vector<Frame*> new_frames(DeviceHandle device, FrameInfo info, i32 num) {
+  std::vector<Frame*> out;
+  if (num <= 0) return out;
+  u8* block = new_block_buffer(device, info.size() * (size_t)num, num);
+  for (i32 i = 0; i < num; ++i) out.push_back(new Frame(info, block + info.size() * (size_t)i));
+  return out;
+}
+
+void delete_frame(DeviceHandle device, Frame* frame) {
+  delete_buffer(device, frame->data);
+  delete frame;
+}
+
+// ---- registries ------------------------------------------------------------------------------
+namespace {
+std::vector<KernelRegistration>& kernel_registry() { static std::vector<KernelRegistration> r; return r; }
+std::vector<OpRegistration>& op_registry() { static std::vector<OpRegistration> r; return r; }
+}  // namespace
+
+KernelBuilder::KernelBuilder(const std::string& op, KernelConstructor ctor, KernelKind kind) {
+  reg_.op_name = op;
+  reg_.constructor = std::move(ctor);
+  reg_.kind = kind;
+}
+KernelBuilder::~KernelBuilder() {
+  if (reg_.constructor) kernel_registry().push_back(reg_);
+}
+OpBuilder::~OpBuilder() {
+  if (!reg_.name.empty()) op_registry().push_back(reg_);
+}
+
+}  // namespace scanner
+
+// ---- mini engine + C API ---------------------------------------------------------------------
+using namespace scanner;
+
+namespace {
+
+struct EngineKernel {
+  KernelRegistration reg;
+  const OpRegistration* op = nullptr;
+  DeviceHandle device;
+  std::unique_ptr<BaseKernel> kernel;
+};
+
+struct EngineOutputs {
+  DeviceHandle device;
+  Elements elements;  // one per input row
+};
+
+void set_err(char* err, size_t n, const std::string& s) {
+  if (err && n) { strncpy(err, s.c_str(), n - 1); err[n - 1] = 0; }
+}
+
+const OpRegistration* find_op(const char* name) {
+  // the last registration of a name wins, like re-registering a module
+  const OpRegistration* f = nullptr;
+  for (auto& o : op_registry()) if (o.name == name) f = &o;
+  return f;
+}
+
+}  // namespace
+
+#define SHIM_EXPORT extern "C" __attribute__((visibility("default")))
+
+SHIM_EXPORT int stshim_num_kernels() { return (int)kernel_registry().size(); }
+
+SHIM_EXPORT int stshim_kernel_info(int i, char* op, int op_len, int* device_type, int* kind, int* can_batch) {
+  if (i < 0 || i >= (int)kernel_registry().size()) return 1;
+  const auto& r = kernel_registry()[i];
+  if (op && op_len > 0) { strncpy(op, r.op_name.c_str(), op_len - 1); op[op_len - 1] = 0; }
+  if (device_type) *device_type = (int)r.device_type;
+  if (kind) *kind = (int)r.kind;
+  if (can_batch) *can_batch = r.can_batch;
+  return 0;
+}
+
+// n_in/n_out: column counts; stencil: up to max_stencil offsets written, count returned in n_stencil
+SHIM_EXPORT int stshim_op_info(const char* op, int* n_in, int* n_out, int* out_is_frame, int* stencil, int max_stencil,
+                               int* n_stencil) {
+  const OpRegistration* o = find_op(op);
+  if (!o) return 1;
+  if (n_in) *n_in = (int)o->inputs.size();
+  if (n_out) *n_out = (int)o->outputs.size();
+  if (out_is_frame) *out_is_frame = !o->outputs.empty() && o->outputs[0].type == ColumnType::Video;
+  int ns = (int)o->stencil.size();
+  if (n_stencil) *n_stencil = ns;
+  for (int i = 0; i < ns && i < max_stencil; ++i) stencil[i] = o->stencil[i];
+  return 0;
+}
+
+SHIM_EXPORT void* stshim_kernel_create(const char* op, int device_type, int device_id, const uint8_t* args,
+                                       size_t n_args, char* err, size_t err_len) {
+  const KernelRegistration* found = nullptr;
+  for (auto& r : kernel_registry())
+    if (r.op_name == op && (int)r.device_type == device_type) found = &r;
+  if (!found) {
+    set_err(err, err_len, std::string("no kernel registered for op ") + op + " on that device type");
+    return nullptr;
+  }
+  auto* ek = new EngineKernel();
+  ek->reg = *found;
+  ek->op = find_op(op);
+  ek->device = DeviceHandle{(DeviceType)device_type, device_id};
+  KernelConfig cfg;
+  cfg.devices.push_back(ek->device);
+  if (ek->op) {
+    for (auto& c : ek->op->inputs) cfg.input_columns.push_back(c.name);
+    for (auto& c : ek->op->outputs) cfg.output_columns.push_back(c.name);
+  }
+  if (args && n_args) cfg.args.assign(args, args + n_args);
+  ek->kernel.reset(found->constructor(cfg));
+  Result res;
+  ek->kernel->validate(&res);
+  if (!res.success()) {
+    set_err(err, err_len, res.msg());
+    delete ek;
+    return nullptr;
+  }
+  ek->kernel->reset();
+  return ek;
+}
+
+SHIM_EXPORT void stshim_kernel_destroy(void* k) { delete (EngineKernel*)k; }
+
+// Runs the op over a stream of n frames.  frames[i]: pointer (on the kernel's device) to a dense
+// (h,w,c) frame of `frame_type`.  batch: rows per execute() for batched kernels.  stencil /
+// n_stencil: override of the op's registered stencil (n_stencil == 0 keeps it).  Rows whose
+// stencil reaches outside [0,n) use the clamped edge frame.
+SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, int h, int w, int c, int frame_type,
+                                    int batch, const int* stencil, int n_stencil, char* err, size_t err_len) {
+  auto* ek = (EngineKernel*)k;
+  if (!ek || n < 0 || (n > 0 && !frames)) { set_err(err, err_len, "bad arguments"); return nullptr; }
+  std::vector<i32> st;
+  if (n_stencil > 0) st.assign(stencil, stencil + n_stencil);
+  else if (ek->op && !ek->op->stencil.empty()) st = ek->op->stencil;
+  else st = {0};
+  const bool stenciled = ek->reg.kind == KernelKind::Stenciled || ek->reg.kind == KernelKind::StenciledBatched;
+  if (!stenciled && (st.size() != 1 || st[0] != 0)) {
+    set_err(err, err_len, "stencil given to a kernel that is not stenciled");
+    return nullptr;
+  }
+  const bool batched = ek->reg.kind == KernelKind::Batched || ek->reg.kind == KernelKind::StenciledBatched;
+  if (batch < 1 || !batched) batch = 1;
+
+  FrameInfo info(h, w, c, (FrameType)frame_type);
+  std::vector<Frame> in_frames;
+  in_frames.reserve(n);
+  for (int i = 0; i < n; ++i) in_frames.emplace_back(info, (u8*)frames[i]);
+  auto elem = [&](int row) {
+    int rr = std::min(std::max(row, 0), n - 1);
+    Element e(&in_frames[rr]);
+    e.index = rr;
+    return e;
+  };
+
+  auto* outs = new EngineOutputs();
+  outs->device = ek->device;
+  for (int r0 = 0; r0 < n; r0 += batch) {
+    const int nb = std::min(batch, n - r0);
+    BatchedElements out_cols(1);
+    switch (ek->reg.kind) {
+      case KernelKind::Batched: {
+        BatchedElements in(1);
+        for (int i = 0; i < nb; ++i) in[0].push_back(elem(r0 + i));
+        static_cast<BatchedKernel*>(ek->kernel.get())->execute(in, out_cols);
+        break;
+      }
+      case KernelKind::StenciledBatched: {
+        StenciledBatchedElements in(1);
+        for (int i = 0; i < nb; ++i) {
+          Elements win;
+          for (i32 s : st) win.push_back(elem(r0 + i + s));
+          in[0].push_back(win);
+        }
+        static_cast<StenciledBatchedKernel*>(ek->kernel.get())->execute(in, out_cols);
+        break;
+      }
+      case KernelKind::Stenciled: {
+        StenciledElements in(1);
+        for (i32 s : st) in[0].push_back(elem(r0 + s));
+        Elements o;
+        static_cast<StenciledKernel*>(ek->kernel.get())->execute(in, o);
+        out_cols[0] = o;
+        break;
+      }
+      case KernelKind::Plain: {
+        Elements in{elem(r0)}, o;
+        static_cast<Kernel*>(ek->kernel.get())->execute(in, o);
+        out_cols[0] = o;
+        break;
+      }
+    }
+    if ((int)out_cols[0].size() != nb) {
+      set_err(err, err_len, "kernel produced " + std::to_string(out_cols[0].size()) + " outputs for " + std::to_string(nb) + " rows");
+      for (auto& e : out_cols[0]) outs->elements.push_back(e);
+      // fall through to cleanup by the caller
+      return outs;
+    }
+    for (auto& e : out_cols[0]) outs->elements.push_back(e);
+  }
+  return outs;
+}
+
+SHIM_EXPORT int stshim_outputs_count(void* o) { return o ? (int)((EngineOutputs*)o)->elements.size() : 0; }
+
+SHIM_EXPORT int stshim_output_get(void* o, int i, const void** data, size_t* size, int* is_frame, int* shape3, int* type) {
+  auto* outs = (EngineOutputs*)o;
+  if (!outs || i < 0 || i >= (int)outs->elements.size()) return 1;
+  Element& e = outs->elements[i];
+  if (e.is_frame) {
+    Frame* f = e.as_frame();
+    if (data) *data = f->data;
+    if (size) *size = f->size();
+    if (shape3) { shape3[0] = f->shape[0]; shape3[1] = f->shape[1]; shape3[2] = f->shape[2]; }
+    if (type) *type = (int)f->type;
+  } else {
+    if (data) *data = e.buffer;
+    if (size) *size = e.size;
+  }
+  if (is_frame) *is_frame = e.is_frame;
+  return 0;
+}
+
+SHIM_EXPORT int stshim_output_copy(void* o, int i, void* dst_host, size_t n) {
+  auto* outs = (EngineOutputs*)o;
+  const void* p = nullptr;
+  size_t sz = 0;
+  if (stshim_output_get(o, i, &p, &sz, nullptr, nullptr, nullptr) || n > sz) return 1;
+  memcpy_buffer((u8*)dst_host, CPU_DEVICE, (const u8*)p, outs->device, n);
+  return 0;
+}
+
+SHIM_EXPORT void stshim_outputs_free(void* o) {
+  auto* outs = (EngineOutputs*)o;
+  if (!outs) return;
+  for (auto& e : outs->elements) {
+    if (e.is_frame) delete_frame(outs->device, e.as_frame());
+    else if (e.buffer) delete_buffer(outs->device, e.buffer);
+  }
+  delete outs;
+}
+
+SHIM_EXPORT size_t stshim_live_buffers(int device_type) { return shim_live_buffers((DeviceType)device_type); }

@@ -1,0 +1,389 @@
+"""In-process stand-in for the slice of the scannerpy graph API that the hot path's tests use.
+
+The reference drives its ops through a Scanner ``Client`` (``sc.io.Input`` -> ``sc.ops.X`` ->
+``sc.io.Output`` ; ``sc.run`` ; ``stream.load()``; /root/reference/scannertools/tests/
+test_all.py:150-177,222-233).  Scanner itself (scanner-research/scanner) is neither vendored nor
+installable here, so this module reproduces exactly that surface for in-memory frame streams:
+
+    sc = Client()
+    sc.ingest_frames('test1', frames_uint8_nhw3)                 # instead of sc.ingest_videos
+    frame = sc.io.Input([NamedVideoStream(sc, 'test1')])
+    hist = sc.ops.Histogram(frame=frame, device=DeviceType.GPU, batch=64)
+    out = NamedStream(sc, 'hist'); sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
+    next(out.load())
+
+C++ ops (``Histogram``, ``OpticalFlow``) are looked up in the kernel registry of
+``libscannertools_imgproc.so`` and executed by its mini engine (scanner_shim/shim.cpp): the same
+``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``) are the
+functions of this package.  What is deliberately absent: the database, video decode, the
+master/worker runtime, scheduling.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _native
+from . import shot_detection as _shot
+from . import types as _types
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+IMGPROC_LIB = os.path.join(_HERE, "lib", "libscannertools_imgproc.so")
+
+
+class DeviceType:
+    CPU = 0
+    GPU = 1
+
+
+class CacheMode:
+    Error = 0
+    Ignore = 1
+    Overwrite = 2
+
+
+class PerfParams:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @classmethod
+    def estimate(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def manual(cls, work_packet_size=None, io_packet_size=None, **kw):
+        return cls(work_packet_size=work_packet_size, io_packet_size=io_packet_size, **kw)
+
+
+_FRAME_DTYPES = {0: np.uint8, 1: np.float32, 2: np.float64}
+
+_LIB = None
+
+
+def _imgproc():
+    """dlopen the op library; its static initialisers register ops and kernels (the mechanism of
+    scannertools_infra/__init__.py:90-100 -> scannerpy.op.register_module)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(IMGPROC_LIB):
+            raise RuntimeError("libscannertools_imgproc.so is not built (%s); run __graft_entry__.build()" % IMGPROC_LIB)
+        _native.lib()  # loads torch's HIP runtime + libscannertools_hip.so first
+        L = ctypes.CDLL(IMGPROC_LIB)
+        vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.stshim_num_kernels.restype = ci
+        L.stshim_kernel_info.argtypes = [ci, ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.stshim_op_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                     ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
+        L.stshim_kernel_create.restype = vp
+        L.stshim_kernel_create.argtypes = [ctypes.c_char_p, ci, ci, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+        L.stshim_kernel_destroy.argtypes = [vp]
+        L.stshim_run_frames.restype = vp
+        L.stshim_run_frames.argtypes = [vp, ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, ctypes.POINTER(ci), ci,
+                                        ctypes.c_char_p, sz]
+        L.stshim_outputs_count.argtypes = [vp]
+        L.stshim_output_get.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ci),
+                                        ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.stshim_output_copy.argtypes = [vp, ci, vp, sz]
+        L.stshim_outputs_free.argtypes = [vp]
+        L.stshim_live_buffers.restype = sz
+        L.stshim_live_buffers.argtypes = [ci]
+        _LIB = L
+    return _LIB
+
+
+def registered_kernels():
+    """[(op name, device type, kind, can_batch)] of the loaded op library."""
+    L = _imgproc()
+    out = []
+    for i in range(L.stshim_num_kernels()):
+        name = ctypes.create_string_buffer(64)
+        dev, kind, cb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.stshim_kernel_info(i, name, 64, ctypes.byref(dev), ctypes.byref(kind), ctypes.byref(cb))
+        out.append((name.value.decode(), dev.value, kind.value, bool(cb.value)))
+    return out
+
+
+def op_info(name):
+    L = _imgproc()
+    n_in, n_out, isf, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    st = (ctypes.c_int * 16)()
+    if L.stshim_op_info(name.encode(), ctypes.byref(n_in), ctypes.byref(n_out), ctypes.byref(isf), st, 16, ctypes.byref(ns)):
+        return None
+    return {"inputs": n_in.value, "outputs": n_out.value, "frame_output": bool(isf.value),
+            "stencil": list(st[:ns.value]) or [0]}
+
+
+# ---------------------------------------------------------------------------------------------
+# graph nodes
+# ---------------------------------------------------------------------------------------------
+class _Node:
+    def length(self):
+        raise NotImplementedError
+
+    def rows(self, idx):
+        """elements for the given sorted list of row indices -> list"""
+        raise NotImplementedError
+
+
+class _InputNode(_Node):
+    def __init__(self, stream):
+        self.stream = stream
+
+    def length(self):
+        return len(self.stream._frames())
+
+    def rows(self, idx):
+        fr = self.stream._frames()
+        return [fr[i] for i in idx]
+
+
+class _SampleNode(_Node):
+    """Range / Gather / Stride: a row-index mapping onto the parent (sc.streams.*)."""
+
+    def __init__(self, parent, index_fn):
+        self.parent = parent
+        self._index_fn = index_fn
+
+    def _map(self):
+        return self._index_fn(self.parent.length())
+
+    @property
+    def reader(self):
+        return getattr(self.parent, "reader", None)
+
+    def length(self):
+        return len(self._map())
+
+    def rows(self, idx):
+        m = self._map()
+        return self.parent.rows([m[i] for i in idx]) if idx else []
+
+
+class _CppOpNode(_Node):
+    def __init__(self, client, name, parent, device, batch, stencil, args):
+        self.client, self.name, self.parent = client, name, parent
+        self.device = DeviceType.CPU if device is None else device
+        self.batch = int(batch) if batch else 1
+        info = op_info(name)
+        self.stencil = list(stencil) if stencil is not None else info["stencil"]
+        self.args = args or b""
+
+    def length(self):
+        return self.parent.length()
+
+    def rows(self, idx):
+        import torch
+        if not idx:
+            return []
+        L = _imgproc()
+        n_total = self.parent.length()
+        err = ctypes.create_string_buffer(512)
+        dev_id = self.client.device_id
+        k = L.stshim_kernel_create(self.name.encode(), self.device, dev_id, self.args, len(self.args), err, 512)
+        if not k:
+            raise RuntimeError("cannot create kernel for op %s on device type %d: %s" % (self.name, self.device, err.value.decode()))
+        out = {}
+        try:
+            smin, smax = min(self.stencil + [0]), max(self.stencil + [0])
+            # contiguous runs of requested rows -> one engine stream each
+            runs, start = [], 0
+            for i in range(1, len(idx) + 1):
+                if i == len(idx) or idx[i] != idx[i - 1] + 1:
+                    runs.append((idx[start], idx[i - 1]))
+                    start = i
+            for a, b in runs:
+                # input rows this run touches; windows that reach outside the stream clamp to its
+                # edges, which is also what the engine does at the edges of the sub-stream
+                lo = max(0, a + smin)
+                hi = min(n_total - 1, b + smax)
+                frames = self.parent.rows(list(range(lo, hi + 1)))
+                if self.device == DeviceType.GPU:
+                    frames = [f if (isinstance(f, torch.Tensor) and f.is_cuda) else
+                              torch.as_tensor(np.ascontiguousarray(f)).cuda(dev_id) for f in frames]
+                    ptrs = [f.data_ptr() for f in frames]
+                else:
+                    frames = [np.ascontiguousarray(f.cpu().numpy() if isinstance(f, torch.Tensor) else f) for f in frames]
+                    ptrs = [f.ctypes.data for f in frames]
+                h, w, c = frames[0].shape
+                dt = frames[0].dtype
+                ftype = 0 if dt in (np.uint8, torch.uint8) else 1
+                tab = (ctypes.c_void_p * len(ptrs))(*ptrs)
+                st = (ctypes.c_int * len(self.stencil))(*self.stencil)
+                if self.device == DeviceType.GPU:
+                    torch.cuda.synchronize(dev_id)  # kernel contexts run on their own streams
+                res = L.stshim_run_frames(k, tab, len(ptrs), h, w, c, ftype, self.batch, st, len(self.stencil), err, 512)
+                if not res or err.value:
+                    if res:
+                        L.stshim_outputs_free(res)
+                    raise RuntimeError("op %s failed: %s" % (self.name, err.value.decode()))
+                try:
+                    for r in range(a, b + 1):
+                        out[r] = self._fetch(L, res, r - lo)
+                finally:
+                    L.stshim_outputs_free(res)
+        finally:
+            L.stshim_kernel_destroy(k)
+        return [out[r] for r in idx]
+
+    @staticmethod
+    def _fetch(L, res, i):
+        data, size = ctypes.c_void_p(), ctypes.c_size_t()
+        isf, typ = ctypes.c_int(), ctypes.c_int()
+        shape = (ctypes.c_int * 3)()
+        if L.stshim_output_get(res, i, ctypes.byref(data), ctypes.byref(size), ctypes.byref(isf), shape, ctypes.byref(typ)):
+            raise RuntimeError("missing output row %d" % i)
+        buf = (ctypes.c_uint8 * size.value)()
+        if L.stshim_output_copy(res, i, buf, size.value):
+            raise RuntimeError("copying output row %d failed" % i)
+        raw = bytes(buf)
+        if isf.value:
+            return np.frombuffer(raw, dtype=_FRAME_DTYPES[typ.value]).reshape(shape[0], shape[1], shape[2])
+        return raw
+
+
+class _PyOpNode(_Node):
+    """A batched python op over one input column (ShotBoundaries: batch = whole stream)."""
+
+    def __init__(self, fn, parent, deserialize):
+        self.fn, self.parent, self.deserialize = fn, parent, deserialize
+
+    def length(self):
+        return self.parent.length()
+
+    def rows(self, idx):
+        n = self.parent.length()
+        elements = [self.deserialize(e) for e in self.parent.rows(list(range(n)))]
+        res = self.fn(None, elements)
+        if len(res) != n:
+            raise RuntimeError("python op returned %d rows for %d inputs" % (len(res), n))
+        return [res[i] for i in idx]
+
+
+class _OutputNode:
+    def __init__(self, node, streams):
+        self.node, self.streams = node, streams
+
+
+# ---------------------------------------------------------------------------------------------
+# streams
+# ---------------------------------------------------------------------------------------------
+class NamedVideoStream:
+    def __init__(self, sc, name):
+        self.sc, self.name = sc, name
+
+    def _frames(self):
+        if self.name not in self.sc._videos:
+            raise KeyError("no video stream named %r (use Client.ingest_frames)" % self.name)
+        return self.sc._videos[self.name]
+
+    def len(self):
+        return len(self._frames())
+
+
+class NamedStream:
+    def __init__(self, sc, name):
+        self.sc, self.name = sc, name
+
+    def _rows(self):
+        if self.name not in self.sc._tables:
+            raise KeyError("stream %r has not been written (run the graph first)" % self.name)
+        return self.sc._tables[self.name]
+
+    def len(self):
+        return len(self._rows()[0])
+
+    def load(self, rows=None, ty=None):
+        data, reader = self._rows()
+        sel = range(len(data)) if rows is None else rows
+        for i in sel:
+            e = data[i]
+            yield reader(e) if reader and isinstance(e, (bytes, type(None))) else e
+
+
+# ---------------------------------------------------------------------------------------------
+# client
+# ---------------------------------------------------------------------------------------------
+class _IO:
+    def __init__(self, sc):
+        self.sc = sc
+
+    def Input(self, streams):
+        if len(streams) != 1:
+            raise ValueError("one stream per Input in this stand-in")
+        return _InputNode(streams[0])
+
+    def Output(self, node, streams):
+        return _OutputNode(node, streams)
+
+
+class _Streams:
+    def Range(self, node, ranges=None, **kw):
+        ranges = ranges if ranges is not None else kw.get("ranges")
+        r = ranges[0]
+
+        def fn(n):
+            return list(range(r["start"], min(r["end"], n)))
+        return _SampleNode(node, fn)
+
+    def Gather(self, node, indices):
+        rows = list(indices[0])
+        return _SampleNode(node, lambda n: rows)
+
+    def Stride(self, node, strides):
+        s = strides[0] if isinstance(strides, (list, tuple)) else strides
+        s = s["stride"] if isinstance(s, dict) else s
+        return _SampleNode(node, lambda n: list(range(0, n, s)))
+
+
+class _Ops:
+    def __init__(self, sc):
+        self.sc = sc
+
+    def Histogram(self, frame, device=None, batch=None, bins=None):
+        """sc.ops.Histogram(frame=..., device=..., batch=...) (tests/test_all.py:154,
+        old/histograms.py:13-14).  ``bins`` is this build's optional extension (default 16)."""
+        import struct
+        args = struct.pack("<i", bins) if bins is not None else b""
+        node = _CppOpNode(self.sc, "Histogram", frame, device, batch, None, args)
+        node.reader = _types.histograms
+        return node
+
+    def OpticalFlow(self, frame, stencil=None, device=None, batch=None):
+        """sc.ops.OpticalFlow(frame=..., stencil=[-1,0], device=...) (tests/test_all.py:166)."""
+        return _CppOpNode(self.sc, "OpticalFlow", frame, device, batch, stencil, b"")
+
+    def ShotBoundaries(self, histograms):
+        """sc.ops.ShotBoundaries(histograms=hist) (tests/test_all.py:227)."""
+        return _PyOpNode(_shot.shot_boundaries, histograms, _types.histograms)
+
+
+class Client:
+    """Minimal ``scannerpy.Client`` look-alike for this path."""
+
+    def __init__(self, device_id=0, **_ignored):
+        self.device_id = device_id
+        self._videos, self._tables = {}, {}
+        self.io, self.ops, self.streams = _IO(self), _Ops(self), _Streams()
+
+    def ingest_frames(self, name, frames):
+        """Register decoded RGB frames (n,h,w,3) uint8 -- numpy or a CUDA torch tensor -- as a
+        named video stream (stands in for ingest_videos + the H.264 decoder)."""
+        self._videos[name] = frames
+
+    def run(self, outputs, perf_params=None, cache_mode=CacheMode.Error, show_progress=False, **_kw):
+        outputs = outputs if isinstance(outputs, (list, tuple)) else [outputs]
+        for o in outputs:
+            for s in o.streams:
+                if s.name in self._tables and cache_mode == CacheMode.Error:
+                    raise RuntimeError("stream %r exists (CacheMode.Error)" % s.name)
+        for o in outputs:
+            n = o.node.length()
+            rows = o.node.rows(list(range(n)))
+            reader = getattr(o.node, "reader", None)
+            for s in o.streams:
+                if s.name in self._tables and cache_mode == CacheMode.Ignore:
+                    continue
+                self._tables[s.name] = (rows, reader)
+
+    def live_device_buffers(self):
+        return _imgproc().stshim_live_buffers(DeviceType.GPU)

@@ -1,0 +1,140 @@
+"""GPU: the reference's own op tests (scannertools/tests/test_all.py:141-177,222-233) replayed
+against this build -- Python front-end -> mini engine -> Scanner-style kernel classes -> C ABI ->
+HIP -- with the value checks the reference lacks (every row compared with the CPU oracle)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+from util import texture_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    """Stands in for scannertools_infra.tests.sc: a client with 'test1' ingested."""
+    client = Client()
+    frames, _ = texture_stream(7, 60, 120, 160)
+    client.ingest_frames("test1", frames)
+    client.ingest_frames("test1_gpu", torch.from_numpy(frames).cuda())
+    return client
+
+
+class DeviceTestBench:
+    def test_cpu(self, sc):
+        self.run(sc, DeviceType.CPU)
+
+    def test_gpu(self, sc):
+        self.run(sc, DeviceType.GPU)
+
+
+class TestHistogram(DeviceTestBench):
+    def run(self, sc, device):
+        input = NamedVideoStream(sc, 'test1')
+        frame = sc.io.Input([input])
+        hist = sc.ops.Histogram(frame=frame, device=device)
+        output = NamedStream(sc, 'test_hist')
+        output_op = sc.io.Output(hist, [output])
+        sc.run(output_op, PerfParams.estimate(), cache_mode=CacheMode.Overwrite, show_progress=False)
+        first = next(output.load())
+        assert len(first) == 3 and all(c.dtype == np.int32 and c.shape == (16,) for c in first)
+        frames = sc._videos['test1']
+        assert output.len() == len(frames)
+        for i, h in enumerate(output.load()):
+            np.testing.assert_array_equal(np.stack(h), oracle.hist_u8c3(frames[i], 16))
+
+
+class TestHistogramBatched(DeviceTestBench):
+    def run(self, sc, device):
+        frame = sc.io.Input([NamedVideoStream(sc, 'test1_gpu' if device == DeviceType.GPU else 'test1')])
+        hist = sc.ops.Histogram(frame=frame, device=device, batch=17, bins=256)
+        output = NamedStream(sc, 'test_hist_b')
+        sc.run(sc.io.Output(hist, [output]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        frames = sc._videos['test1']
+        for i, h in enumerate(output.load()):
+            np.testing.assert_array_equal(np.stack(h), oracle.hist_u8c3(frames[i], 256))
+
+
+class TestOpticalFlow(DeviceTestBench):
+    def run(self, sc, device):
+        input = NamedVideoStream(sc, 'test1')
+        frame = sc.io.Input([input])
+        flow = sc.ops.OpticalFlow(frame=frame, stencil=[-1, 0], device=device)
+        flow_range = sc.streams.Range(flow, ranges=[{'start': 0, 'end': 50}])
+        output = NamedStream(sc, 'test_flow')
+        output_op = sc.io.Output(flow_range, [output])
+        sc.run(output_op, PerfParams.estimate(), cache_mode=CacheMode.Overwrite, show_progress=False)
+        assert output.len() == 50
+
+        flow_array = next(output.load())
+        assert flow_array.dtype == np.float32
+        assert flow_array.shape[0] == 120
+        assert flow_array.shape[1] == 160
+        assert flow_array.shape[2] == 2
+        frames = sc._videos['test1']
+        for i, fl in enumerate(output.load()):
+            a, b = frames[max(i - 1, 0)], frames[i]      # stencil [-1, 0]; row 0 clamps to (0, 0)
+            ref = oracle.optical_flow_rgb(a, b)
+            assert np.abs(fl - ref).max() <= 5e-3
+            if i in (0, 1, 25):
+                assert np.linalg.norm(fl - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-30) + 1e-6
+
+
+class TestOpticalFlowDefaultStencilBatched(DeviceTestBench):
+    def run(self, sc, device):
+        frame = sc.io.Input([NamedVideoStream(sc, 'test1')])
+        flow = sc.ops.OpticalFlow(frame=frame, device=device, batch=8)      # registered stencil {0, 1}
+        gathered = sc.streams.Gather(flow, [[3, 4, 5, 40, 59]])
+        output = NamedStream(sc, 'test_flow_g')
+        sc.run(sc.io.Output(gathered, [output]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        frames = sc._videos['test1']
+        rows = [3, 4, 5, 40, 59]
+        assert output.len() == len(rows)
+        for r, fl in zip(rows, output.load()):
+            ref = oracle.optical_flow_rgb(frames[r], frames[min(r + 1, 59)])   # last row: edge clamp
+            assert np.abs(fl - ref).max() <= 5e-3
+
+
+def test_shot_detection(sc):
+    """tests/test_all.py:222-233 with a stream whose cuts are planted, so the count is known."""
+    rng = np.random.default_rng(0)
+    n, h, w = 600, 36, 48
+    cuts = [97, 230, 231 + 150, 500]
+    frames = np.empty((n, h, w, 3), np.uint8)
+    base = rng.integers(0, 256, (h, w, 3))
+    for i in range(n):
+        if i in cuts:
+            base = rng.integers(0, 256, (h, w, 3))
+        frames[i] = np.clip(base + rng.integers(-3, 4, (h, w, 3)), 0, 255)
+    sc.ingest_frames('shots', frames)
+    input = NamedVideoStream(sc, 'shots')
+    frame = sc.io.Input([input])
+    range_frame = sc.streams.Range(frame, [{'start': 0, 'end': 1000}])
+    hist = sc.ops.Histogram(frame=range_frame)
+    boundaries = sc.ops.ShotBoundaries(histograms=hist)
+    output = NamedStream(sc, 'output')
+    output_op = sc.io.Output(boundaries, [output])
+    sc.run(
+        output_op, PerfParams.manual(work_packet_size=1000, io_packet_size=1000, pipeline_instances_per_node=1),
+        cache_mode=CacheMode.Overwrite, show_progress=False)
+    found = next(output.load(rows=[0]))
+    assert found == cuts
+    assert all(r is None for r in list(output.load())[1:])
+    # identical to the reference algorithm run on oracle histograms
+    assert found == oracle.shot_boundaries(np.stack([oracle.hist_u8c3(f, 16) for f in frames]))
+
+
+def test_engine_frees_every_output_buffer(sc):
+    assert sc.live_device_buffers() == 0
+
+
+def test_cache_mode_error(sc):
+    frame = sc.io.Input([NamedVideoStream(sc, 'test1')])
+    hist = sc.ops.Histogram(frame=sc.streams.Range(frame, [{'start': 0, 'end': 2}]), device=DeviceType.GPU)
+    out = NamedStream(sc, 'test_hist')        # exists from TestHistogram
+    with pytest.raises(RuntimeError):
+        sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
+    with pytest.raises(KeyError):
+        NamedStream(sc, 'never_written').len()

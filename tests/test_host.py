@@ -1,0 +1,168 @@
+"""CPU: host logic (ShotBoundaries, wire readers, sharding) and the C-ABI surface."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "shot_golden.npz"))
+CASES = sorted({k.rsplit("__", 1)[0] for k in GOLD.files})
+
+
+# ---- ShotBoundaries (product) vs the reference's golden outputs: bit-exact ----------------------
+@pytest.mark.parametrize("case", CASES)
+def test_shot_boundaries_matches_reference_golden(case):
+    from scannertools_amd.shot_detection import shot_boundaries
+    h = GOLD[case + "__hist"]
+    frames = [[np.array(h[i, j]) for j in range(3)] for i in range(len(h))]   # wire format of types.histograms
+    res = shot_boundaries(None, frames)
+    assert len(res) == len(h)
+    assert res[0] == GOLD[case + "__bounds"].tolist()
+    assert all(r is None for r in res[1:])                                     # shot_detection.py:28
+
+
+def test_shot_boundaries_contract_and_constants():
+    import scannertools_amd as sa
+    assert sa.WINDOW_SIZE == 500 and sa.BOUNDARY_BATCH == 10000000
+    one = [[np.zeros(16, np.int32)] * 3]
+    assert sa.shot_boundaries(None, one) == [[]]
+    with pytest.raises(ValueError):
+        sa.shot_boundaries(None, [np.zeros((2, 16), np.int32)] * 4)
+
+
+def test_histogram_diffs_is_chebyshev_mean():
+    from scipy.spatial import distance
+    from scannertools_amd.shot_detection import histogram_diffs
+    h = np.random.default_rng(0).integers(0, 5000, (40, 3, 16)).astype(np.int32)
+    ref = [0.0] + [np.mean([distance.chebyshev(h[i - 1][j], h[i][j]) for j in range(3)]) for i in range(1, 40)]
+    np.testing.assert_array_equal(histogram_diffs(h), np.array(ref))
+
+
+def test_wire_readers():
+    from scannertools_amd import types
+    h = np.arange(48, dtype=np.int32)
+    parts = types.histograms(h.tobytes())
+    assert len(parts) == 3 and all(p.dtype == np.int32 and p.shape == (16,) for p in parts)
+    np.testing.assert_array_equal(np.concatenate(parts), h)
+    assert types.histograms(None) is None
+    f = np.arange(2 * 3 * 2, dtype=np.float32)
+    assert types.flow(f.tobytes(), 2, 3).shape == (2, 3, 2) and types.flow(None, 2, 3) is None
+
+
+# ---- sharding -----------------------------------------------------------------------------------
+def test_shard_ranges_cover_and_halo():
+    from scannertools_amd.sharding import flow_shard, local_pairs, shard_range
+    for n in (0, 1, 7, 10000, 10001):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(e - s for s, e in rs) - min(e - s for s, e in rs) <= 1
+    rows, frames = flow_shard(10000, 3, 8)
+    assert rows == (3750, 5000) and frames == (3750, 5001)          # one halo frame
+    rows, frames = flow_shard(10000, 7, 8)
+    assert frames == (8750, 10000)                                   # last shard: edge clamp, no halo
+    p = local_pairs(rows, frames, 10000)
+    assert p[0].tolist() == [0, 1] and p[-1].tolist() == [1249, 1249]  # last row pairs the last frame with itself
+    rows, frames = flow_shard(100, 1, 4, stencil=(-1, 0))
+    assert rows == (25, 50) and frames == (24, 50)
+
+
+def test_two_rank_gloo_shot_pipeline(tmp_path):
+    """world_size 2 over gloo on CPU: shard -> gather on rank 0 -> ShotBoundaries == single-process."""
+    out = str(tmp_path / "b.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "tests", "_dist_worker.py"), out, "1000"]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert np.load(out).tolist() == GOLD["s0_n1000_b16__bounds"].tolist()
+
+
+# ---- C ABI --------------------------------------------------------------------------------------
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "scannertools_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(st_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scannertools_amd import _native
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(_native.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "header declares %s but the library does not export it" % n
+    # and the Python binding covers the same set
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_abi_host_only_entry_points():
+    from scannertools_amd import _native
+    import oracle
+    L = _native.lib()
+    assert L.st_abi_version() == 1
+    assert L.st_status_string(0) == b"ok" and b"unsupported" in L.st_status_string(4)
+    p = _native.default_params()
+    assert (p.num_levels, p.pyr_scale, p.fast_pyramids, p.win_size, p.num_iters, p.poly_n, p.poly_sigma, p.flags) == \
+        (3, 0.5, 0, 15, 3, 5, 1.2, 0)                      # optical_flow_kernel_cpu.cpp:16
+    from scannertools_amd.hip import fb_level_geom, fb_levels
+    for h, w in ((1080, 1920), (2160, 3840), (480, 640), (203, 317), (48, 64)):
+        assert fb_levels(h, w) == oracle.fb_levels(h, w)
+        for k in range(fb_levels(h, w) + 1):
+            assert fb_level_geom(h, w, k) == oracle.fb_level_geom(h, w, k)
+    with pytest.raises(TypeError):
+        _native.default_params(nonsense=1)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a GPU nothing computes: context creation reports an error, the front-end raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scannertools_amd import _native
+    from scannertools_amd.hip import HipContext
+    h = ctypes.c_void_p()
+    assert _native.lib().st_ctx_create(0, ctypes.byref(h)) != 0 and not h.value
+    with pytest.raises(RuntimeError):
+        HipContext(0)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "scannertools_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt and "oracle.c" not in txt.replace("oracle/oracle.c", ""), f
+
+
+# ---- Scanner op library ---------------------------------------------------------------------------
+def test_imgproc_library_registrations():
+    from scannertools_amd import engine
+    regs = engine.registered_kernels()
+    ops = {(name, dev) for name, dev, _, _ in regs}
+    assert {("Histogram", 0), ("Histogram", 1), ("OpticalFlow", 0), ("OpticalFlow", 1)} <= ops
+    for name, dev, kind, can_batch in regs:
+        assert can_batch                                           # .batch() as in histogram_kernel_cpu.cpp:54-57
+        assert kind == (1 if name == "Histogram" else 3)           # Batched / StenciledBatched
+    assert engine.op_info("OpticalFlow")["stencil"] == [0, 1]      # optical_flow_kernel_cpu.cpp:51-54
+    assert engine.op_info("OpticalFlow")["frame_output"] and not engine.op_info("Histogram")["frame_output"]
+    assert engine.op_info("NoSuchOp") is None
+
+
+def test_engine_reports_missing_gpu_cleanly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scannertools_amd.engine import Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+    sc = Client()
+    sc.ingest_frames("v", np.zeros((2, 8, 8, 3), np.uint8))
+    frame = sc.io.Input([NamedVideoStream(sc, "v")])
+    hist = sc.ops.Histogram(frame=frame, device=DeviceType.CPU)
+    with pytest.raises(RuntimeError, match="st_ctx_create"):
+        sc.run(sc.io.Output(hist, [NamedStream(sc, "o")]), PerfParams.estimate())

@@ -1,0 +1,122 @@
+"""CPU: the oracle against golden vectors and analytic known answers."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from util import random_frames, smooth_texture, translated_rgb_pair
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "shot_golden.npz"))
+CASES = sorted({k.rsplit("__", 1)[0] for k in GOLD.files})
+
+
+# ---- A8: pinned by the reference itself (fixtures made by importing shot_detection.py) ----
+@pytest.mark.parametrize("case", CASES)
+def test_shot_oracle_matches_reference_golden(case):
+    h = GOLD[case + "__hist"]
+    assert oracle.shot_boundaries(h) == GOLD[case + "__bounds"].tolist()
+
+
+# ---- A0/A1: pinned by definition -------------------------------------------------------------
+@pytest.mark.parametrize("bins", [16, 256, 10])
+def test_hist_oracle_matches_bincount(bins):
+    f = random_frames(bins, 2, 53, 71)
+    for fr in f:
+        ref = np.stack([np.bincount(((fr[..., c].astype(np.int64) * bins) >> 8).ravel(), minlength=bins) for c in range(3)])
+        np.testing.assert_array_equal(oracle.hist_u8c3(fr, bins), ref)
+
+
+def test_hist_oracle_known_answers():
+    z = np.zeros((40, 50, 3), np.uint8)
+    h = oracle.hist_u8c3(z, 16)
+    assert (h[:, 0] == 2000).all() and h[:, 1:].sum() == 0
+    f = random_frames(1, 1, 64, 64)[0]
+    h256, h16 = oracle.hist_u8c3(f, 256), oracle.hist_u8c3(f, 16)
+    assert (h256.sum(axis=1) == 64 * 64).all()
+    np.testing.assert_array_equal(h256.reshape(3, 16, 16).sum(axis=2), h16)   # 256 -> 16 fold
+
+
+# ---- A2 -------------------------------------------------------------------------------------
+def test_gray_oracle_known_answers():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 90]]], np.uint8)
+    for bits, cb, cg, cr in ((15, 3735, 19235, 9798), (14, 1868, 9617, 4899)):
+        assert cb + cg + cr == 1 << bits
+        g = oracle.gray_u8(px, bits)[0]
+        rnd = 1 << (bits - 1)
+        assert g[0] == (255 * cb + rnd) >> bits == 29      # R byte gets the B weight (BGR2GRAY on RGB)
+        assert g[1] == (255 * cg + rnd) >> bits
+        assert g[2] == (255 * cr + rnd) >> bits
+        assert g[3] == 255 and g[4] == 0
+        assert g[5] == (10 * cb + 200 * cg + 90 * cr + rnd) >> bits
+
+
+# ---- A3 driver geometry ------------------------------------------------------------------------
+def test_level_geometry():
+    assert oracle.fb_levels(1080, 1920) == 3
+    assert [oracle.fb_level_geom(1080, 1920, k) for k in range(4)] == [
+        (1080, 1920, 0.0, 3), (540, 960, 0.5, 3), (270, 480, 1.5, 9), (135, 240, 3.5, 19)]
+    assert oracle.fb_levels(2160, 3840) == 3
+    assert oracle.fb_levels(480, 640) == 3 and oracle.fb_level_geom(480, 640, 3)[:2] == (60, 80)
+    assert oracle.fb_levels(48, 64) == 0          # 32-px rule crops every coarser level
+
+
+def test_gaussian_kernels():
+    np.testing.assert_array_equal(oracle.gaussian_kernel(3, 0.0), [0.25, 0.5, 0.25])
+    for n, s in ((3, 0.5), (9, 1.5), (19, 3.5)):
+        k = oracle.gaussian_kernel(n, s)
+        assert abs(k.sum() - 1) < 1e-6 and np.allclose(k, k[::-1]) and k.argmax() == n // 2
+
+
+def test_blur_preserves_constant_and_resize_modes():
+    c = np.full((20, 30), 7.0, np.float32)
+    np.testing.assert_allclose(oracle.gaussian_blur(c, 9, 1.5), 7.0, rtol=1e-6)
+    a = np.arange(48, dtype=np.float32).reshape(6, 8)
+    np.testing.assert_array_equal(oracle.resize_linear(a, 6, 8), a)                 # identity copy
+    np.testing.assert_allclose(oracle.resize_linear(a, 3, 4), (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]) / 4)
+    up = oracle.resize_linear(a, 12, 16)
+    assert up.shape == (12, 16) and up[0, 0] == a[0, 0] and up[-1, -1] == a[-1, -1]
+
+
+# ---- A4 -------------------------------------------------------------------------------------
+def test_polyexp_recovers_quadratic_coefficients():
+    h, w = 64, 80
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    a, bx, by, cxx, cyy, cxy = 3.0, 0.5, -0.25, 0.01, 0.02, -0.015
+    I = a + bx * (x - 40) + by * (y - 30) + cxx * (x - 40) ** 2 + cyy * (y - 30) ** 2 + cxy * (x - 40) * (y - 30)
+    R = oracle.polyexp(I.astype(np.float32))
+    for yy, xx in ((30, 40), (20, 25), (45, 60)):
+        exp = [by + 2 * cyy * (yy - 30) + cxy * (xx - 40), bx + 2 * cxx * (xx - 40) + cxy * (yy - 30), cyy, cxx, cxy]
+        np.testing.assert_allclose(R[yy, xx], exp, atol=2e-6)
+
+
+# ---- A5 quirk ---------------------------------------------------------------------------------
+def test_update_matrices_last_row_col_quirk():
+    f0, _ = translated_rgb_pair(9, 60, 70, 0, 0)
+    R = oracle.polyexp(oracle.gray_u8(f0).astype(np.float32))
+    M = oracle.update_matrices(R, R, np.zeros((60, 70, 2), np.float32))
+    assert np.abs(M[:-1, :-1, 3:]).max() == 0
+    assert np.abs(M[-1, :, 3:]).max() > 0 and np.abs(M[:, -1, 3:]).max() > 0
+
+
+# ---- A3 end to end ----------------------------------------------------------------------------
+def test_flow_oracle_recovers_translation():
+    tx, ty = 3, -2
+    t = smooth_texture(0, 280, 360)
+    f0 = t[20:260, 20:340].astype(np.uint8)
+    f1 = t[20 - ty:260 - ty, 20 - tx:340 - tx].astype(np.uint8)
+    fl = oracle.farneback(f0, f1)
+    inner = fl[40:-40, 40:-40]
+    assert abs(np.median(inner[..., 0]) - tx) < 0.01 and abs(np.median(inner[..., 1]) - ty) < 0.01
+    assert np.abs(inner - [tx, ty]).mean() < 0.01
+    z = oracle.farneback(f0, f0)
+    assert np.abs(z[:100, :150]).max() < 1e-3
+
+
+def test_flow_oracle_direction_and_rgb_entry():
+    f0, f1 = translated_rgb_pair(4, 120, 160, 2, 1)
+    a = oracle.optical_flow_rgb(f0, f1)
+    b = oracle.optical_flow_rgb(f1, f0)
+    inner = slice(30, -30)
+    assert np.median(a[inner, inner, 0]) > 1.5 and np.median(b[inner, inner, 0]) < -1.5
+    np.testing.assert_array_equal(a, oracle.farneback(oracle.gray_u8(f0), oracle.gray_u8(f1)))
