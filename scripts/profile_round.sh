@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round profile: the bench line, rocprofv3 --kernel-trace --stats of the SAME command, and PMC
+# passes (separate runs, counters only) for HBM traffic.  Run on the GPU box from the repo root:
+#   bash scripts/profile_round.sh <tag>
+set -u
+tag=$1
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/round_$tag
+mkdir -p $out
+python3 bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --no-cpu-baseline > $out/trace.log 2>&1
+pass() { name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/$name.log 2>&1
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pass wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
+pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS
+cat $out/bench.json
