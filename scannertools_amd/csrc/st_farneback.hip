@@ -646,6 +646,7 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   const int wo = L.inb ? w : 0;
   const int o = y * w + x;
   if (ST_ABLATE & 1) gi = L.inb ? (o < np - w - 1 ? o : 0) : 0;
+  if (ST_ABLATE & 32) { const int yz = (y1 + (y % 3) * 2) % (h - 1); gi = L.inb ? yz * w + x1 : 0; }
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     L.q[c] = R0[c * np + o];
@@ -1099,11 +1100,15 @@ struct IterArgs {
   double scale_x, scale_y;  // coarse/fine size ratios as cv::resize computes them
   float mul;                // 1/pyr_scale
   double scale;             // 1/(block_size^2)
+  long long* prof;          // ST_PROF builds only: per-phase s_memtime stamps of a few workgroups
 };
 
+enum { FLOW_ZERO = 0, FLOW_FIELD = 1, FLOW_COARSE = 2, FLOW_ANY = 3 };
+
+template <int MODE = FLOW_ANY>
 __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
                                                const float* __restrict__ C, int x, int y) {
-  if (C) {
+  if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
     // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
     float fx = (float)((x + 0.5) * a.scale_x - 0.5);
     int sx = (int)floorf(fx);
@@ -1129,11 +1134,11 @@ __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* _
     }
     return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
   }
-  if (fin) return ld_flow(fin, y * a.w + x);
+  if (MODE == FLOW_FIELD || (MODE == FLOW_ANY && fin)) return ld_flow(fin, y * a.w + x);
   return make_float2(0.f, 0.f);
 }
 
-template <int M, int RB, typename VT>
+template <int M, int RB, typename VT, int MODE>
 __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   constexpr int W = 2 * M + 1;
   constexpr int NSEG = B2_OUT / RB;  // phase-2 segments per row (RB pixels each)
@@ -1172,7 +1177,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
-      f[i] = iter_flow_at(a, fin, C, xc, yy);
+      f[i] = iter_flow_at<MODE>(a, fin, C, xc, yy);
       um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
     }
 #pragma unroll
@@ -1209,17 +1214,28 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   UmLoads L[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
-    fl[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+    fl[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
     um_issue(R0, R1, np, h, w, xc, d_clamp(y0 + r + M + 1, 0, h - 1), fl[r], L[r]);
   }
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
 
-  for (int yb = y0; yb < y1; yb += W) {
-#pragma unroll
-    for (int b = 0; b < W / RB; ++b) {
-      const int ybb = yb + b * RB;
-      if (ybb < y1) {  // workgroup-uniform
+#ifdef ST_PROF
+  int pslot = 0;
+  const bool pon = a.prof && tid == 64 && blockIdx.x == 3 && blockIdx.y == 1 && (blockIdx.z == 0 || blockIdx.z == 20);
+  long long* pbuf = a.prof + (blockIdx.z == 0 ? 0 : 4096);
+#define PSTAMP() do { __builtin_amdgcn_sched_barrier(0); if (pon && pslot < 4000) pbuf[pslot++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP() do {} while (0)
+#endif
+  // One batch per trip; the ring is kept statically indexed by shifting it RB rows per batch
+  // (60 register moves) instead of unrolling the loop over the ring period: the unrolled body
+  // was ~100 KB of code and thrashed the 64 KB instruction cache.
+#pragma unroll 1
+  for (int ybb = y0; ybb < y1; ybb += RB) {
+    {
+      {
+        PSTAMP();
         // ---- phase 1: finish the rows entering the window, slide the column sums ----
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -1228,11 +1244,27 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             V[r][c][tid] = (VT)vs[c];
-            const float d = m[c] - ring[b * RB + r][c];
+            const float d = m[c] - ring[r][c];
             vs[c] += d;
-            ring[b * RB + r][c] = m[c];
+            ring[r][c] = m[c];  // parked in the slot it frees; rotated into place below
           }
         }
+        {
+          float tmp[RB][5];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) tmp[r][c] = ring[r][c];
+#pragma unroll
+          for (int j = 0; j + RB < W; ++j)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) ring[j][c] = ring[j + RB][c];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
+        }
+        PSTAMP();
         // issue the next batch's loads, prefetch the flows of the batch after it
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -1240,8 +1272,10 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        PSTAMP();
         __syncthreads();
+        PSTAMP();
         // ---- phase 2: horizontal window + solve ----
         if (tid < RB * NSEG && !(ST_ABLATE & 8)) {
           const int r = tid / NSEG, sg = tid - r * NSEG;
@@ -1276,7 +1310,269 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           }
           }
         }
+        PSTAMP();
         __syncthreads();
+        PSTAMP();
+        // ---- phase 3: coalesced flow store ----
+        if (writer) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const int y = ybb + r;
+            if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_flow_iter_t: the same iteration with the R0 rows and an R1 tile brought into LDS by wide
+// LDS-DMA loads (global_load_lds, 16 B per lane = one 256-column row segment per wave
+// instruction) instead of 15 narrow per-lane loads per pixel.  Measured on k_flow_iter: the
+// vector-memory *instruction* pipeline, not HBM, was the limiter (load issue = 57 % of a
+// batch).  Per batch a workgroup now issues ~19 memory instructions per wave instead of 48.
+//   R0T  [RB][5][256]      the entering rows of R0 for the strip
+//   R1T  [T_TR][5][T_TC]   rows tyA.. / columns txA.. of R1, where (txA,tyA) is the minimum of
+//                          the gather origins of the batch (reduced over the workgroup one batch
+//                          ahead from the prefetched flows); lanes whose 2x2 footprint falls
+//                          outside the tile (large flow spread) take per-lane global loads.
+// Requires w % 4 == 0 (16-byte aligned row segments); other widths use k_flow_iter.
+// ---------------------------------------------------------------------------------------------
+constexpr int T_TR = 6, T_TC = 288;
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int M, int RB>
+__global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
+  constexpr int W = 2 * M + 1;
+  constexpr int NSEG = B2_OUT / RB;
+  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % RB == 0 && RB * NSEG <= B2_T, "bad batch geometry");
+  // one LDS object (a second one makes hipcc drain vmcnt before unrelated ds_reads)
+  constexpr int OFF_V = 0, OFF_F = OFF_V + RB * 5 * B2_T, OFF_R0 = OFF_F + RB * B2_T * 2,
+                OFF_R1 = OFF_R0 + RB * 5 * B2_T, OFF_RED = OFF_R1 + T_TR * 5 * T_TC, SMEM = OFF_RED + 4;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float(*V)[5][B2_T] = reinterpret_cast<float(*)[5][B2_T]>(smem + OFF_V);
+  float2(*F)[B2_T] = reinterpret_cast<float2(*)[B2_T]>(smem + OFF_F);
+  float(*R0T)[5][B2_T] = reinterpret_cast<float(*)[5][B2_T]>(smem + OFF_R0);
+  float(*R1T)[5][T_TC] = reinterpret_cast<float(*)[5][T_TC]>(smem + OFF_R1);
+  int* red = reinterpret_cast<int*>(smem + OFF_RED);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = a.h, w = a.w;
+  const int np = h * w;
+  const int pr = blockIdx.z;
+  const int sx0 = (int)blockIdx.x * B2_OUT - B2_HALO;
+  const int x = sx0 + tid;
+  const int xc = d_clamp(x, 0, w - 1);
+  const int lxc = xc - sx0;  // this thread's (clamped) column inside the strip tiles
+  const int y0 = blockIdx.y * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
+
+  const float* __restrict__ R0;
+  const float* __restrict__ R1;
+  if (a.pairs) {
+    R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
+    R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
+  } else {
+    R0 = a.R;
+    R1 = a.R1_direct;
+  }
+  const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
+  const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
+  float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
+
+  // ---- ring / column-sum initialisation (per-lane loads; once per segment) ----
+  float ring[W][5];
+#pragma unroll
+  for (int s0 = 0; s0 < W; s0 += 3) {
+    UmLoads Li[3];
+    float2 f[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
+      f[i] = iter_flow_at(a, fin, C, xc, yy);
+      um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) um_finish(Li[i], h, w, xc, d_clamp(y0 - M + s0 + i, 0, h - 1), f[i], ring[s0 + i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double vs[5];
+  if (y0 == 0) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = (double)(ring[M][c] * (float)(M + 2));
+#pragma unroll
+    for (int yy = 1; yy < M; ++yy)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[M + yy][c];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float d = ring[2 * M][c] - ring[M][c];
+      vs[c] += d;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+    for (int s = 0; s < W; ++s)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
+  }
+
+  // gather origin of one (column, row, flow): returns false when the bilinear footprint leaves the image
+  auto origin = [&](int yy, float2 f, int& x1, int& y1i) -> bool {
+    const float gx = xc + f.x, gy = yy + f.y;
+    x1 = (int)floorf(gx); y1i = (int)floorf(gy);
+    return (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1i < (unsigned)(h - 1);
+  };
+  // workgroup minimum of the gather origins of a batch -> red[0..1]
+  auto reduce_origin = [&](const float2* fb, int ybase) {
+    int mx = 0x7fffffff, my = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      int x1, y1i;
+      if (origin(d_clamp(ybase + r + M + 1, 0, h - 1), fb[r], x1, y1i)) { mx = min(mx, x1); my = min(my, y1i); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o)); my = min(my, __shfl_xor(my, o)); }
+    if (lane == 0) { atomicMin(&red[0], mx); atomicMin(&red[1], my); }
+  };
+  // DMA of the R0 rows and the R1 tile of the batch whose first entering row is ybase + M + 1
+  auto issue_tiles = [&](int ybase, int txA, int tyA) {
+    for (int p = wv; p < RB * 5; p += 4) {
+      const int r = p / 5, c = p - r * 5;
+      const int row = d_clamp(ybase + r + M + 1, 0, h - 1);
+      const int col = sx0 + 4 * lane;
+      if (col >= 0 && col < w) glds16(R0 + c * np + row * w + col, &R0T[r][c][0]);
+    }
+    if (txA != 0x7fffffff) {
+      for (int p = wv; p < T_TR * 5; p += 4) {
+        const int rr = p / 5, c = p - rr * 5;
+        const int row = tyA + rr;
+        if (row < h) {
+          const float* g = R1 + c * np + row * w + txA;
+          if (txA + 4 * lane < w) glds16(g + 4 * lane, &R1T[rr][c][0]);
+          if (lane < (T_TC - 256) / 4 && txA + 256 + 4 * lane < w) glds16(g + 256 + 4 * lane, &R1T[rr][c][256]);
+        }
+      }
+    }
+  };
+
+  float2 fl[RB], fn[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+  if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
+  __syncthreads();
+  reduce_origin(fl, y0);
+  __syncthreads();
+  int txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3), tyA = red[1];
+  issue_tiles(y0, txA, tyA);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+
+#ifdef ST_PROF
+  int pslot = 0;
+  const bool pon = a.prof && tid == 64 && blockIdx.x == 3 && blockIdx.y == 1 && (blockIdx.z == 0 || blockIdx.z == 20);
+  long long* pbuf = a.prof + (blockIdx.z == 0 ? 0 : 4096);
+#endif
+  for (int yb = y0; yb < y1; yb += W) {
+#pragma unroll
+    for (int b = 0; b < W / RB; ++b) {
+      const int ybb = yb + b * RB;
+      if (ybb < y1) {  // workgroup-uniform
+        PSTAMP();
+        __syncthreads();  // (A) tiles of this batch have landed (vmcnt drained by the barrier); red consumed
+        PSTAMP();
+        if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
+        // ---- phase 1: UpdateMatrices of the entering rows from the LDS tiles, slide the column sums ----
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int yy = d_clamp(ybb + r + M + 1, 0, h - 1);
+          UmLoads L;
+          int x1, y1i;
+          L.inb = origin(yy, fl[r], x1, y1i);
+          {
+            const float gx = xc + fl[r].x, gy = yy + fl[r].y;
+            L.fx = gx - x1; L.fy = gy - y1i;
+          }
+#pragma unroll
+          for (int c = 0; c < 5; ++c) L.q[c] = R0T[r][c][lxc];
+          const int lx = x1 - txA, ly = y1i - tyA;
+          const bool intile = L.inb && lx >= 0 && lx + 1 < T_TC && ly >= 0 && ly + 1 < T_TR;
+          if (intile) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+              L.t[c].x = R1T[ly][c][lx]; L.t[c].y = R1T[ly][c][lx + 1];
+              L.b[c].x = R1T[ly + 1][c][lx]; L.b[c].y = R1T[ly + 1][c][lx + 1];
+            }
+          } else if (L.inb) {
+            const int gi = y1i * w + x1;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+              L.t[c].x = R1[c * np + gi]; L.t[c].y = R1[c * np + gi + 1];
+              L.b[c].x = R1[c * np + gi + w]; L.b[c].y = R1[c * np + gi + w + 1];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = 0.f; }
+          }
+          float m[5];
+          um_finish(L, h, w, xc, yy, fl[r], m);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            V[r][c][tid] = (float)vs[c];
+            const float d = m[c] - ring[b * RB + r][c];
+            vs[c] += d;
+            ring[b * RB + r][c] = m[c];
+          }
+        }
+        PSTAMP();
+        __syncthreads();  // (A2) red reset visible before the new minima arrive
+        reduce_origin(fn, ybb + RB);
+        __syncthreads();  // (B) V visible, tiles free, red complete
+        PSTAMP();
+        txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3);
+        tyA = red[1];
+        issue_tiles(ybb + RB, txA, tyA);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) fl[r] = fn[r];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        PSTAMP();
+        // ---- phase 2: horizontal window + solve ----
+        if (tid < RB * NSEG) {
+          const int r = tid / NSEG, sg = tid - r * NSEG;
+          const int j0 = B2_HALO + sg * RB;
+          double t[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const float* vp = &V[r][c][j0 - M];
+            double acc = vp[0];
+#pragma unroll
+            for (int i = 1; i < W; ++i) acc += (double)vp[i];
+            t[c] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            if (i > 0) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c) t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
+            }
+            const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
+            const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        PSTAMP();
+        __syncthreads();  // (C)
         // ---- phase 3: coalesced flow store ----
         if (writer) {
 #pragma unroll
@@ -1469,12 +1765,46 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   a.rows_per_seg = rows;
   dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
+#ifdef ST_PROF
+  static long long* prof_buf = nullptr;
+  if (!prof_buf) { (void)hipMalloc((void**)&prof_buf, 8192 * sizeof(long long)); }
+  (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
+  a.prof = (a.h >= 1000) ? prof_buf : nullptr;
+#endif
   static const int rb = getenv("ST_ITER_RB") ? atoi(getenv("ST_ITER_RB")) : 3;
+  static const int tile = getenv("ST_ITER_TILE") ? atoi(getenv("ST_ITER_TILE")) : 0;
+  if (tile && a.w % 4 == 0 && a.h >= 2) {
+    hipLaunchKernelGGL((k_flow_iter_t<7, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  } else
+  {
   static const int vdouble = getenv("ST_ITER_VDOUBLE") ? atoi(getenv("ST_ITER_VDOUBLE")) : 0;
-  if (rb == 5) hipLaunchKernelGGL((k_flow_iter<7, 5, float>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (vdouble) hipLaunchKernelGGL((k_flow_iter<7, 3, double>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter<7, 3, float>), grid, dim3(B2_T), 0, ctx->stream, a);
+  (void)vdouble; (void)rb;
+  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
+  }
+#ifdef ST_PROF
+  if (a.prof && getenv("ST_PROF_DUMP")) {
+    static int dumped = 0;
+    if (dumped++ == 8) {  // one warm level-0 launch
+      std::vector<long long> hbuf(8192);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(hbuf.data(), prof_buf, 8192 * sizeof(long long), hipMemcpyDeviceToHost);
+      for (int wgi = 0; wgi < 2; ++wgi) {
+        long long* q = hbuf.data() + wgi * 4096;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        int nb = 0;
+        for (int i = 0; i + 6 < 4000 && q[i + 6]; i += 6, ++nb)
+          for (int j = 0; j < 6; ++j) acc[j] += (double)(q[i + j + 1] - q[i + j]);
+        fprintf(stderr, "[prof wg%d] batches %d  cycles/batch (6 intervals between stamps; k_flow_iter: P1finish issue bar1 P2 bar2 P3+loop | k_flow_iter_t: barA P1 A2+reduce+B issue P2 C+P3+loop): %.0f %.0f %.0f %.0f %.0f %.0f  total %.0f\n",
+                wgi, nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb,
+                (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / nb);
+      }
+    }
+  }
+#endif
   return ST_OK;
 }
 
