@@ -33,6 +33,9 @@ namespace {
 #ifndef ST_ABLATE
 #define ST_ABLATE 0
 #endif
+#ifndef ST_P2_FLOAT_TRIPLES
+#define ST_P2_FLOAT_TRIPLES 0
+#endif
 
 constexpr int kMaxTaps = 32;   // Gaussian pyramid kernel taps (reference needs <= 19)
 constexpr int kMaxPolyN = 7;
@@ -635,6 +638,15 @@ struct UmLoads {
   bool inb;
 };
 
+// Loads address the planes as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
+// compiler can use the SGPR-base addressing form (one VGPR per address, no 64-bit VALU math).
+__device__ __forceinline__ float ldf(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ f2u ldf2(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const float* __restrict__ R1, int np, int h,
                                          int w, int x, int y, float2 f, UmLoads& L) {
   float fx = x + f.x, fy = y + f.y;
@@ -647,17 +659,14 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   const int o = y * w + x;
   if (ST_ABLATE & 1) gi = L.inb ? (o < np - w - 1 ? o : 0) : 0;
   if (ST_ABLATE & 32) { const int yz = (y1 + (y % 3) * 2) % (h - 1); gi = L.inb ? yz * w + x1 : 0; }
+  const unsigned plane = 4u * (unsigned)np;
+  unsigned bo = 4u * (unsigned)o, bt = 4u * (unsigned)gi, bb = 4u * (unsigned)(gi + wo);
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
-    L.q[c] = R0[c * np + o];
-    if (ST_ABLATE & 4) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = L.q[c]; continue; }
-#ifdef ST_GATHER_DWORD
-    L.t[c].x = R1[c * np + gi]; L.t[c].y = R1[c * np + gi + 1];
-    L.b[c].x = R1[c * np + gi + wo]; L.b[c].y = R1[c * np + gi + wo + 1];
-#else
-    L.t[c] = *reinterpret_cast<const f2u*>(R1 + c * np + gi);
-    L.b[c] = *reinterpret_cast<const f2u*>(R1 + c * np + gi + wo);
-#endif
+    L.q[c] = ldf(R0, bo);
+    if (ST_ABLATE & 4) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = L.q[c]; }
+    else { L.t[c] = ldf2(R1, bt); L.b[c] = ldf2(R1, bb); }
+    bo += plane; bt += plane; bb += plane;
   }
 }
 
@@ -712,8 +721,8 @@ struct UMArgs {
   float mul;                 // 1/pyr_scale
 };
 
-__device__ __forceinline__ float2 ld_flow(const float* f, int idx) {
-  return *reinterpret_cast<const float2*>(f + 2 * (size_t)idx);
+__device__ __forceinline__ float2 ld_flow(const float* __restrict__ f, int idx) {
+  return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(f) + 8u * (unsigned)idx);
 }
 
 __global__ __launch_bounds__(256) void k_update_matrices(UMArgs a) {
@@ -1289,9 +1298,16 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             const VT* vp = &V[r][c][j0 - M];
+#if ST_P2_FLOAT_TRIPLES
+            // window of 15 as five float triples summed in double (5 cvt + 4 DP adds instead of 15 + 14)
+            double acc = (double)((vp[0] + vp[1]) + vp[2]);
+#pragma unroll
+            for (int i = 3; i < W; i += 3) acc += (double)((vp[i] + vp[i + 1]) + vp[i + 2]);
+#else
             double acc = vp[0];
 #pragma unroll
             for (int i = 1; i < W; ++i) acc += (double)vp[i];
+#endif
             t[c] = acc;
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -1299,7 +1315,14 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           for (int i = 0; i < RB; ++i) {
             if (i > 0) {
 #pragma unroll
-              for (int c = 0; c < 5; ++c) t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
+              for (int c = 0; c < 5; ++c) {
+#if ST_P2_FLOAT_TRIPLES
+                const float dv = V[r][c][j0 + i + M] - V[r][c][j0 + i - M - 1];
+                t[c] += dv;
+#else
+                t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
+#endif
+              }
             }
             const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
             const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
@@ -1346,7 +1369,7 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int M, int RB>
+template <int M, int RB, int MODE>
 __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
   constexpr int W = 2 * M + 1;
   constexpr int NSEG = B2_OUT / RB;
@@ -1395,7 +1418,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
-      f[i] = iter_flow_at(a, fin, C, xc, yy);
+      f[i] = iter_flow_at<MODE>(a, fin, C, xc, yy);
       um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
     }
 #pragma unroll
@@ -1465,7 +1488,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 
   float2 fl[RB], fn[RB];
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
   if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
   __syncthreads();
   reduce_origin(fl, y0);
@@ -1473,18 +1496,17 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
   int txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3), tyA = red[1];
   issue_tiles(y0, txA, tyA);
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
 
 #ifdef ST_PROF
   int pslot = 0;
   const bool pon = a.prof && tid == 64 && blockIdx.x == 3 && blockIdx.y == 1 && (blockIdx.z == 0 || blockIdx.z == 20);
   long long* pbuf = a.prof + (blockIdx.z == 0 ? 0 : 4096);
 #endif
-  for (int yb = y0; yb < y1; yb += W) {
-#pragma unroll
-    for (int b = 0; b < W / RB; ++b) {
-      const int ybb = yb + b * RB;
-      if (ybb < y1) {  // workgroup-uniform
+#pragma unroll 1
+  for (int ybb = y0; ybb < y1; ybb += RB) {
+    {
+      {
         PSTAMP();
         __syncthreads();  // (A) tiles of this batch have landed (vmcnt drained by the barrier); red consumed
         PSTAMP();
@@ -1526,10 +1548,25 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             V[r][c][tid] = (float)vs[c];
-            const float d = m[c] - ring[b * RB + r][c];
+            const float d = m[c] - ring[r][c];
             vs[c] += d;
-            ring[b * RB + r][c] = m[c];
+            ring[r][c] = m[c];
           }
+        }
+        {
+          float tmp[RB][5];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) tmp[r][c] = ring[r][c];
+#pragma unroll
+          for (int j = 0; j + RB < W; ++j)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) ring[j][c] = ring[j + RB][c];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
         }
         PSTAMP();
         __syncthreads();  // (A2) red reset visible before the new minima arrive
@@ -1542,7 +1579,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) fl[r] = fn[r];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
         PSTAMP();
         // ---- phase 2: horizontal window + solve ----
         if (tid < RB * NSEG) {
@@ -1757,7 +1794,8 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
   // aim for two full rounds of resident workgroups (2 per CU at 256 VGPRs); whole ring periods
-  long long target = (long long)ctx->num_cus * 4;
+  static const int seg_mult = getenv("ST_ITER_SEGMULT") ? atoi(getenv("ST_ITER_SEGMULT")) : 2;
+  long long target = (long long)ctx->num_cus * seg_mult;
   long long segs = (target + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
   int rows = (int)((a.h + segs - 1) / segs);
   rows = (rows + 14) / 15 * 15;
@@ -1774,15 +1812,18 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   static const int rb = getenv("ST_ITER_RB") ? atoi(getenv("ST_ITER_RB")) : 3;
   static const int tile = getenv("ST_ITER_TILE") ? atoi(getenv("ST_ITER_TILE")) : 0;
   if (tile && a.w % 4 == 0 && a.h >= 2) {
-    hipLaunchKernelGGL((k_flow_iter_t<7, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
+    if (a.coarse) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   } else
   {
   static const int vdouble = getenv("ST_ITER_VDOUBLE") ? atoi(getenv("ST_ITER_VDOUBLE")) : 0;
   (void)vdouble; (void)rb;
-  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
+  static const int extra_lds = getenv("ST_ITER_EXTRA_LDS") ? atoi(getenv("ST_ITER_EXTRA_LDS")) : 0;  // occupancy experiments
+  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
+  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   }
 #ifdef ST_PROF
