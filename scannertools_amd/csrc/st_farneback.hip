@@ -552,8 +552,10 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
             const float p2 = s[2][tid + k], m2 = s[2][tid - k];
             double tg = p0 + m0;
             g0 = a.c.g[k];
-            b1 += tg * g0;
-            b4 += tg * a.c.xxg[k];
+            // tg and the taps are float-valued, so tg*tap is exact in double and the fused form
+            // rounds exactly like the reference's separate multiply and add (one DP op instead of two)
+            b1 = __builtin_fma(tg, (double)g0, b1);
+            b4 = __builtin_fma(tg, (double)a.c.xxg[k], b4);
             b2 += (p0 - m0) * a.c.xg[k];
             b3 += (p1 + m1) * g0;
             b6 += (p1 - m1) * a.c.xg[k];

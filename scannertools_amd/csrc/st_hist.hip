@@ -4,10 +4,15 @@
 // (/root/reference/scannertools/scannertools_cpp/imgproc/histogram_kernel_cpu.cpp:25-45):
 // three cv::calcHist passes per frame become ONE pass over the frame's bytes.
 //
-// HBM-bound integer work: each frame byte is read exactly once with 16-B-per-lane coalesced
-// loads; counts go to wave-private 3x256 LDS sub-histograms (ds_add_u32, no return value),
-// are summed across the workgroup's waves, folded to `bins` and committed with one global
-// atomic per non-empty bin per workgroup.  Algorithmic bytes per frame = 3*w*h + 3*bins*4.
+// Each frame byte is read exactly once with 16-B-per-lane coalesced loads; counts go to LDS
+// sub-histograms with ds_add_u32 (no return value), are folded to `bins` and committed with one
+// global atomic per non-empty bin per workgroup.  Algorithmic bytes per frame = 3*w*h + 3*bins*4.
+// Two kernels: k_hist_u8c3_v2<8> (default: 8 lane-indexed copies per workgroup, data-independent
+// throughput) and k_hist_u8c3 (one copy per wave; kept for A/B runs, ST_HIST_VARIANT=0).
+// Measured ceiling on this chip: one LDS atomic per byte runs at ~8 lanes/clk/CU, i.e. ~4 TB/s
+// of frame bytes chip-wide, whatever the conflict pattern (scripts/bench_hist.py).
+#include <cstdlib>
+
 #include "st_internal.h"
 
 namespace {
@@ -116,6 +121,106 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3(FrameSrc src, long long 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2: C lane-indexed copies of the 3x256 counters shared by the whole workgroup.  A lane always
+// updates copy (lane & (C-1)), so within a 32-lane LDS pass at most 32/C lanes can meet on one
+// address and the bank pattern is (bin * C + lane) % 32: random data costs ~1.5x (C = 16) instead
+// of the ~3.5x of one histogram per wave, and the all-equal frame costs 32/C-way instead of 32-way.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void count16c(unsigned* h, uint4 q, unsigned c0, unsigned c1, unsigned c2) {
+  // c0/c1/c2 already include the lane's copy index; counters of a bin are C dwords apart
+  lds_inc(h + c0 + (q.x & 0xff) * C);
+  lds_inc(h + c1 + ((q.x >> 8) & 0xff) * C);
+  lds_inc(h + c2 + ((q.x >> 16) & 0xff) * C);
+  lds_inc(h + c0 + (q.x >> 24) * C);
+  lds_inc(h + c1 + (q.y & 0xff) * C);
+  lds_inc(h + c2 + ((q.y >> 8) & 0xff) * C);
+  lds_inc(h + c0 + ((q.y >> 16) & 0xff) * C);
+  lds_inc(h + c1 + (q.y >> 24) * C);
+  lds_inc(h + c2 + (q.z & 0xff) * C);
+  lds_inc(h + c0 + ((q.z >> 8) & 0xff) * C);
+  lds_inc(h + c1 + ((q.z >> 16) & 0xff) * C);
+  lds_inc(h + c2 + (q.z >> 24) * C);
+  lds_inc(h + c0 + (q.w & 0xff) * C);
+  lds_inc(h + c1 + ((q.w >> 8) & 0xff) * C);
+  lds_inc(h + c2 + ((q.w >> 16) & 0xff) * C);
+  lds_inc(h + c0 + (q.w >> 24) * C);
+}
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
+                                                           int32_t* __restrict__ out) {
+  __shared__ unsigned sh[768 * C];
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const uint8_t* p = src.ptrs ? src.ptrs[frame] : src.base + (size_t)frame * src.stride;
+  for (int i = tid; i < 768 * C; i += kThreads) sh[i] = 0;
+  __syncthreads();
+  const unsigned copy = tid & (C - 1);
+
+  long long head = (long long)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > nbytes) head = nbytes;
+  const long long nvec = (nbytes - head) >> 4;
+  const long long tail = head + (nvec << 4);
+  const uint4* vp = reinterpret_cast<const uint4*>(p + head);
+  const long long per = (nvec + chunks - 1) / chunks;
+  const long long v0 = (long long)chunk * per;
+  long long v1 = v0 + per;
+  if (v1 > nvec) v1 = nvec;
+
+  long long i = v0 + tid;
+  const unsigned ph = (unsigned)((head + i) % 3);
+  const unsigned o0 = ph * 256 * C + copy, o1 = ((ph + 1) % 3) * 256 * C + copy, o2 = ((ph + 2) % 3) * 256 * C + copy;
+  // six vectors in flight per thread (two phase cycles)
+  for (; i + 5 * kThreads < v1; i += 6 * kThreads) {
+    uint4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads];
+    uint4 d = vp[i + 3 * kThreads], e = vp[i + 4 * kThreads], f = vp[i + 5 * kThreads];
+    count16c<C>(sh, a, o0, o1, o2);
+    count16c<C>(sh, b, o1, o2, o0);
+    count16c<C>(sh, c, o2, o0, o1);
+    count16c<C>(sh, d, o0, o1, o2);
+    count16c<C>(sh, e, o1, o2, o0);
+    count16c<C>(sh, f, o2, o0, o1);
+  }
+  for (; i + 2 * kThreads < v1; i += 3 * kThreads) {
+    uint4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads];
+    count16c<C>(sh, a, o0, o1, o2);
+    count16c<C>(sh, b, o1, o2, o0);
+    count16c<C>(sh, c, o2, o0, o1);
+  }
+  if (i < v1) {
+    uint4 a = vp[i];
+    count16c<C>(sh, a, o0, o1, o2);
+    if (i + kThreads < v1) {
+      uint4 b = vp[i + kThreads];
+      count16c<C>(sh, b, o1, o2, o0);
+    }
+  }
+  if (chunk == 0) {
+    for (long long b = tid; b < head; b += kThreads) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
+    for (long long b = tail + tid; b < nbytes; b += kThreads) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
+  }
+  __syncthreads();
+  // fold the C copies of every counter into copy 0
+  for (int b = tid; b < 768; b += kThreads) {
+    unsigned s = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += sh[b * C + ((c + tid) & (C - 1))];
+    sh[b * C] = s;  // only this thread touches bin b's copies
+  }
+  __syncthreads();
+  int32_t* o = out + (size_t)frame * 3 * bins;
+  for (int ob = tid; ob < 3 * bins; ob += kThreads) {
+    const int ch = ob / bins, bin = ob - ch * bins;
+    const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
+    unsigned s = 0;
+    for (int v = lo; v < hi; ++v) s += sh[(ch * 256 + v) * C];
+    if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, s);
+  }
+}
+
 int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
   const long long nbytes = 3LL * h * w;
   const long long nvec = nbytes / 16;
@@ -130,7 +235,18 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     int nf = n - f0 < 65535 ? n - f0 : 65535;
     FrameSrc s = src;
     if (s.ptrs) s.ptrs += f0; else s.base += (size_t)f0 * s.stride;
+    static const int variant = getenv("ST_HIST_VARIANT") ? atoi(getenv("ST_HIST_VARIANT")) : 8;
     st_timed t(ctx, ST_K_HIST);
+    if (variant == 8)
+      hipLaunchKernelGGL(k_hist_u8c3_v2<8>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+    else if (variant == 16)
+      hipLaunchKernelGGL(k_hist_u8c3_v2<16>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+    else if (variant == 4)
+      hipLaunchKernelGGL(k_hist_u8c3_v2<4>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+    else
     hipLaunchKernelGGL(k_hist_u8c3, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
                        nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
     ST_HIP(ctx, hipGetLastError());
