@@ -186,6 +186,18 @@ def main():
     hist_bytes = (3 * h * w + 3 * args.bins * 4) * B
     hist_gbs = hist_bytes * hist_steps / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
 
+    # HBM bytes per k_flow_iter launch from the PMC counters of the committed profile of this same
+    # command (scripts/profile_round.sh -> scripts/pmc_traffic.py -> profiles/traffic.json):
+    # 128-B read requests + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes.  None when the
+    # profile is missing or was taken at another batch size / resolution.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and (B, h, w) == (32, 1080, 1920):
+        try:
+            traffic = float(json.load(open(tpath))["k_flow_iter"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+
     result = None
     if rank == 0:
         result = {
@@ -215,7 +227,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": blur_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/traffic.json)",
+                "algorithmic_bytes_per_launch": blur_bytes_per_step * args.steps / max(blur_launches, 1),
                 "launches": blur_launches,
                 "avg_launch_ms": blur_ms / max(blur_launches, 1),
                 "algorithmic_bytes_per_step": blur_bytes_per_step,

@@ -1116,31 +1116,44 @@ struct IterArgs {
 
 enum { FLOW_ZERO = 0, FLOW_FIELD = 1, FLOW_COARSE = 2, FLOW_ANY = 3 };
 
+// x-dependent half of the INTER_LINEAR up-sample (fixed per thread: a thread owns one column)
+struct CoarseX {
+  int sx;
+  float a0, a1;
+  bool pair;  // sx+1 is inside the coarse row
+};
+
+__device__ __forceinline__ CoarseX coarse_x(const IterArgs& a, int x) {
+  CoarseX cx;
+  float fx = (float)((x + 0.5) * a.scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= a.cw - 1) { fx = 0.f; sx = a.cw - 1; }
+  cx.sx = sx; cx.a1 = fx; cx.a0 = 1.f - fx; cx.pair = sx + 1 < a.cw;
+  return cx;
+}
+
 template <int MODE = FLOW_ANY>
 __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
-                                               const float* __restrict__ C, int x, int y) {
+                                               const float* __restrict__ C, const CoarseX& cx, int x, int y) {
   if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
     // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
-    float fx = (float)((x + 0.5) * a.scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= sx;
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= a.cw - 1) { fx = 0.f; sx = a.cw - 1; }
     float fy = (float)((y + 0.5) * a.scale_y - 0.5);
     int sy = (int)floorf(fy);
     fy -= sy;
     const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
-    const float a1 = fx, a0 = 1.f - fx, b0 = 1.f - fy, b1 = fy;
+    const float a1 = cx.a1, a0 = cx.a0, b0 = 1.f - fy, b1 = fy;
     float2 ta, tb;
-    if (sx + 1 < a.cw) {
-      float2 p = ld_flow(C, ya * a.cw + sx), q = ld_flow(C, ya * a.cw + sx + 1);
+    if (cx.pair) {
+      float2 p = ld_flow(C, ya * a.cw + cx.sx), q = ld_flow(C, ya * a.cw + cx.sx + 1);
       ta.x = p.x * a0 + q.x * a1; ta.y = p.y * a0 + q.y * a1;
-      p = ld_flow(C, yb * a.cw + sx); q = ld_flow(C, yb * a.cw + sx + 1);
+      p = ld_flow(C, yb * a.cw + cx.sx); q = ld_flow(C, yb * a.cw + cx.sx + 1);
       tb.x = p.x * a0 + q.x * a1; tb.y = p.y * a0 + q.y * a1;
     } else {
-      float2 p = ld_flow(C, ya * a.cw + sx);
+      float2 p = ld_flow(C, ya * a.cw + cx.sx);
       ta.x = p.x * 1.f; ta.y = p.y * 1.f;
-      p = ld_flow(C, yb * a.cw + sx);
+      p = ld_flow(C, yb * a.cw + cx.sx);
       tb.x = p.x * 1.f; tb.y = p.y * 1.f;
     }
     return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
@@ -1178,6 +1191,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
+  const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
   // ring slot s holds M of source row y0 - M + s (clamped) at entry; vs = window sum of row y0
   float ring[W][5];
@@ -1188,7 +1202,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
-      f[i] = iter_flow_at<MODE>(a, fin, C, xc, yy);
+      f[i] = iter_flow_at<MODE>(a, fin, C, cx, xc, yy);
       um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
     }
 #pragma unroll
@@ -1225,11 +1239,11 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   UmLoads L[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
-    fl[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+    fl[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
     um_issue(R0, R1, np, h, w, xc, d_clamp(y0 + r + M + 1, 0, h - 1), fl[r], L[r]);
   }
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
 
 #ifdef ST_PROF
   int pslot = 0;
@@ -1283,7 +1297,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
         PSTAMP();
         __syncthreads();
         PSTAMP();
@@ -1410,6 +1424,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
   const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
+  const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
   // ---- ring / column-sum initialisation (per-lane loads; once per segment) ----
   float ring[W][5];
@@ -1420,7 +1435,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
-      f[i] = iter_flow_at<MODE>(a, fin, C, xc, yy);
+      f[i] = iter_flow_at<MODE>(a, fin, C, cx, xc, yy);
       um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
     }
 #pragma unroll
@@ -1490,7 +1505,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 
   float2 fl[RB], fn[RB];
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
   if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
   __syncthreads();
   reduce_origin(fl, y0);
@@ -1498,7 +1513,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
   int txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3), tyA = red[1];
   issue_tiles(y0, txA, tyA);
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
 
 #ifdef ST_PROF
   int pslot = 0;
@@ -1581,7 +1596,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) fl[r] = fn[r];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
         PSTAMP();
         // ---- phase 2: horizontal window + solve ----
         if (tid < RB * NSEG) {
