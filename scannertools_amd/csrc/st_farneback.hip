@@ -1290,6 +1290,13 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
             for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
         }
         PSTAMP();
+        // ---- phase 3 of the PREVIOUS batch: its flow rows are stored here, ahead of the next
+        // batch's loads, so that the stores do not queue behind 48 loads in the memory pipeline ----
+        if (writer && ybb > y0) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            *reinterpret_cast<float2*>(fout + 2 * (size_t)((ybb - RB + r) * w + x)) = F[r][tid];
+        }
         // issue the next batch's loads, prefetch the flows of the batch after it
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -1352,15 +1359,16 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
         PSTAMP();
         __syncthreads();
         PSTAMP();
-        // ---- phase 3: coalesced flow store ----
-        if (writer) {
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            const int y = ybb + r;
-            if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
-          }
-        }
       }
+    }
+  }
+  // flow of the last batch
+  if (writer) {
+    const int ylast = y0 + ((y1 - y0 - 1) / RB) * RB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int y = ylast + r;
+      if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
     }
   }
 }
