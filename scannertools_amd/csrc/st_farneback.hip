@@ -1261,7 +1261,15 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
     {
       {
         PSTAMP();
-        // ---- phase 1: finish the rows entering the window, slide the column sums ----
+        // ---- phase 3 of the PREVIOUS batch first: its flow rows go out ahead of this batch's
+        // loads, so that the stores do not queue behind them in the memory pipeline ----
+        if (writer && ybb > y0) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            *reinterpret_cast<float2*>(fout + 2 * (size_t)((ybb - RB + r) * w + x)) = F[r][tid];
+        }
+        // ---- phase 1: per entering row, finish its UpdateMatrices (loads issued one batch ago),
+        // slide the column sums, and immediately re-issue that row's register set for the next batch ----
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           float m[5];
@@ -1273,6 +1281,8 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
             vs[c] += d;
             ring[r][c] = m[c];  // parked in the slot it frees; rotated into place below
           }
+          fl[r] = fn[r];
+          um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
         }
         {
           float tmp[RB][5];
@@ -1288,20 +1298,6 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
-        }
-        PSTAMP();
-        // ---- phase 3 of the PREVIOUS batch: its flow rows are stored here, ahead of the next
-        // batch's loads, so that the stores do not queue behind 48 loads in the memory pipeline ----
-        if (writer && ybb > y0) {
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-            *reinterpret_cast<float2*>(fout + 2 * (size_t)((ybb - RB + r) * w + x)) = F[r][tid];
-        }
-        // issue the next batch's loads, prefetch the flows of the batch after it
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          fl[r] = fn[r];
-          um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
