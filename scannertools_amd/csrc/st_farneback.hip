@@ -538,6 +538,14 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
 #pragma unroll
     for (int r = 0; r < PE_RB; ++r) nxt[r] = I[d_clamp(y + PE_RB + N + r, 0, h - 1) * w + xc];
     __syncthreads();
+    // Consume the prefetched rows BEFORE this batch's stores are issued: vmcnt retires in order
+    // and counts stores, so waiting for these loads after the stores would also wait for the
+    // stores' acknowledgements (the stall that bounded the first version of this kernel).
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + PE_RB];
+#pragma unroll
+    for (int r = 0; r < PE_RB; ++r) ring[2 * N + r] = nxt[r];
+    __builtin_amdgcn_sched_barrier(0);
     if (writer) {
 #pragma unroll
       for (int r = 0; r < PE_RB; ++r) {
@@ -570,10 +578,6 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + PE_RB];
-#pragma unroll
-    for (int r = 0; r < PE_RB; ++r) ring[2 * N + r] = nxt[r];
     buf ^= 1;
   }
 }
@@ -1146,10 +1150,12 @@ __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* _
     const float a1 = cx.a1, a0 = cx.a0, b0 = 1.f - fy, b1 = fy;
     float2 ta, tb;
     if (cx.pair) {
-      float2 p = ld_flow(C, ya * a.cw + cx.sx), q = ld_flow(C, ya * a.cw + cx.sx + 1);
-      ta.x = p.x * a0 + q.x * a1; ta.y = p.y * a0 + q.y * a1;
-      p = ld_flow(C, yb * a.cw + cx.sx); q = ld_flow(C, yb * a.cw + cx.sx + 1);
-      tb.x = p.x * a0 + q.x * a1; tb.y = p.y * a0 + q.y * a1;
+      // the two horizontally adjacent coarse vectors in ONE 16-byte load (8-byte aligned)
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+      const f4u pa = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(ya * a.cw + cx.sx));
+      const f4u pb = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(yb * a.cw + cx.sx));
+      ta.x = pa.x * a0 + pa.z * a1; ta.y = pa.y * a0 + pa.w * a1;
+      tb.x = pb.x * a0 + pb.z * a1; tb.y = pb.y * a0 + pb.w * a1;
     } else {
       float2 p = ld_flow(C, ya * a.cw + cx.sx);
       ta.x = p.x * 1.f; ta.y = p.y * 1.f;
