@@ -283,3 +283,26 @@ def test_flow_rejects_unsupported(hip_ctx):
     with pytest.raises(StError):
         hip_ctx.optical_flow(f, pairs=[(0, 2)])
     assert tuple(hip_ctx.optical_flow(f, pairs=np.zeros((0, 2), np.int32)).shape) == (0, 64, 64, 2)
+
+
+# ---------------------------------------------------------------- BASELINE config 4 size (4K)
+def test_flow_4k_properties(hip_ctx):
+    """3840x2160 (config 4): level geometry, planted translation, batch == single, zero on identical."""
+    from scannertools_amd.hip import fb_level_geom, fb_levels
+    h, w = 2160, 3840
+    assert fb_levels(h, w) == 3 and fb_level_geom(h, w, 3)[:2] == (270, 480)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    low = torch.rand((1, 3, h // 8 + 12, w // 8 + 12), device="cuda", generator=g)
+    tex = torch.nn.functional.interpolate(low, size=(h + 64, w + 64), mode="bicubic", align_corners=False)[0]
+    tex = ((tex - tex.amin()) / (tex.amax() - tex.amin()) * 255).permute(1, 2, 0)
+    f0 = tex[32:32 + h, 32:32 + w].to(torch.uint8).contiguous()
+    f1 = tex[32 - 2:32 - 2 + h, 32 - 5:32 - 5 + w].to(torch.uint8).contiguous()      # next(x+5, y+2) = prev(x, y)
+    fr = torch.stack([f0, f1, f0])
+    fl = hip_ctx.optical_flow(fr, pairs=[(0, 1), (1, 2), (0, 2)])
+    inner = fl[0, 200:-200, 200:-200]
+    assert abs(float(inner[..., 0].median()) - 5) < 0.05 and abs(float(inner[..., 1].median()) - 2) < 0.05
+    inner = fl[1, 200:-200, 200:-200]
+    assert abs(float(inner[..., 0].median()) + 5) < 0.05 and abs(float(inner[..., 1].median()) + 2) < 0.05
+    assert float(fl[2, :1500, :3000].abs().max()) < 0.05                              # identical frames
+    single = hip_ctx.optical_flow(fr[:2])
+    assert rel_l2(fl[0].cpu().numpy(), single[0].cpu().numpy()) < 1e-6

@@ -97,3 +97,23 @@ def test_hist_rejects_bad_arguments(hip_ctx):
         hip_ctx.histogram(f, 257)
     with pytest.raises(TypeError):
         hip_ctx.histogram(torch.zeros((1, 4, 4, 3), dtype=torch.uint8), 16)  # CPU tensor: no fallback
+
+
+def test_shot_pipeline_on_device_stream(hip_ctx):
+    """Config 3 in miniature: 1080p stream generated on the device with planted cuts ->
+    Histogram (HIP) -> ShotBoundaries (host); compared with the planted cuts."""
+    from scannertools_amd.shot_detection import shot_boundaries
+    n, h, w = 240, 1080, 1920
+    cuts = [60, 130, 131 + 40]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    base = None
+    for i in range(n):
+        if i == 0 or i in cuts:
+            gain = 0.3 + 0.7 * torch.rand(3, device="cuda", generator=g)
+            base = (torch.rand((h, w, 3), device="cuda", generator=g) * 255.0 * gain).to(torch.int16)
+        frames[i] = (base + torch.randint(-3, 4, (h, w, 3), dtype=torch.int16, device="cuda", generator=g)).clamp_(0, 255).to(torch.uint8)
+    hist = hip_ctx.histogram(frames, 16)
+    assert (hist.sum(dim=2) == h * w).all()
+    res = shot_boundaries(None, list(hist.cpu().numpy()))
+    assert res[0] == cuts and all(r is None for r in res[1:])
