@@ -1663,6 +1663,7 @@ int check_params(st_ctx* ctx, const st_fb_params& p, int h, int w) {
     return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: win_size=%d (odd, <= 63)", p.win_size);
   if (p.num_iters < 1 || p.num_levels < 0) return st_set_error(ctx, ST_ERR_INVALID, "farneback: bad iteration/level count");
   if (p.gray_bits != 14 && p.gray_bits != 15) return st_set_error(ctx, ST_ERR_INVALID, "farneback: gray_bits must be 14 or 15");
+  if ((long long)h * w > 200000000LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "farneback: frames above 200 Mpx are not supported (32-bit plane offsets)");
   int levels = fb_levels(h, w, p);
   for (int k = 0; k <= levels; ++k) {
     LevelGeom g = fb_level_geom(h, w, p, k);
@@ -1937,7 +1938,9 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
   }
   // per-pair stages, coarse to fine
-  if (p.win_size == 15 && !getenv("ST_UNFUSED")) {
+  bool tiny = false;  // 1-pixel-wide/high levels take the generic kernels (the fused one reads 2x2 footprints)
+  for (int k = 0; k <= levels; ++k) tiny = tiny || geom[k].lh < 2 || geom[k].lw < 2;
+  if (p.win_size == 15 && !tiny && !getenv("ST_UNFUSED")) {
     // fused iterations (k_flow_iter): M is never materialised; the M scratch doubles as the
     // two ping-pong flow fields of a level
     float* fbuf[2] = {M[0], M[1]};
@@ -2149,6 +2152,7 @@ ST_EXPORT int st_fb_flow_iteration(st_ctx* ctx, const float* r0_dev, const float
   if (!r0_dev || !r1_dev || !flow_out_dev || h <= 0 || w <= 0)
     return st_set_error(ctx, ST_ERR_INVALID, "flow_iteration: bad arguments");
   if (block_size != 15) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "flow_iteration: block_size=%d (15 only)", block_size);
+  if (h < 2 || w < 2) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "flow_iteration: needs at least 2x2 pixels");
   if (flow_out_dev == flow_in_dev) return st_set_error(ctx, ST_ERR_INVALID, "flow_iteration: in-place not allowed");
   IterArgs q;
   memset(&q, 0, sizeof(q));

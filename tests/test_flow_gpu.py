@@ -274,6 +274,16 @@ def test_flow_1080p_pair(hip_ctx):
     assert abs(np.median(inner[..., 0]) - 4) < 0.05 and abs(np.median(inner[..., 1]) - 3) < 0.05
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 40), (40, 1), (2, 2), (3, 5), (31, 33)])
+def test_flow_tiny_frames(hip_ctx, h, w):
+    """Degenerate geometries (single level, clamps everywhere) still match the oracle."""
+    f = random_frames(h * 7 + w, 2, h, w)
+    got = hip_ctx.optical_flow(cu(f)).cpu().numpy()[0]
+    ref = oracle.optical_flow_rgb(f[0], f[1])
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+
+
 def test_flow_rejects_unsupported(hip_ctx):
     from scannertools_amd.hip import StError
     f = torch.zeros((2, 64, 64, 3), dtype=torch.uint8, device="cuda")

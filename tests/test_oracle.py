@@ -120,3 +120,14 @@ def test_flow_oracle_direction_and_rgb_entry():
     inner = slice(30, -30)
     assert np.median(a[inner, inner, 0]) > 1.5 and np.median(b[inner, inner, 0]) < -1.5
     np.testing.assert_array_equal(a, oracle.farneback(oracle.gray_u8(f0), oracle.gray_u8(f1)))
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The C restatement runs clean under ASan/UBSan on small and ragged shapes (1x1 ... 130x70)."""
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", d, "asan_driver"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(d, "asan_driver")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "oracle sanitizer run ok" in out.stdout
