@@ -1736,7 +1736,8 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
       const int bx = (g.lw + 255) / 256;
       long long segs = ((long long)ctx->num_cus * 8 + (long long)bx * n - 1) / ((long long)bx * n);
       int rows = (int)((g.lh + segs - 1) / segs);
-      const int min_rows = S == 8 ? 4 : 8;
+      static const int min8 = getenv("ST_PYR8_ROWS") ? atoi(getenv("ST_PYR8_ROWS")) : 4;
+      const int min_rows = S == 8 ? min8 : 8;
       if (rows < min_rows) rows = g.lh < min_rows ? g.lh : min_rows;
       z.rows_per_seg = rows;
       dim3 grid(bx, (g.lh + rows - 1) / rows, n);
