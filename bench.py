@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): the Farneback
 OpticalFlow op over a device-resident 1080p frame stream (stencil {0,1}: one flow field per
 consecutive frame pair) together with the per-channel Histogram op on the same frames.  One
-"step" = one batch of B frames per GPU: Histogram on B frames (256 bins) + OpticalFlow on the B
-pairs formed with one halo frame (B+1 frames resident).  value = frames/s through both ops,
+"step" = one batch of B = 256 frames per GPU (257 resident frames, 256
+pairs): Histogram on B frames (256 bins) + OpticalFlow on the B pairs formed with one halo frame.  value = frames/s through both ops,
 whole job (all ranks), inputs already in HBM when the timed region starts.
 
 Multi-GPU: frames are independent (pairs need one halo frame), so every rank processes its own
@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="frames (= flow pairs) per step per GPU")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="frames (= flow pairs) per step per GPU; 256 pairs over 257 resident frames = SURVEY.md 8d config 2")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--bins", type=int, default=256)
@@ -192,7 +193,7 @@ def main():
     # profile is missing or was taken at another batch size / resolution.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and (B, h, w) == (32, 1080, 1920):
+    if os.path.exists(tpath) and (B, h, w) == (256, 1080, 1920):
         try:
             traffic = float(json.load(open(tpath))["k_flow_iter"]["hbm_bytes_per_launch"])
         except Exception:

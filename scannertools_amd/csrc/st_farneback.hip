@@ -1878,6 +1878,18 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   return ST_OK;
 }
 
+// The fused iteration kernel applies to the reference's 15x15 window on frames whose pyramid
+// levels are at least 2x2; it needs two flow fields per pair instead of two matrix fields.
+bool fused_path(int h, int w, const st_fb_params& p) {
+  if (p.win_size != 15 || getenv("ST_UNFUSED")) return false;
+  const int levels = fb_levels(h, w, p);
+  for (int k = 0; k <= levels; ++k) {
+    LevelGeom g = fb_level_geom(h, w, p, k);
+    if (g.lh < 2 || g.lw < 2) return false;
+  }
+  return true;
+}
+
 // Scratch needed to process `nf` distinct frames and `npairs` pairs in one pass.
 size_t pass_bytes(int h, int w, const st_fb_params& p, int nf, int npairs) {
   const int levels = fb_levels(h, w, p);
@@ -1895,7 +1907,7 @@ size_t pass_bytes(int h, int w, const st_fb_params& p, int nf, int npairs) {
     LevelGeom g = fb_level_geom(h, w, p, k);
     b += st_align_up(sizeof(float) * 5 * (size_t)g.lh * g.lw * nf);  // R_k
   }
-  b += 2 * st_align_up(sizeof(float) * 5 * np0 * npairs);            // M ping/pong
+  b += 2 * st_align_up(sizeof(float) * (fused_path(h, w, p) ? 2 : 5) * np0 * npairs);  // flow or M ping/pong
   b += 2 * st_align_up(sizeof(float) * 2 * (maxCoarse ? maxCoarse : 1) * npairs);  // coarse flows
   b += st_align_up(sizeof(void*) * nf) + st_align_up(sizeof(int) * 2 * npairs) + st_align_up(sizeof(void*) * npairs);
   return b + 4096;
@@ -1918,8 +1930,9 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     R[k] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * npk * nf);
   }
   float* M[2];
-  M[0] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * np0 * npairs);
-  M[1] = (float*)st_ws_alloc(ctx, sizeof(float) * 5 * np0 * npairs);
+  const bool fused = fused_path(h, w, p);
+  M[0] = (float*)st_ws_alloc(ctx, sizeof(float) * (fused ? 2 : 5) * np0 * npairs);
+  M[1] = (float*)st_ws_alloc(ctx, sizeof(float) * (fused ? 2 : 5) * np0 * npairs);
   float* cflow[2];
   cflow[0] = (float*)st_ws_alloc(ctx, sizeof(float) * 2 * maxCoarse * npairs);
   cflow[1] = (float*)st_ws_alloc(ctx, sizeof(float) * 2 * maxCoarse * npairs);
@@ -1939,9 +1952,7 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
   }
   // per-pair stages, coarse to fine
-  bool tiny = false;  // 1-pixel-wide/high levels take the generic kernels (the fused one reads 2x2 footprints)
-  for (int k = 0; k <= levels; ++k) tiny = tiny || geom[k].lh < 2 || geom[k].lw < 2;
-  if (p.win_size == 15 && !tiny && !getenv("ST_UNFUSED")) {
+  if (fused) {
     // fused iterations (k_flow_iter): M is never materialised; the M scratch doubles as the
     // two ping-pong flow fields of a level
     float* fbuf[2] = {M[0], M[1]};

@@ -17,4 +17,10 @@ pass write WRITE_SIZE
 pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 pass wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
 pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS
+# summarise on the box (the raw rocprofv3 output exceeds what gpurun copies back) and drop the raw data
+mkdir -p $out/summary
+python3 scripts/rocpd_stats.py $out/trace/trace_results.db > $out/summary/kernel_stats.txt
+python3 scripts/pmc_traffic.py $out > $out/summary/pmc_traffic.json
+cp $out/bench.json $out/summary/bench.json
+rm -rf $out/trace $out/fetch $out/write $out/rdreq $out/wrreq $out/sq
 cat $out/bench.json
