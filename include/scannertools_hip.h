@@ -59,7 +59,7 @@ int st_ctx_destroy(st_ctx* ctx);
 int st_ctx_set_stream(st_ctx* ctx, void* hip_stream);
 int st_ctx_reset_stream(st_ctx* ctx);
 int st_ctx_sync(st_ctx* ctx);
-/* Cap on scratch the context may hold (bytes; 0 = default 24 GiB).  Large pair batches are
+/* Cap on scratch the context may hold (bytes; 0 = default 64 GiB).  Large pair batches are
  * processed in passes that fit. */
 int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes);
 int st_ctx_release_workspace(st_ctx* ctx);

@@ -95,7 +95,7 @@ ST_EXPORT int st_ctx_sync(st_ctx* ctx) {
 
 ST_EXPORT int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes) {
   if (!ctx) return ST_ERR_INVALID;
-  ctx->ws_limit = bytes ? bytes : ((size_t)24 << 30);
+  ctx->ws_limit = bytes ? bytes : ((size_t)64 << 30);
   return ST_OK;
 }
 

@@ -27,7 +27,7 @@ struct st_ctx {
   // bump-allocated scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  size_t ws_limit = (size_t)24 << 30;
+  size_t ws_limit = (size_t)64 << 30;
   size_t ws_off = 0;
   // small device table for pointer arrays
   unsigned timing_mask = 0;
