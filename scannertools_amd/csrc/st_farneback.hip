@@ -182,6 +182,23 @@ __global__ __launch_bounds__(256) void k_gray(GrayArgs a) {
   }
 }
 
+// Four pixels per thread: 12 source bytes as three aligned dwords, one dword store.  Needs
+// 4-byte aligned frames and npix % 4 == 0 (checked on the host); the byte kernel covers the rest.
+__global__ __launch_bounds__(256) void k_gray4(GrayArgs a) {
+  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(a.frames[blockIdx.y]);
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(a.gray + (size_t)blockIdx.y * a.npix);
+  const int n4 = a.npix >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const unsigned w0 = src[3 * (size_t)i], w1 = src[3 * (size_t)i + 1], w2 = src[3 * (size_t)i + 2];
+    // bytes: w0 = r0 g0 b0 r1 | w1 = g1 b1 r2 g2 | w2 = b2 r3 g3 b3   (little endian, "r" = byte 0 of a pixel)
+    const int g0 = (int)((w0 & 0xff) * a.cb + ((w0 >> 8) & 0xff) * a.cg + ((w0 >> 16) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g1 = (int)((w0 >> 24) * a.cb + (w1 & 0xff) * a.cg + ((w1 >> 8) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g2 = (int)(((w1 >> 16) & 0xff) * a.cb + (w1 >> 24) * a.cg + (w2 & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g3 = (int)(((w2 >> 8) & 0xff) * a.cb + ((w2 >> 16) & 0xff) * a.cg + (w2 >> 24) * a.cr + a.rnd) >> a.shift;
+    dst[i] = (unsigned)g0 | ((unsigned)g1 << 8) | ((unsigned)g2 << 16) | ((unsigned)g3 << 24);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pyramid image of level k: float(gray) -> GaussianBlur(ks, sigma) at FULL resolution ->
 // resize to (dh, dw).  Only the blurred samples the resize reads are computed: per 32x8
@@ -436,10 +453,29 @@ __global__ __launch_bounds__(256) void k_pyr_dec(PyrDecArgs a) {
   const int dy0 = blockIdx.y * a.rows_per_seg;
   const int dy1 = min(a.dh, dy0 + a.rows_per_seg);
 
+  // Source bytes [xl, xl+KS] of a row.  Interior threads fetch them as NW aligned dwords (one or
+  // two wide loads instead of KS+1 byte loads: the byte version was bound by the number of
+  // vector-memory instructions) and realign with v_alignbyte; border threads, and rows that are not
+  // dword aligned, take the reflected byte path.
+  constexpr int NW = S == 2 ? 2 : (S == 4 ? 3 : 6);
+  constexpr int NAL = (KS + 1 + 3) / 4;
+  const int xa = xl & ~3;
+  const unsigned shift = (unsigned)(xl & 3);
+  const bool wide = !edge && (sw & 3) == 0 && xa + 4 * NW <= sw && (((uintptr_t)src) & 3) == 0;
   auto hrow = [&](int y, float& hA, float& hB) {
     const uint8_t* __restrict__ g = src + (size_t)d_reflect101(y, sh) * sw;
     float b[KS + 1];
-    if (!edge) {
+    if (wide) {
+      const unsigned* __restrict__ gw = reinterpret_cast<const unsigned*>(g + xa);
+      unsigned wv[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) wv[i] = gw[i];
+      unsigned al[NAL];
+#pragma unroll
+      for (int j = 0; j < NAL; ++j) al[j] = __builtin_amdgcn_alignbyte(wv[j + 1 < NW ? j + 1 : NW - 1], wv[j], shift);
+#pragma unroll
+      for (int i = 0; i <= KS; ++i) b[i] = (float)((al[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    } else if (!edge) {
 #pragma unroll
       for (int i = 0; i <= KS; ++i) b[i] = (float)g[xl + i];
     } else {
@@ -1686,7 +1722,8 @@ int rows_per_segment(st_ctx* ctx, int h, int strips, int batch, int halo) {
   return rows;
 }
 
-int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int h, int w, int bits, uint8_t* gray) {
+int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int h, int w, int bits, uint8_t* gray,
+                bool frames_aligned4) {
   GrayArgs a;
   a.frames = frames_table_dev;
   a.gray = gray;
@@ -1694,10 +1731,13 @@ int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int 
   if (bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }
   a.shift = bits;
   a.rnd = 1 << (bits - 1);
-  int bx = (a.npix + 255) / 256;
+  const bool vec = frames_aligned4 && a.npix % 4 == 0 && ((uintptr_t)gray & 3) == 0;
+  int bx = ((vec ? a.npix / 4 : a.npix) + 255) / 256;
   if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
   st_timed t(ctx, ST_K_GRAY);
-  hipLaunchKernelGGL(k_gray, dim3(bx, n), dim3(256), 0, ctx->stream, a);
+  if (vec) hipLaunchKernelGGL(k_gray4, dim3(bx, n), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_gray, dim3(bx, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
@@ -1946,7 +1986,9 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   ST_HIP(ctx, hipMemcpyAsync(d_outs, outs, sizeof(void*) * npairs, hipMemcpyHostToDevice, ctx->stream));
 
   // per-frame stages: each distinct frame once
-  ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray));
+  bool aligned4 = true;
+  for (int i = 0; i < nf; ++i) aligned4 = aligned4 && ((uintptr_t)frames[i] & 3) == 0;
+  ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
   for (int k = levels; k >= 0; --k) {
     ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
     ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
@@ -2115,7 +2157,7 @@ ST_EXPORT int st_gray_u8(st_ctx* ctx, const uint8_t* rgb_dev, int h, int w, int 
   ST_TRY(st_ws_reserve(ctx, 4096));
   const uint8_t** t = (const uint8_t**)st_ws_alloc(ctx, sizeof(void*));
   ST_HIP(ctx, hipMemcpyAsync(t, &rgb_dev, sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-  return launch_gray(ctx, t, 1, h, w, gray_bits, gray_dev);
+  return launch_gray(ctx, t, 1, h, w, gray_bits, gray_dev, ((uintptr_t)rgb_dev & 3) == 0);
 }
 
 ST_EXPORT int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w, const st_fb_params* params, int level,
