@@ -4,8 +4,11 @@ Mirrors ``/root/reference/scannertools/scannertools/shot_detection.py:11-28``: s
 same arguments, same output contract (row 0 = list of boundary indices, rows 1.. = None), same
 constants.  The reference op is a Python/numpy op that Scanner runs on the host with the whole
 stream as one batch; so is this one.  The per-pair histogram distances are computed in one
-vectorised pass instead of 3(n-1) scipy calls; the windowed outlier test keeps the reference's
-``np.mean`` / ``np.std`` calls on the same slices so that every comparison is bit-identical.
+vectorised pass instead of 3(n-1) scipy calls.  The windowed outlier test evaluates the
+reference's ``np.mean`` / ``np.std`` over the same slices: full-width windows go through one
+strided 2-D reduction (numpy reduces each row with the same pairwise summation as the 1-D call,
+so means and standard deviations are bit-identical -- tests/test_host.py checks this against the
+per-window loop and against the reference's golden outputs), the <= 999 edge windows one by one.
 """
 from typing import Any, Sequence
 
@@ -47,10 +50,36 @@ def shot_boundaries(config, histograms: Sequence[Histogram]) -> Sequence[Any]:
     n = len(diffs)
 
     # Do simple outlier detection to find boundaries between shots (shot_detection.py:21-26)
+    boundaries = outlier_boundaries(diffs)
+
+    return [boundaries] + [None for _ in range(len(histograms) - 1)]
+
+
+def outlier_boundaries(diffs: np.ndarray) -> list:
+    """i in [1, n) with diffs[i] - mean(win) > 2.5 * std(win), win = diffs[max(i-W,0):min(i+W,n)]."""
+    diffs = np.ascontiguousarray(diffs, dtype=np.float64)
+    n, W = len(diffs), WINDOW_SIZE
+    flag = np.zeros(n, dtype=bool)
+    if n >= 2 * W:
+        # rows W..n-W have the full window diffs[i-W:i+W]: one strided (n-2W+1, 2W) view
+        v = np.lib.stride_tricks.sliding_window_view(diffs, 2 * W)
+        idx = np.arange(W, n - W + 1)
+        flag[idx] = diffs[idx] - np.mean(v, axis=1) > 2.5 * np.std(v, axis=1)
+        edge = list(range(1, W)) + list(range(n - W + 1, n))
+    else:
+        edge = range(1, n)
+    for i in edge:
+        window = diffs[max(i - W, 0):min(i + W, n)]
+        flag[i] = diffs[i] - np.mean(window) > 2.5 * np.std(window)
+    return [int(i) for i in np.nonzero(flag)[0]]
+
+
+def _outlier_boundaries_loop(diffs: np.ndarray) -> list:
+    """The reference's loop, verbatim in structure (shot_detection.py:21-26); test cross-check."""
+    n = len(diffs)
     boundaries = []
     for i in range(1, n):
         window = diffs[max(i - WINDOW_SIZE, 0):min(i + WINDOW_SIZE, n)]
         if diffs[i] - np.mean(window) > 2.5 * np.std(window):
             boundaries.append(i)
-
-    return [boundaries] + [None for _ in range(len(histograms) - 1)]
+    return boundaries

@@ -34,6 +34,19 @@ def test_shot_boundaries_contract_and_constants():
         sa.shot_boundaries(None, [np.zeros((2, 16), np.int32)] * 4)
 
 
+def test_vectorised_window_statistics_equal_the_reference_loop():
+    from scannertools_amd.shot_detection import _outlier_boundaries_loop, outlier_boundaries
+    rng = np.random.default_rng(0)
+    for trial in range(25):
+        n = int(rng.integers(1, 3500)) if trial < 22 else (999, 1000, 1001)[trial - 22]
+        d = np.abs(rng.standard_normal(n)) * float(rng.integers(1, 1000)) / 3.0
+        if n > 5:
+            d[rng.integers(0, n, 5)] *= 50
+        d[0] = 0
+        assert outlier_boundaries(d) == _outlier_boundaries_loop(d), (trial, n)
+    assert outlier_boundaries(np.zeros(0)) == [] and outlier_boundaries(np.zeros(1)) == []
+
+
 def test_histogram_diffs_is_chebyshev_mean():
     from scipy.spatial import distance
     from scannertools_amd.shot_detection import histogram_diffs
