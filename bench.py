@@ -186,6 +186,18 @@ def main():
     ctx.timing_enable([])
     hist_bytes = (3 * h * w + 3 * args.bins * 4) * B
     hist_gbs = hist_bytes * hist_steps / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
+    # same kernel on i.i.d. uniform bytes (SURVEY.md 8d "random u8" input): the LDS-atomic-heavy case
+    g = torch.Generator(device=device).manual_seed(7 + rank)
+    rnd = torch.randint(0, 256, (B, h, w, 3), dtype=torch.uint8, device=device, generator=g)
+    ctx.histogram(rnd, args.bins, out=hist_out)
+    ctx.timing_enable([_native.K_HIST])
+    ctx.timing_reset()
+    for i in range(hist_steps):
+        ctx.histogram(rnd, args.bins, out=hist_out)
+    rnd_launches, rnd_ms = ctx.timing_read(_native.K_HIST)
+    ctx.timing_enable([])
+    del rnd
+    rnd_gbs = hist_bytes * hist_steps / (rnd_ms * 1e-3) / 1e9 if rnd_ms > 0 else 0.0
 
     # HBM bytes per k_flow_iter launch from the PMC counters of the committed profile of this same
     # command (scripts/profile_round.sh -> scripts/pmc_traffic.py -> profiles/traffic.json):
@@ -242,13 +254,15 @@ def main():
             },
             "histogram": {
                 "frames_per_s": B * hist_steps / th,
-                "kernel": "k_hist_u8c3",
+                "kernel": "k_hist_u8c3_v2",
                 "achieved": hist_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": hist_gbs / HBM_PEAK_GBS,
                 "launches": hist_launches,
                 "avg_launch_ms": hist_ms / max(hist_launches, 1),
+                "uniform_random_frames": {"achieved": rnd_gbs, "frac": rnd_gbs / HBM_PEAK_GBS,
+                                          "frames_per_s": B * hist_steps / (rnd_ms * 1e-3) if rnd_ms > 0 else 0.0},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

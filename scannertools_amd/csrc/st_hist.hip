@@ -224,7 +224,8 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
 int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
   const long long nbytes = 3LL * h * w;
   const long long nvec = nbytes / 16;
-  long long target = (long long)ctx->num_cus * 16;
+  static const int tmul = getenv("ST_HIST_TARGET") ? atoi(getenv("ST_HIST_TARGET")) : 16;
+  long long target = (long long)ctx->num_cus * tmul;
   long long chunks = (target + n - 1) / n;
   long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
   if (chunks > max_chunks) chunks = max_chunks;

@@ -5,7 +5,7 @@ import torch
 from scannertools_amd import _native
 from scannertools_amd.hip import HipContext
 ctx = HipContext(0)
-n, h, w = 64, 1080, 1920
+n, h, w = int(os.environ.get('N', 64)), 1080, 1920
 g = torch.Generator(device="cuda").manual_seed(0)
 data = {"random": torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g),
         "equal": torch.full((n, h, w, 3), 77, dtype=torch.uint8, device="cuda")}
