@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 
@@ -33,6 +34,60 @@ std::map<uintptr_t, Block>::iterator find_block(const u8* p) {
   return g_blocks.end();
 }
 
+// Host buffers come from a small pool of PINNED blocks (Scanner keeps pinned pools for the same
+// reason): a D2H copy into freshly malloc'ed pageable memory is bound by first-touch page faults
+// (~2 GB/s), not by PCIe.  Blocks are reused when a free one is at most 2x the request; the pool
+// is capped so that it cannot grow without bound.  Without a GPU runtime plain malloc is used.
+struct HostBlock { u8* p; size_t size; bool pinned; };
+std::vector<HostBlock> g_host_pool;                 // free blocks
+std::map<uintptr_t, HostBlock> g_host_live;         // blocks handed out
+size_t g_host_pooled_bytes = 0;
+constexpr size_t kHostPoolCap = (size_t)8 << 30;
+constexpr size_t kHostPoolMin = (size_t)1 << 20;    // small buffers are not worth pinning
+
+u8* host_alloc(size_t size) {
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    for (size_t i = 0; i < g_host_pool.size(); ++i) {
+      if (g_host_pool[i].size >= size && g_host_pool[i].size <= 2 * size) {
+        HostBlock b = g_host_pool[i];
+        g_host_pool.erase(g_host_pool.begin() + i);
+        g_host_pooled_bytes -= b.size;
+        g_host_live[(uintptr_t)b.p] = b;
+        return b.p;
+      }
+    }
+  }
+  HostBlock b{nullptr, size, false};
+  if (size >= kHostPoolMin) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, size, hipHostMallocDefault) == hipSuccess) { b.p = (u8*)p; b.pinned = true; }
+    else (void)hipGetLastError();
+  }
+  if (!b.p) b.p = (u8*)malloc(size);
+  LOG_IF(FATAL, b.p == nullptr) << "host allocation failed";
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  g_host_live[(uintptr_t)b.p] = b;
+  return b.p;
+}
+
+void host_free(u8* p) {
+  HostBlock b;
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    auto it = g_host_live.find((uintptr_t)p);
+    LOG_IF(FATAL, it == g_host_live.end()) << "freeing unknown host block";
+    b = it->second;
+    g_host_live.erase(it);
+    if (b.pinned && g_host_pooled_bytes + b.size <= kHostPoolCap) {
+      g_host_pool.push_back(b);
+      g_host_pooled_bytes += b.size;
+      return;
+    }
+  }
+  if (b.pinned) (void)hipHostFree(b.p); else free(b.p);
+}
+
 u8* raw_alloc(DeviceHandle device, size_t size) {
   void* p = nullptr;
   if (size == 0) size = 1;
@@ -40,8 +95,7 @@ u8* raw_alloc(DeviceHandle device, size_t size) {
     LOG_IF(FATAL, hipSetDevice(device.id) != hipSuccess) << "hipSetDevice failed";
     LOG_IF(FATAL, hipMalloc(&p, size) != hipSuccess) << "hipMalloc failed";
   } else {
-    p = malloc(size);
-    LOG_IF(FATAL, p == nullptr) << "malloc failed";
+    p = host_alloc(size);
   }
   return (u8*)p;
 }
@@ -51,7 +105,7 @@ void raw_free(DeviceHandle device, u8* p) {
     (void)hipSetDevice(device.id);
     (void)hipFree(p);
   } else {
-    free(p);
+    host_free(p);
   }
 }
 }  // namespace
@@ -158,6 +212,8 @@ struct EngineOutputs {
   DeviceHandle device;
   Elements elements;  // one per input row
 };
+
+double g_last_execute_seconds = 0.0;  // wall time spent inside execute() by the last stshim_run_frames
 
 void set_err(char* err, size_t n, const std::string& s) {
   if (err && n) { strncpy(err, s.c_str(), n - 1); err[n - 1] = 0; }
@@ -267,7 +323,9 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
 
   auto* outs = new EngineOutputs();
   outs->device = ek->device;
+  g_last_execute_seconds = 0.0;
   for (int r0 = 0; r0 < n; r0 += batch) {
+    const auto t_begin = std::chrono::steady_clock::now();
     const int nb = std::min(batch, n - r0);
     BatchedElements out_cols(1);
     switch (ek->reg.kind) {
@@ -302,6 +360,7 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
         break;
       }
     }
+    g_last_execute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if ((int)out_cols[0].size() != nb) {
       set_err(err, err_len, "kernel produced " + std::to_string(out_cols[0].size()) + " outputs for " + std::to_string(nb) + " rows");
       for (auto& e : out_cols[0]) outs->elements.push_back(e);
@@ -351,5 +410,7 @@ SHIM_EXPORT void stshim_outputs_free(void* o) {
   }
   delete outs;
 }
+
+SHIM_EXPORT double stshim_last_execute_seconds() { return g_last_execute_seconds; }
 
 SHIM_EXPORT size_t stshim_live_buffers(int device_type) { return shim_live_buffers((DeviceType)device_type); }

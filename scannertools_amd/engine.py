@@ -86,6 +86,7 @@ def _imgproc():
         L.stshim_output_copy.argtypes = [vp, ci, vp, sz]
         L.stshim_outputs_free.argtypes = [vp]
         L.stshim_live_buffers.restype = sz
+        L.stshim_last_execute_seconds.restype = ctypes.c_double
         L.stshim_live_buffers.argtypes = [ci]
         _LIB = L
     return _LIB
@@ -212,6 +213,7 @@ class _CppOpNode(_Node):
                 if self.device == DeviceType.GPU:
                     torch.cuda.synchronize(dev_id)  # kernel contexts run on their own streams
                 res = L.stshim_run_frames(k, tab, len(ptrs), h, w, c, ftype, self.batch, st, len(self.stencil), err, 512)
+                self.client.execute_seconds += L.stshim_last_execute_seconds()
                 if not res or err.value:
                     if res:
                         L.stshim_outputs_free(res)
@@ -232,13 +234,16 @@ class _CppOpNode(_Node):
         shape = (ctypes.c_int * 3)()
         if L.stshim_output_get(res, i, ctypes.byref(data), ctypes.byref(size), ctypes.byref(isf), shape, ctypes.byref(typ)):
             raise RuntimeError("missing output row %d" % i)
-        buf = (ctypes.c_uint8 * size.value)()
+        if isf.value:
+            arr = np.empty((shape[0], shape[1], shape[2]), dtype=_FRAME_DTYPES[typ.value])
+            assert arr.nbytes == size.value
+            if L.stshim_output_copy(res, i, arr.ctypes.data_as(ctypes.c_void_p), size.value):
+                raise RuntimeError("copying output row %d failed" % i)
+            return arr
+        buf = ctypes.create_string_buffer(size.value)
         if L.stshim_output_copy(res, i, buf, size.value):
             raise RuntimeError("copying output row %d failed" % i)
-        raw = bytes(buf)
-        if isf.value:
-            return np.frombuffer(raw, dtype=_FRAME_DTYPES[typ.value]).reshape(shape[0], shape[1], shape[2])
-        return raw
+        return buf.raw
 
 
 class _PyOpNode(_Node):
@@ -363,6 +368,7 @@ class Client:
     def __init__(self, device_id=0, **_ignored):
         self.device_id = device_id
         self._videos, self._tables = {}, {}
+        self.execute_seconds = 0.0  # wall time spent inside kernel execute() calls (excludes Python copies)
         self.io, self.ops, self.streams = _IO(self), _Ops(self), _Streams()
 
     def ingest_frames(self, name, frames):
