@@ -28,15 +28,6 @@
 
 namespace {
 
-// compile-time diagnostics switch (never set in product builds): 1 aligned instead of gathered R1
-// reads, 2 no 2x2 solve, 4 no R1 loads, 8 no phase 2 at all
-#ifndef ST_ABLATE
-#define ST_ABLATE 0
-#endif
-#ifndef ST_P2_FLOAT_TRIPLES
-#define ST_P2_FLOAT_TRIPLES 0
-#endif
-
 constexpr int kMaxTaps = 32;   // Gaussian pyramid kernel taps (reference needs <= 19)
 constexpr int kMaxPolyN = 7;
 
@@ -699,15 +690,13 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   int gi = L.inb ? y1 * w + x1 : 0;  // out of range: harmless in-plane address, result unused
   const int wo = L.inb ? w : 0;
   const int o = y * w + x;
-  if (ST_ABLATE & 1) gi = L.inb ? (o < np - w - 1 ? o : 0) : 0;
-  if (ST_ABLATE & 32) { const int yz = (y1 + (y % 3) * 2) % (h - 1); gi = L.inb ? yz * w + x1 : 0; }
   const unsigned plane = 4u * (unsigned)np;
   unsigned bo = 4u * (unsigned)o, bt = 4u * (unsigned)gi, bb = 4u * (unsigned)(gi + wo);
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     L.q[c] = ldf(R0, bo);
-    if (ST_ABLATE & 4) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = L.q[c]; }
-    else { L.t[c] = ldf2(R1, bt); L.b[c] = ldf2(R1, bb); }
+    L.t[c] = ldf2(R1, bt);
+    L.b[c] = ldf2(R1, bb);
     bo += plane; bt += plane; bb += plane;
   }
 }
@@ -1347,28 +1336,17 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
         __syncthreads();
         PSTAMP();
         // ---- phase 2: horizontal window + solve ----
-        if (tid < RB * NSEG && !(ST_ABLATE & 8)) {
+        if (tid < RB * NSEG) {
           const int r = tid / NSEG, sg = tid - r * NSEG;
           const int j0 = B2_HALO + sg * RB;
-          if (ST_ABLATE & 16) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-              F[r][j0 + i] = make_float2(V[r][0][j0 + i] + V[r][1][j0 + i] + V[r][2][j0 + i], V[r][3][j0 + i] + V[r][4][j0 + i]);
-          } else {
+          {
           double t[5];
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             const VT* vp = &V[r][c][j0 - M];
-#if ST_P2_FLOAT_TRIPLES
-            // window of 15 as five float triples summed in double (5 cvt + 4 DP adds instead of 15 + 14)
-            double acc = (double)((vp[0] + vp[1]) + vp[2]);
-#pragma unroll
-            for (int i = 3; i < W; i += 3) acc += (double)((vp[i] + vp[i + 1]) + vp[i + 2]);
-#else
             double acc = vp[0];
 #pragma unroll
             for (int i = 1; i < W; ++i) acc += (double)vp[i];
-#endif
             t[c] = acc;
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -1377,17 +1355,11 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
             if (i > 0) {
 #pragma unroll
               for (int c = 0; c < 5; ++c) {
-#if ST_P2_FLOAT_TRIPLES
-                const float dv = V[r][c][j0 + i + M] - V[r][c][j0 + i - M - 1];
-                t[c] += dv;
-#else
                 t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
-#endif
               }
             }
             const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
             const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
-            if (ST_ABLATE & 2) { F[r][j0 + i] = make_float2((float)(g11 + g12 + g22), (float)(h1 + h2)); continue; }
             const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
             F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
             __builtin_amdgcn_sched_barrier(0);
@@ -1776,8 +1748,7 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
       const int bx = (g.lw + 255) / 256;
       long long segs = ((long long)ctx->num_cus * 8 + (long long)bx * n - 1) / ((long long)bx * n);
       int rows = (int)((g.lh + segs - 1) / segs);
-      static const int min8 = getenv("ST_PYR8_ROWS") ? atoi(getenv("ST_PYR8_ROWS")) : 4;
-      const int min_rows = S == 8 ? min8 : 8;
+      const int min_rows = S == 8 ? 4 : 8;
       if (rows < min_rows) rows = g.lh < min_rows ? g.lh : min_rows;
       z.rows_per_seg = rows;
       dim3 grid(bx, (g.lh + rows - 1) / rows, n);
@@ -1829,10 +1800,9 @@ int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
 }
 
 int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
-  if (a.m == 7 && !getenv("ST_BLUR_GENERIC")) {
+  if (a.m == 7) {
     const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-    // segments are whole ring periods (15 rows) so that the static ring indexing stays aligned
-    // >= 4 workgroups per CU if the level is big enough; never below one ring period
+    // whole ring periods (15 rows) per segment; >= 4 workgroups per CU when the level allows
     long long segs = ((long long)ctx->num_cus * 4 + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
     int rows = (int)((a.h + segs - 1) / segs);
     rows = (rows + 14) / 15 * 15;
@@ -1840,14 +1810,8 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
     if (rows > 135 && a.h > 135) rows = 135;
     a.rows_per_seg = rows;
     dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
-    static const int variant = getenv("ST_BLUR_VARIANT") ? atoi(getenv("ST_BLUR_VARIANT")) : 0;
     st_timed t(ctx, ST_K_BLUR_UPDATE);
-    if (variant == 1) hipLaunchKernelGGL((k_blur_update_v2<7, false, 1, 4>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (variant == 3) hipLaunchKernelGGL((k_blur_update_v2<7, true, 2, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (variant == 4) hipLaunchKernelGGL((k_blur_update_v2<7, false, 5, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (variant == 5) hipLaunchKernelGGL((k_blur_update_v2<7, false, 2, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (variant == 6) hipLaunchKernelGGL((k_blur_update_v2<7, true, 1, 3>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_blur_update_v2<7, true, 5, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_blur_update_v2<7, true, 5, 2>), grid, dim3(B2_T), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
@@ -1862,9 +1826,10 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-  // aim for two full rounds of resident workgroups (2 per CU at 256 VGPRs); whole ring periods
-  static const int seg_mult = getenv("ST_ITER_SEGMULT") ? atoi(getenv("ST_ITER_SEGMULT")) : 2;
-  long long target = (long long)ctx->num_cus * seg_mult;
+  // One round of resident workgroups per launch (2 per CU at this register budget) when the level
+  // is big enough: the ring initialisation (15 rows of UpdateMatrices per segment) is pure
+  // overhead, so segments are as tall as parallelism allows; whole ring periods.
+  long long target = (long long)ctx->num_cus * 2;
   long long segs = (target + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
   int rows = (int)((a.h + segs - 1) / segs);
   rows = (rows + 14) / 15 * 15;
@@ -1878,23 +1843,18 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
   a.prof = (a.h >= 1000) ? prof_buf : nullptr;
 #endif
-  static const int rb = getenv("ST_ITER_RB") ? atoi(getenv("ST_ITER_RB")) : 3;
-  static const int tile = getenv("ST_ITER_TILE") ? atoi(getenv("ST_ITER_TILE")) : 0;
+  // ST_ITER_TILE=1 selects the experimental LDS-tiled variant (slower, kept for A/B runs)
+  static const bool tile = getenv("ST_ITER_TILE") && atoi(getenv("ST_ITER_TILE")) != 0;
   if (tile && a.w % 4 == 0 && a.h >= 2) {
     if (a.coarse) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
     else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
     else hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
-    ST_HIP(ctx, hipGetLastError());
-  } else
-  {
-  static const int vdouble = getenv("ST_ITER_VDOUBLE") ? atoi(getenv("ST_ITER_VDOUBLE")) : 0;
-  (void)vdouble; (void)rb;
-  static const int extra_lds = getenv("ST_ITER_EXTRA_LDS") ? atoi(getenv("ST_ITER_EXTRA_LDS")) : 0;  // occupancy experiments
-  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
-  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), extra_lds, ctx->stream, a);
-  ST_HIP(ctx, hipGetLastError());
+  } else {
+    if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
   }
+  ST_HIP(ctx, hipGetLastError());
 #ifdef ST_PROF
   if (a.prof && getenv("ST_PROF_DUMP")) {
     static int dumped = 0;
@@ -1908,7 +1868,7 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
         int nb = 0;
         for (int i = 0; i + 6 < 4000 && q[i + 6]; i += 6, ++nb)
           for (int j = 0; j < 6; ++j) acc[j] += (double)(q[i + j + 1] - q[i + j]);
-        fprintf(stderr, "[prof wg%d] batches %d  cycles/batch (6 intervals between stamps; k_flow_iter: P1finish issue bar1 P2 bar2 P3+loop | k_flow_iter_t: barA P1 A2+reduce+B issue P2 C+P3+loop): %.0f %.0f %.0f %.0f %.0f %.0f  total %.0f\n",
+        fprintf(stderr, "[prof wg%d] batches %d  cycles between the 6 stamps of a batch: %.0f %.0f %.0f %.0f %.0f %.0f  total %.0f\n",
                 wgi, nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb,
                 (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / nb);
       }
@@ -2029,51 +1989,36 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     }
     return ST_OK;
   }
-  // per-pair stages, coarse to fine.  Within a level the pairs are processed in groups of G:
-  // a group's UpdateMatrices + numIters blur passes run back to back so that its R0/R1/M
-  // working set (166 MB per 1080p pair at level 0) can stay in the 256 MB Infinity Cache
-  // between passes instead of streaming from HBM each time.
-  static const int group_env = getenv("ST_PAIR_GROUP") ? atoi(getenv("ST_PAIR_GROUP")) : 0;
+  // unfused path (window sizes other than 15, degenerate frames): materialised M, one
+  // UpdateMatrices + numIters blur launches per level
   int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
   for (int k = levels; k >= 0; --k) {
     const int lh = geom[k].lh, lw = geom[k].lw;
-    const size_t npk = (size_t)lh * lw;
-    int G = npairs;
-    if (group_env > 0) {
-      // groups sized so that (G+1) expansions + 2G matrices fit ~200 MB
-      const double per_pair = 60.0 * npk, per_frame = 20.0 * npk;
-      int fit = (int)((200e6 * group_env - per_frame) / per_pair);
-      G = fit < 1 ? 1 : (fit > npairs ? npairs : fit);
+    UMArgs u;
+    memset(&u, 0, sizeof(u));
+    u.R = R[k]; u.pairs = d_pairs; u.M = M[0]; u.h = lh; u.w = lw;
+    if (k < levels) {
+      u.ch = geom[k + 1].lh; u.cw = geom[k + 1].lw;
+      u.coarse = cflow[cur];
+      u.scale_x = 1. / ((double)lw / u.cw);
+      u.scale_y = 1. / ((double)lh / u.ch);
+      u.mul = (float)(1. / p.pyr_scale);
     }
-    for (int g0 = 0; g0 < npairs; g0 += G) {
-      const int gn = npairs - g0 < G ? npairs - g0 : G;
-      UMArgs u;
-      memset(&u, 0, sizeof(u));
-      u.R = R[k]; u.pairs = d_pairs + 2 * g0; u.M = M[0] + (size_t)g0 * 5 * npk; u.h = lh; u.w = lw;
-      if (k < levels) {
-        u.ch = geom[k + 1].lh; u.cw = geom[k + 1].lw;
-        u.coarse = cflow[cur] + (size_t)g0 * 2 * u.ch * u.cw;
-        u.scale_x = 1. / ((double)lw / u.cw);
-        u.scale_y = 1. / ((double)lh / u.ch);
-        u.mul = (float)(1. / p.pyr_scale);
+    ST_TRY(launch_update_matrices(ctx, u, npairs));
+    int mi = 0;
+    for (int it = 0; it < p.num_iters; ++it) {
+      const bool last = it == p.num_iters - 1;
+      BlurArgs bl;
+      memset(&bl, 0, sizeof(bl));
+      bl.R = R[k]; bl.pairs = d_pairs; bl.Min = M[mi]; bl.Mout = M[mi ^ 1];
+      bl.h = lh; bl.w = lw; bl.m = p.win_size / 2;
+      bl.update = !last; bl.write_flow = last;
+      bl.scale = 1. / ((double)p.win_size * p.win_size);
+      if (last) {
+        if (k == 0) bl.flow_ptrs = d_outs; else bl.flow = cflow[cur ^ 1];
       }
-      ST_TRY(launch_update_matrices(ctx, u, gn));
-      int mi = 0;
-      for (int it = 0; it < p.num_iters; ++it) {
-        const bool last = it == p.num_iters - 1;
-        BlurArgs b;
-        memset(&b, 0, sizeof(b));
-        b.R = R[k]; b.pairs = d_pairs + 2 * g0;
-        b.Min = M[mi] + (size_t)g0 * 5 * npk; b.Mout = M[mi ^ 1] + (size_t)g0 * 5 * npk;
-        b.h = lh; b.w = lw; b.m = p.win_size / 2;
-        b.update = !last; b.write_flow = last;
-        b.scale = 1. / ((double)p.win_size * p.win_size);
-        if (last) {
-          if (k == 0) b.flow_ptrs = d_outs + g0; else b.flow = cflow[cur ^ 1] + (size_t)g0 * 2 * npk;
-        }
-        ST_TRY(launch_blur(ctx, b, gn));
-        mi ^= 1;
-      }
+      ST_TRY(launch_blur(ctx, bl, npairs));
+      mi ^= 1;
     }
     cur ^= 1;
   }

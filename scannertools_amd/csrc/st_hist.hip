@@ -224,8 +224,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
 int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
   const long long nbytes = 3LL * h * w;
   const long long nvec = nbytes / 16;
-  static const int tmul = getenv("ST_HIST_TARGET") ? atoi(getenv("ST_HIST_TARGET")) : 16;
-  long long target = (long long)ctx->num_cus * tmul;
+  long long target = (long long)ctx->num_cus * 16;
   long long chunks = (target + n - 1) / n;
   long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
   if (chunks > max_chunks) chunks = max_chunks;
@@ -236,20 +235,15 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     int nf = n - f0 < 65535 ? n - f0 : 65535;
     FrameSrc s = src;
     if (s.ptrs) s.ptrs += f0; else s.base += (size_t)f0 * s.stride;
-    static const int variant = getenv("ST_HIST_VARIANT") ? atoi(getenv("ST_HIST_VARIANT")) : 8;
+    // ST_HIST_VARIANT=0 selects the one-copy-per-wave kernel (A/B runs); default: 8 lane-indexed copies
+    static const bool one_copy = getenv("ST_HIST_VARIANT") && atoi(getenv("ST_HIST_VARIANT")) == 0;
     st_timed t(ctx, ST_K_HIST);
-    if (variant == 8)
-      hipLaunchKernelGGL(k_hist_u8c3_v2<8>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
-                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
-    else if (variant == 16)
-      hipLaunchKernelGGL(k_hist_u8c3_v2<16>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
-                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
-    else if (variant == 4)
-      hipLaunchKernelGGL(k_hist_u8c3_v2<4>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+    if (one_copy)
+      hipLaunchKernelGGL(k_hist_u8c3, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
                          nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
     else
-    hipLaunchKernelGGL(k_hist_u8c3, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
-                       nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+      hipLaunchKernelGGL(k_hist_u8c3_v2<8>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
+                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;
