@@ -7,10 +7,12 @@
 // Each frame byte is read exactly once with 16-B-per-lane coalesced loads; counts go to LDS
 // sub-histograms with ds_add_u32 (no return value), are folded to `bins` and committed with one
 // global atomic per non-empty bin per workgroup.  Algorithmic bytes per frame = 3*w*h + 3*bins*4.
-// Two kernels: k_hist_u8c3_v2<8> (default: 8 lane-indexed copies per workgroup, data-independent
-// throughput) and k_hist_u8c3 (one copy per wave; kept for A/B runs, ST_HIST_VARIANT=0).
-// Measured: 5.3 TB/s at 256 frames per launch, 4.0 TB/s at 64, whatever the conflict pattern
-// (scripts/bench_hist.py).
+// Kernels: k_hist_u8c3_v2<32,1024> (default: one 1024-thread workgroup per CU, 32 lane-indexed
+// copies of the 768 counters = 96 KB of LDS, so a lane always hits its own bank and no two lanes of
+// an LDS pass ever meet on a counter: data-independent throughput), k_hist_u8c3_v2<8,256> and
+// k_hist_u8c3 (one copy per wave) kept for A/B runs (ST_HIST_VARIANT=8 / 0).
+// Measured at 256 1080p frames per launch: 5.7 TB/s (scripts/bench_hist.py); LDS-atomic rates per
+// layout: scripts/ubench/ldsatomic.hip.
 #include <cstdlib>
 
 #include "st_internal.h"
@@ -148,15 +150,16 @@ __device__ __forceinline__ void count16c(unsigned* h, uint4 q, unsigned c0, unsi
   lds_inc(h + c0 + (q.w >> 24) * C);
 }
 
-template <int C>
-__global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
+template <int C, int T>
+__global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
                                                            int32_t* __restrict__ out) {
+  static_assert(T % 3 == 1, "the channel phase of a thread's vectors must advance by one per step");
   __shared__ unsigned sh[768 * C];
   const int tid = threadIdx.x;
   const int frame = blockIdx.y;
   const int chunk = blockIdx.x;
   const uint8_t* p = src.ptrs ? src.ptrs[frame] : src.base + (size_t)frame * src.stride;
-  for (int i = tid; i < 768 * C; i += kThreads) sh[i] = 0;
+  for (int i = tid; i < 768 * C; i += T) sh[i] = 0;
   __syncthreads();
   const unsigned copy = tid & (C - 1);
 
@@ -173,19 +176,37 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
   long long i = v0 + tid;
   const unsigned ph = (unsigned)((head + i) % 3);
   const unsigned o0 = ph * 256 * C + copy, o1 = ((ph + 1) % 3) * 256 * C + copy, o2 = ((ph + 2) % 3) * 256 * C + copy;
-  // six vectors in flight per thread (two phase cycles)
-  for (; i + 5 * kThreads < v1; i += 6 * kThreads) {
-    uint4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads];
-    uint4 d = vp[i + 3 * kThreads], e = vp[i + 4 * kThreads], f = vp[i + 5 * kThreads];
+  // Software pipeline over the steps every thread of the workgroup takes in full (six vectors =
+  // two phase cycles per step): the loads of step k+1 are requested before the 96 counter updates
+  // of step k.  The trip count is uniform and the loop has no conditional loads, so the compiler's
+  // vmcnt bookkeeping sees the same number of outstanding loads on every path into the loop.
+  const int full = v1 > v0 ? (int)((v1 - v0) / (6 * T)) : 0;
+  if (full > 0) {
+    uint4 a = vp[i], b = vp[i + T], c = vp[i + 2 * T];
+    uint4 d = vp[i + 3 * T], e = vp[i + 4 * T], f = vp[i + 5 * T];
+    for (int it = 1; it < full; ++it) {
+      i += 6 * T;
+      const uint4 na = vp[i], nb = vp[i + T], nc = vp[i + 2 * T];
+      const uint4 nd = vp[i + 3 * T], ne = vp[i + 4 * T], nf = vp[i + 5 * T];
+      __builtin_amdgcn_sched_barrier(0);
+      count16c<C>(sh, a, o0, o1, o2);
+      count16c<C>(sh, b, o1, o2, o0);
+      count16c<C>(sh, c, o2, o0, o1);
+      count16c<C>(sh, d, o0, o1, o2);
+      count16c<C>(sh, e, o1, o2, o0);
+      count16c<C>(sh, f, o2, o0, o1);
+      a = na; b = nb; c = nc; d = nd; e = ne; f = nf;
+    }
     count16c<C>(sh, a, o0, o1, o2);
     count16c<C>(sh, b, o1, o2, o0);
     count16c<C>(sh, c, o2, o0, o1);
     count16c<C>(sh, d, o0, o1, o2);
     count16c<C>(sh, e, o1, o2, o0);
     count16c<C>(sh, f, o2, o0, o1);
+    i += 6 * T;
   }
-  for (; i + 2 * kThreads < v1; i += 3 * kThreads) {
-    uint4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads];
+  for (; i + 2 * T < v1; i += 3 * T) {
+    uint4 a = vp[i], b = vp[i + T], c = vp[i + 2 * T];
     count16c<C>(sh, a, o0, o1, o2);
     count16c<C>(sh, b, o1, o2, o0);
     count16c<C>(sh, c, o2, o0, o1);
@@ -193,18 +214,18 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
   if (i < v1) {
     uint4 a = vp[i];
     count16c<C>(sh, a, o0, o1, o2);
-    if (i + kThreads < v1) {
-      uint4 b = vp[i + kThreads];
+    if (i + T < v1) {
+      uint4 b = vp[i + T];
       count16c<C>(sh, b, o1, o2, o0);
     }
   }
   if (chunk == 0) {
-    for (long long b = tid; b < head; b += kThreads) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
-    for (long long b = tail + tid; b < nbytes; b += kThreads) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
+    for (long long b = tid; b < head; b += T) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
+    for (long long b = tail + tid; b < nbytes; b += T) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
   }
   __syncthreads();
   // fold the C copies of every counter into copy 0
-  for (int b = tid; b < 768; b += kThreads) {
+  for (int b = tid; b < 768; b += T) {
     unsigned s = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) s += sh[b * C + ((c + tid) & (C - 1))];
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
   }
   __syncthreads();
   int32_t* o = out + (size_t)frame * 3 * bins;
-  for (int ob = tid; ob < 3 * bins; ob += kThreads) {
+  for (int ob = tid; ob < 3 * bins; ob += T) {
     const int ch = ob / bins, bin = ob - ch * bins;
     const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
     unsigned s = 0;
@@ -221,29 +242,53 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3_v2(FrameSrc src, long lo
   }
 }
 
+// Chunks per frame for the default kernel (one 1024-thread workgroup per CU at a time): the
+// launch takes ceil(n*c / CUs) rounds of workgroups that each stream 1/c of a frame, so pick the
+// c that minimises rounds/c (ties: fewer, larger chunks), with at least 6 vectors (one pipelined step) per thread.
+long long chunks_for(int num_cus, int n, long long nvec, int threads) {
+  long long mx = (nvec + 3LL * threads * 2 - 1) / (3LL * threads * 2);
+  if (mx < 1) mx = 1;
+  if (mx > 64) mx = 64;
+  long long best = 1;
+  double best_cost = 1e30;
+  for (long long c = 1; c <= mx; ++c) {
+    const long long rounds = ((long long)n * c + num_cus - 1) / num_cus;
+    const double cost = (double)rounds / (double)c + 0.002 * (double)rounds;  // per-round set-up/fold
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
 int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
   const long long nbytes = 3LL * h * w;
   const long long nvec = nbytes / 16;
-  long long target = (long long)ctx->num_cus * 16;
-  long long chunks = (target + n - 1) / n;
-  long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
+  // ST_HIST_VARIANT selects the older kernels for A/B runs: 8 = eight copies per 256-thread
+  // workgroup, 0 = one copy per wave.  Default: 32 lane-indexed copies, 1024 threads.
+  static const int variant = getenv("ST_HIST_VARIANT") ? atoi(getenv("ST_HIST_VARIANT")) : 32;
+  long long chunks;
+  if (variant == 32) {
+    chunks = chunks_for(ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
+  } else {
+    chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
+    long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+  }
   ST_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * 3 * (size_t)bins * n, ctx->stream));
   // grid.y is limited to 65535 frames per launch
   for (int f0 = 0; f0 < n; f0 += 65535) {
     int nf = n - f0 < 65535 ? n - f0 : 65535;
     FrameSrc s = src;
     if (s.ptrs) s.ptrs += f0; else s.base += (size_t)f0 * s.stride;
-    // ST_HIST_VARIANT=0 selects the one-copy-per-wave kernel (A/B runs); default: 8 lane-indexed copies
-    static const bool one_copy = getenv("ST_HIST_VARIANT") && atoi(getenv("ST_HIST_VARIANT")) == 0;
+    int32_t* o = out_dev + (size_t)f0 * 3 * bins;
+    const dim3 grid((unsigned)chunks, (unsigned)nf);
     st_timed t(ctx, ST_K_HIST);
-    if (one_copy)
-      hipLaunchKernelGGL(k_hist_u8c3, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
-                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+    if (variant == 32)
+      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+    else if (variant == 8)
+      hipLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else
-      hipLaunchKernelGGL(k_hist_u8c3_v2<8>, dim3((unsigned)chunks, (unsigned)nf), dim3(kThreads), 0, ctx->stream, s,
-                         nbytes, (int)chunks, bins, out_dev + (size_t)f0 * 3 * bins);
+      hipLaunchKernelGGL(k_hist_u8c3, grid, dim3(kThreads), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;
