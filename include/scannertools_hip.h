@@ -76,7 +76,9 @@ enum st_kernel_id {
   ST_K_POLYEXP = 3,
   ST_K_UPDATE_MATRICES = 4,
   ST_K_BLUR_UPDATE = 5, /* box blur + 2x2 solve (+ fused UpdateMatrices): the dominant kernel */
-  ST_K_COUNT = 6
+  ST_K_FLOW_HIST = 6,
+  ST_K_DRAW_FLOW = 7,   /* max-reduction + render launches of one st_draw_flow_batch call */
+  ST_K_COUNT = 8
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -164,6 +166,27 @@ int st_fb_update_flow_blur(st_ctx* ctx, const float* r0_dev, const float* r1_dev
 int st_fb_flow_iteration(st_ctx* ctx, const float* r0_dev, const float* r1_dev, const float* flow_in_dev,
                          const float* coarse_flow_dev, int ch, int cw, double pyr_scale, int h, int w,
                          int block_size, float* flow_out_dev);
+
+/* ---- Flow consumers ------------------------------------------------
+ * FlowHistogram: replaces FlowHistogramKernelCPU::execute's per-frame body
+ * (scannertools/old/cpp_ops/flow_histogram_kernel_cpu.cpp:26-57: cv::split, cv::cartToPolar(x, y,
+ * mag, deg, true), cv::calcHist on mag over [0,64) and on deg over [0,360), 64 bins each,
+ * convertTo(CV_32S)) for a whole batch in one launch.
+ * flows: n device pointers to (h, w, 2) float32 flow frames (x then y, the layout OpticalFlow
+ * emits), 8-byte aligned.  out_dev: n * 2 * 64 int32, per frame the magnitude row then the angle
+ * row -- the 512-byte block the reference hands to insert_element() (:55).  Values outside the
+ * ranges (mag >= 64, deg == 360, NaN) are not counted, as in cv::calcHist. */
+int st_flow_hist_batch(st_ctx* ctx, const float* const* flows_dev, int n, int h, int w, int32_t* out_dev);
+/* Same, flow frames at base_dev + i * frame_stride_bytes. */
+int st_flow_hist_strided(st_ctx* ctx, const float* base_dev, size_t frame_stride_bytes, int n, int h,
+                         int w, int32_t* out_dev);
+
+/* DrawFlow: replaces draw_flow() of scannertools/vis.py:8-12 for a batch:
+ * out = hstack(frame, uint8(min(avg / max(avg), 1) * 255) on 3 channels), avg = (fx + fy) / 2 in
+ * float32, max taken over the frame (NaN propagates, as np.max does), numpy's float32 -> uint8
+ * cast.  frames: (h, w, 3) uint8; flows: (h, w, 2) float32, 8-byte aligned; out: (h, 2w, 3) uint8. */
+int st_draw_flow_batch(st_ctx* ctx, const uint8_t* const* frames_dev, const float* const* flows_dev,
+                       int n, int h, int w, uint8_t* const* out_dev);
 
 #ifdef __cplusplus
 }

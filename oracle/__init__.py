@@ -188,6 +188,37 @@ def optical_flow_rgb(frame0, frame1, params=None):
 WINDOW_SIZE = 500  # shot_detection.py:7
 
 
+def cart_to_polar_deg(flow):
+    """(h,w,2) float32 -> (mag, deg) float32, cv::cartToPolar(angleInDegrees=true) restated."""
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w, _ = flow.shape
+    mag = np.empty((h, w), np.float32)
+    deg = np.empty((h, w), np.float32)
+    lib().orc_cart_to_polar_deg(_p(flow), ctypes.c_size_t(h * w), _p(mag), _p(deg))
+    return mag, deg
+
+
+def flow_hist(flow):
+    """(h,w,2) float32 -> (2,64) int32: FlowHistogram (old/cpp_ops/flow_histogram_kernel_cpu.cpp:26-57)."""
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w, c = flow.shape
+    assert c == 2
+    out = np.empty((2, 64), np.int32)
+    lib().orc_flow_hist(_p(flow), h, w, _p(out))
+    return out
+
+
+def draw_flow(frame, flow):
+    """(h,w,3) uint8, (h,w,2) float32 -> (h,2w,3) uint8: DrawFlow (scannertools/vis.py:8-12)."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w, _ = frame.shape
+    assert flow.shape == (h, w, 2)
+    out = np.empty((h, 2 * w, 3), np.uint8)
+    lib().orc_draw_flow(_p(frame), _p(flow), h, w, _p(out))
+    return out
+
+
 def shot_boundaries(histograms):
     """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
     each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices

@@ -551,3 +551,108 @@ ORC_API void orc_optical_flow_rgb(const uint8_t* frame0, const uint8_t* frame1, 
   orc_farneback(g0, g1, h, w, p, flow_out);
   free(g0); free(g1);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Flow consumers.
+ *
+ * FlowHistogram -- FlowHistogramKernelCPU::execute,
+ * /root/reference/scannertools/scannertools/old/cpp_ops/flow_histogram_kernel_cpu.cpp:26-57:
+ *   split(flow) -> cv::cartToPolar(x, y, mag, deg, angleInDegrees=true)
+ *   cv::calcHist(mag, 64 uniform bins on [0,64)), cv::calcHist(deg, 64 uniform bins on [0,360))
+ *   each converted to CV_32S; output = 2 x 64 int32 (magnitude row first).
+ * OpenCV (un-vendored) arithmetic restated, scalar non-FMA build:
+ *   cartToPolar 32F (core/src/mathfuncs.cpp): hal::magnitude32f = sqrt(x*x + y*y) in float;
+ *     hal::fastAtan32f = atan_f32(y, x) * 1.f, the 7th-order odd polynomial of
+ *     core/src/mathfuncs_core.simd.hpp (max error ~0.3 deg), result in [0, 360].
+ *   calcHist 32F uniform (imgproc/src/histogram.cpp calcHist_): idx = cvFloor(double(v)*a + b)
+ *     with a = bins/(hi-lo), b = -a*lo in double; counted iff 0 <= idx < bins (v == hi, NaN
+ *     and negative values are dropped).
+ * PARITY UNPINNED against real OpenCV output (no OpenCV here); pinned by known-answer tests
+ * (axis-aligned vectors -> exact angles/magnitudes) in tests/.
+ * ------------------------------------------------------------------------------------------ */
+#include <float.h>
+#define ORC_CV_PI 3.1415926535897932384626433832795 /* CV_PI */
+
+static inline float orc_fast_atan2_deg(float y, float x) {
+  static const float p1 = 0.9997878412794807f * (float)(180 / ORC_CV_PI);
+  static const float p3 = -0.3258083974640975f * (float)(180 / ORC_CV_PI);
+  static const float p5 = 0.1555786518463281f * (float)(180 / ORC_CV_PI);
+  static const float p7 = -0.04432655554792128f * (float)(180 / ORC_CV_PI);
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+static inline int orc_cv_floor(double v) {
+  /* cvFloor: NaN / out-of-range follow cvtsd2si (INT_MIN), which the range test rejects */
+  if (!(v > -2147483648.0 && v < 2147483648.0)) return INT32_MIN;
+  int i = (int)v;
+  return i - (v < i);
+}
+
+ORC_API void orc_cart_to_polar_deg(const float* flow, size_t npx, float* mag, float* deg) {
+  for (size_t i = 0; i < npx; ++i) {
+    float x = flow[2 * i], y = flow[2 * i + 1];
+    mag[i] = sqrtf(x * x + y * y);
+    deg[i] = orc_fast_atan2_deg(y, x) * 1.f;
+  }
+}
+
+ORC_API void orc_flow_hist(const float* flow, int h, int w, int32_t* out /* 2 x 64 */) {
+  const int bins = 64;
+  const double a_mag = bins / (64.0 - 0.0), b_mag = -a_mag * 0.0;
+  const double a_deg = bins / (360.0 - 0.0), b_deg = -a_deg * 0.0;
+  memset(out, 0, sizeof(int32_t) * 2 * bins);
+  size_t npx = (size_t)h * w;
+  for (size_t i = 0; i < npx; ++i) {
+    float x = flow[2 * i], y = flow[2 * i + 1];
+    float mag = sqrtf(x * x + y * y);
+    float deg = orc_fast_atan2_deg(y, x) * 1.f;
+    int im = orc_cv_floor((double)mag * a_mag + b_mag);
+    int id = orc_cv_floor((double)deg * a_deg + b_deg);
+    if ((unsigned)im < (unsigned)bins) out[im]++;
+    if ((unsigned)id < (unsigned)bins) out[bins + id]++;
+  }
+}
+
+/* DrawFlow -- /root/reference/scannertools/scannertools/vis.py:8-12 (numpy, float32):
+ *   v = (fx + fy) / 2; m = max(v) over the frame (NaN propagates); out = hstack(frame,
+ *   uint8(min(v / m, 1) * 255) replicated to 3 channels).  The float32 -> uint8 cast is numpy's C
+ *   cast: truncate toward zero to int32 (NaN / out of range -> INT32_MIN), keep the low byte.
+ * Pinned by tests/golden/draw_flow_golden.npz (produced by importing vis.py). */
+ORC_API void orc_draw_flow(const uint8_t* frame, const float* flow, int h, int w, uint8_t* out /* h x 2w x 3 */) {
+  size_t npx = (size_t)h * w;
+  float m = -INFINITY;
+  int nan = 0;
+  for (size_t i = 0; i < npx; ++i) {
+    float v = (flow[2 * i] + flow[2 * i + 1]) / 2.f;
+    if (v != v) nan = 1;
+    if (v > m) m = v;
+  }
+  if (nan) m = NAN;
+  for (int y = 0; y < h; ++y) {
+    uint8_t* o = out + (size_t)y * 2 * w * 3;
+    memcpy(o, frame + (size_t)y * w * 3, (size_t)w * 3);
+    for (int x = 0; x < w; ++x) {
+      size_t i = (size_t)y * w + x;
+      float v = (flow[2 * i] + flow[2 * i + 1]) / 2.f;
+      float q = v / m;
+      if (q > 1.0f) q = 1.0f;  /* np.clip(., None, 1): NaN stays NaN */
+      q = q * 255.f;
+      int32_t t = (q > -2147483904.f && q < 2147483648.f) ? (int32_t)q : INT32_MIN;
+      uint8_t b = (uint8_t)(t & 0xff);
+      o[(w + x) * 3 + 0] = b; o[(w + x) * 3 + 1] = b; o[(w + x) * 3 + 2] = b;
+    }
+  }
+}

@@ -12,9 +12,9 @@ installable here, so this module reproduces exactly that surface for in-memory f
     out = NamedStream(sc, 'hist'); sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
     next(out.load())
 
-C++ ops (``Histogram``, ``OpticalFlow``) are looked up in the kernel registry of
+C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``) are looked up in the kernel registry of
 ``libscannertools_imgproc.so`` and executed by its mini engine (scanner_shim/shim.cpp): the same
-``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``) are the
+``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``, ``DrawFlow``) are the
 functions of this package.  What is deliberately absent: the database, video decode, the
 master/worker runtime, scheduling.
 """
@@ -264,6 +264,24 @@ class _PyOpNode(_Node):
         return [res[i] for i in idx]
 
 
+class _PyMapNode(_Node):
+    """A per-row python op over several input columns of equal length (DrawFlow)."""
+
+    def __init__(self, fn, parents):
+        self.fn, self.parents = fn, parents
+
+    def length(self):
+        n = {p.length() for p in self.parents}
+        if len(n) != 1:
+            raise RuntimeError("python op inputs have different lengths: %s" % sorted(n))
+        return n.pop()
+
+    def rows(self, idx):
+        if not idx:
+            return []
+        return self.fn(*[p.rows(idx) for p in self.parents])
+
+
 class _OutputNode:
     def __init__(self, node, streams):
         self.node, self.streams = node, streams
@@ -356,6 +374,19 @@ class _Ops:
     def OpticalFlow(self, frame, stencil=None, device=None, batch=None):
         """sc.ops.OpticalFlow(frame=..., stencil=[-1,0], device=...) (tests/test_all.py:166)."""
         return _CppOpNode(self.sc, "OpticalFlow", frame, device, batch, stencil, b"")
+
+    def FlowHistogram(self, flow, device=None, batch=None):
+        """db.ops.FlowHistogram(flow=flow, device=DeviceType.CPU) (old/histograms.py:74-77)."""
+        node = _CppOpNode(self.sc, "FlowHistogram", flow, device, batch, None, b"")
+        node.reader = _types.flow_histograms
+        return node
+
+    def DrawFlow(self, frame, flow):
+        """sc.ops.DrawFlow(frame=frame, flow=flow): the python op of scannertools/vis.py:8-12,
+        computed on the GPU (scannertools_amd.vis.draw_flow_rows)."""
+        from . import vis as _vis
+        dev = self.sc.device_id
+        return _PyMapNode(lambda frames, flows: _vis.draw_flow_rows(frames, flows, device=dev), [frame, flow])
 
     def ShotBoundaries(self, histograms):
         """sc.ops.ShotBoundaries(histograms=hist) (tests/test_all.py:227)."""

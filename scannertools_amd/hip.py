@@ -125,6 +125,65 @@ class HipContext:
                                                  bins, ctypes.c_void_p(out.data_ptr())))
         return out
 
+    # -- flow consumers ---------------------------------------------------------------------
+    def flow_histogram(self, flows, out=None):
+        """FlowHistogram (old/cpp_ops/flow_histogram_kernel_cpu.cpp:26-57): magnitude and angle
+        histograms (64 bins on [0,64) px and [0,360) degrees) of flow frames.
+
+        flows: CUDA float32 tensor (n,h,w,2) or a list of (h,w,2) tensors.  Returns int32
+        (n,2,64): row i is the 512-byte element the reference op emits."""
+        self._bind()
+        if isinstance(flows, (list, tuple)):
+            n = len(flows)
+            if n == 0:
+                return torch.zeros((0, 2, 64), dtype=torch.int32, device=self.device)
+            for f in flows:
+                _require_cuda(f, torch.float32, "flow")
+            h, w, _ = flows[0].shape
+            if any(tuple(f.shape) != (h, w, 2) for f in flows):
+                raise ValueError("all flows must be (h,w,2) with equal shape")
+            if out is None:
+                out = torch.empty((n, 2, 64), dtype=torch.int32, device=self.device)
+            table = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flows])
+            self._check(self._L.st_flow_hist_batch(self._h, table, n, h, w, ctypes.c_void_p(out.data_ptr())))
+            return out
+        _require_cuda(flows, torch.float32, "flows")
+        if flows.dim() != 4 or flows.shape[3] != 2:
+            raise ValueError("flows must be (n,h,w,2)")
+        n, h, w, _ = flows.shape
+        if out is None:
+            out = torch.empty((n, 2, 64), dtype=torch.int32, device=self.device)
+        if n == 0:
+            return out
+        self._check(self._L.st_flow_hist_strided(self._h, ctypes.c_void_p(flows.data_ptr()), 8 * h * w, n, h, w,
+                                                 ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def draw_flow(self, frames, flows, out=None):
+        """DrawFlow (scannertools/vis.py:8-12): frames (n,h,w,3) uint8 and flows (n,h,w,2) float32
+        (tensors or lists of per-row tensors) -> (n,h,2w,3) uint8, the frame beside its flow map."""
+        self._bind()
+        fr = list(frames) if isinstance(frames, (list, tuple)) else list(frames.unbind(0))
+        fl = list(flows) if isinstance(flows, (list, tuple)) else list(flows.unbind(0))
+        n = len(fr)
+        if len(fl) != n:
+            raise ValueError("frames and flows must have the same number of rows")
+        if n == 0:
+            return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
+        h, w, _ = fr[0].shape
+        for f, g in zip(fr, fl):
+            _require_cuda(f, torch.uint8, "frame")
+            _require_cuda(g, torch.float32, "flow")
+            if tuple(f.shape) != (h, w, 3) or tuple(g.shape) != (h, w, 2):
+                raise ValueError("frames must be (h,w,3) and flows (h,w,2) with equal h,w")
+        if out is None:
+            out = torch.empty((n, h, 2 * w, 3), dtype=torch.uint8, device=self.device)
+        tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        tg = (ctypes.c_void_p * n)(*[g.data_ptr() for g in fl])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_draw_flow_batch(self._h, tf, tg, n, h, w, to))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.

@@ -18,3 +18,11 @@ def flow(buf, height, width):
     if buf is None:
         return None
     return np.frombuffer(buf, dtype=np.dtype(np.float32)).reshape((height, width, 2))
+
+
+def flow_histograms(buf, protobufs=None):
+    """One FlowHistogram element: 2 x int32[64], magnitude then angle
+    (``flow_hist_reader``, scannertools/old/histograms.py:43-46)."""
+    if buf is None:
+        return None
+    return np.split(np.frombuffer(buf, dtype=np.dtype(np.int32)), 2)

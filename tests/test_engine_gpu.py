@@ -97,6 +97,41 @@ class TestOpticalFlowDefaultStencilBatched(DeviceTestBench):
             assert np.abs(fl - ref).max() <= 5e-3
 
 
+class TestFlowHistogramPipeline(DeviceTestBench):
+    """The legacy flow-histogram graph (old/histograms.py:63-78): OpticalFlow -> FlowHistogram."""
+
+    def run(self, sc, device):
+        frame = sc.io.Input([NamedVideoStream(sc, 'test1')])
+        flow = sc.ops.OpticalFlow(frame=frame, device=device, batch=8)
+        fh = sc.ops.FlowHistogram(flow=flow, device=device, batch=5)
+        ranged = sc.streams.Range(fh, ranges=[{'start': 0, 'end': 12}])
+        out_h, out_f = NamedStream(sc, 'test_flow_hist'), NamedStream(sc, 'test_flow_hist_src')
+        sc.run([sc.io.Output(ranged, [out_h]), sc.io.Output(sc.streams.Range(flow, ranges=[{'start': 0, 'end': 12}]), [out_f])],
+               PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        assert out_h.len() == 12
+        first = next(out_h.load())
+        assert len(first) == 2 and all(c.dtype == np.int32 and c.shape == (64,) for c in first)
+        for h, fl in zip(out_h.load(), out_f.load()):
+            np.testing.assert_array_equal(np.stack(h), oracle.flow_hist(fl))
+            assert np.stack(h)[1].sum() == 120 * 160
+
+
+def test_draw_flow_op(sc):
+    """sc.ops.DrawFlow (vis.py:8-12) on the output of OpticalFlow."""
+    frame = sc.io.Input([NamedVideoStream(sc, 'test1')])
+    flow = sc.ops.OpticalFlow(frame=frame, stencil=[-1, 0], device=DeviceType.GPU, batch=8)
+    vis = sc.ops.DrawFlow(frame=frame, flow=flow)
+    out_v, out_f = NamedStream(sc, 'test_draw'), NamedStream(sc, 'test_draw_src')
+    pick = [[0, 1, 7, 30]]
+    sc.run([sc.io.Output(sc.streams.Gather(vis, pick), [out_v]), sc.io.Output(sc.streams.Gather(flow, pick), [out_f])],
+           PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    frames = sc._videos['test1']
+    assert out_v.len() == 4
+    for r, pic, fl in zip(pick[0], out_v.load(), out_f.load()):
+        assert pic.dtype == np.uint8 and pic.shape == (120, 320, 3)
+        np.testing.assert_array_equal(pic, oracle.draw_flow(frames[r], fl))
+
+
 def test_shot_detection(sc):
     """tests/test_all.py:222-233 with a stream whose cuts are planted, so the count is known."""
     rng = np.random.default_rng(0)

@@ -159,12 +159,14 @@ def test_imgproc_library_registrations():
     from scannertools_amd import engine
     regs = engine.registered_kernels()
     ops = {(name, dev) for name, dev, _, _ in regs}
-    assert {("Histogram", 0), ("Histogram", 1), ("OpticalFlow", 0), ("OpticalFlow", 1)} <= ops
+    assert {("Histogram", 0), ("Histogram", 1), ("OpticalFlow", 0), ("OpticalFlow", 1),
+            ("FlowHistogram", 0), ("FlowHistogram", 1)} <= ops
     for name, dev, kind, can_batch in regs:
         assert can_batch                                           # .batch() as in histogram_kernel_cpu.cpp:54-57
-        assert kind == (1 if name == "Histogram" else 3)           # Batched / StenciledBatched
+        assert kind == (3 if name == "OpticalFlow" else 1)         # StenciledBatched / Batched
     assert engine.op_info("OpticalFlow")["stencil"] == [0, 1]      # optical_flow_kernel_cpu.cpp:51-54
     assert engine.op_info("OpticalFlow")["frame_output"] and not engine.op_info("Histogram")["frame_output"]
+    assert not engine.op_info("FlowHistogram")["frame_output"]     # flow_histogram_kernel_cpu.cpp:62
     assert engine.op_info("NoSuchOp") is None
 
 

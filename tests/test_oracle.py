@@ -131,3 +131,40 @@ def test_oracle_under_address_and_ub_sanitizers():
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "oracle sanitizer run ok" in out.stdout
+
+
+# ---- flow consumers ----------------------------------------------------------------------------
+
+def test_draw_flow_oracle_matches_reference_golden():
+    """oracle.draw_flow vs outputs of the reference's vis.py (tests/golden/make_draw_flow_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "draw_flow_golden.npz"))
+    names = sorted(k[:-4] for k in g.files if k.endswith("_out"))
+    assert {"mixed", "zeros", "with_nan", "negative_max", "ragged_7x13"} <= set(names)
+    for name in names:
+        got = oracle.draw_flow(g[name + "_frame"], g[name + "_flow"])
+        np.testing.assert_array_equal(got, g[name + "_out"], err_msg=name)
+
+
+def test_flow_hist_oracle_known_answers():
+    """cartToPolar/calcHist restatement: exact axis angles, cv::fastAtan2's documented 45-degree
+    value, range edges."""
+    fl = np.zeros((1, 8, 2), np.float32)
+    fl[0, 0] = (1, 0); fl[0, 1] = (0, 1); fl[0, 2] = (-1, 0); fl[0, 3] = (0, -1)
+    fl[0, 4] = (3, 4); fl[0, 5] = (1, 1); fl[0, 6] = (64, 0); fl[0, 7] = (0, 0)
+    mag, deg = oracle.cart_to_polar_deg(fl)
+    np.testing.assert_array_equal(mag[0], np.float32([1, 1, 1, 1, 5, np.sqrt(np.float32(2)), 64, 0]))
+    np.testing.assert_array_equal(deg[0, :4], np.float32([0, 90, 180, 270]))
+    assert abs(deg[0, 5] - 44.990456) < 1e-5            # cv::fastAtan2(1, 1)
+    assert abs(deg[0, 4] - np.degrees(np.arctan2(4, 3))) < 0.3 and deg[0, 7] == 0
+    h = oracle.flow_hist(fl)
+    assert h.shape == (2, 64) and h.dtype == np.int32
+    assert h[0].sum() == 7 and h[0, 1] == 5 and h[0, 5] == 1 and h[0, 0] == 1   # mag 64 dropped
+    assert h[1].sum() == 8 and h[1, 0] == 3 and h[1, 16] == 1 and h[1, 32] == 1 and h[1, 48] == 1
+    # histogram == bincount of floor() of the polar images
+    rng = np.random.default_rng(0)
+    f = (rng.standard_normal((40, 50, 2)) * 20).astype(np.float32)
+    mag, deg = oracle.cart_to_polar_deg(f)
+    hm = np.bincount(np.floor(mag[mag < 64].astype(np.float64)).astype(int), minlength=64)
+    dd = deg.astype(np.float64) * (64 / 360.0)
+    hd = np.bincount(np.floor(dd[dd < 64]).astype(int), minlength=64)
+    np.testing.assert_array_equal(oracle.flow_hist(f), np.stack([hm, hd]))
