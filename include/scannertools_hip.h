@@ -140,13 +140,16 @@ int st_fb_level_geom(int h, int w, const st_fb_params* params, int level, int* l
                      double* sigma, int* ksize);
 
 /* ---- stage-level entry points (parity tests drive each Farneback stage separately) ---------
- * All arrays are dense device arrays.  Planar fields are (5, h, w) F32 (channel c at
- * base + c*h*w); flow fields are (h, w, 2) F32 interleaved. */
+ * All arrays are dense device arrays.  M fields are planar (5, h, w) F32 (channel c at
+ * base + c*h*w); flow fields are (h, w, 2) F32 interleaved.  Polynomial expansions R (r_dev,
+ * r0_dev, r1_dev; 5*h*w floats, 16-byte aligned) use the layout the production kernels read:
+ * channels 0..3 of OpenCV's interleaved 5-channel R as h*w float4, then channel 4 as h*w
+ * floats. */
 int st_gray_u8(st_ctx* ctx, const uint8_t* rgb_dev, int h, int w, int gray_bits, uint8_t* gray_dev);
 int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w, const st_fb_params* params,
                     int level, float* img_dev /* (lh, lw) */);
 int st_fb_polyexp(st_ctx* ctx, const float* img_dev, int h, int w, int poly_n, double poly_sigma,
-                  float* r_dev /* (5,h,w) */);
+                  float* r_dev /* R layout, 5*h*w floats */);
 /* M = UpdateMatrices(R0, R1, flow).  If coarse_flow_dev != NULL the flow is first produced as
  * resize(coarse_flow (ch, cw, 2) -> (h, w), INTER_LINEAR) * (1/pyr_scale) (the level
  * transition of calc()); else flow_dev (h, w, 2) is used; if both are NULL the flow is zero. */

@@ -16,8 +16,9 @@
 //
 // Data layout in HBM (dense, per frame or per pair):
 //   gray  u8 (h,w)            I_k  f32 (lh,lw)
-//   R_k   f32 planar (5,lh,lw): [d/dy, d/dx, yy, xx, xy] -- SoA so that every row access is a
-//         unit-stride 4-B-per-lane stream and the bilinear gather of R1 stays coalesced
+//   R_k   f32, per frame lh*lw float4 [d/dy, d/dx, yy, xx] then lh*lw float [xy]: one 16-B and one
+//         4-B load per pixel, coalesced across a wave (also for the bilinear gather of R1 when
+//         the flow is smooth); see the note above update_matrices_px
 //   M     f32 planar (5,lh,lw): [G11, G12, G22, h1, h2] (two buffers, ping-pong per iteration)
 //   flow  f32 (lh,lw,2) interleaved (u,v): the op's output format
 #include <cmath>
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256) void k_pyr_dec(PyrDecArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct PolyArgs {
   const float* img;  // n x (h*w)
-  float* R;          // n x 5 x (h*w)
+  float* R;          // n x (h*w float4 + h*w float), see "R layout" above update_matrices_px
   int h, w, rows_per_seg;
   PolyCoef c;
 };
@@ -597,11 +598,11 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
             b5 += (p2 + m2) * g0;
           }
           const int o = (y + r) * w + x;
-          R[o] = (float)(b3 * a.c.ig11);
-          R[np + o] = (float)(b2 * a.c.ig11);
-          R[2 * np + o] = (float)(b1 * a.c.ig03 + b5 * a.c.ig33);
-          R[3 * np + o] = (float)(b1 * a.c.ig03 + b4 * a.c.ig33);
-          R[4 * np + o] = (float)(b6 * a.c.ig55);
+          // R layout: channels 0..3 as one float4 per pixel, channel 4 as a plane behind them
+          reinterpret_cast<float4*>(R)[o] = make_float4((float)(b3 * a.c.ig11), (float)(b2 * a.c.ig11),
+                                                        (float)(b1 * a.c.ig03 + b5 * a.c.ig33),
+                                                        (float)(b1 * a.c.ig03 + b4 * a.c.ig33));
+          R[4 * (size_t)np + o] = (float)(b6 * a.c.ig55);
         }
       }
     }
@@ -610,7 +611,13 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// A5: FarnebackUpdateMatrices for one pixel.  R0/R1 planar with plane stride np.
+// A5: FarnebackUpdateMatrices for one pixel.
+// R layout (one expansion of np = h*w pixels, 20*np bytes): channels 0..3 of OpenCV's interleaved
+// 5-channel R as np float4 (16-byte aligned, one wide load per pixel), channel 4 as np floats
+// behind them.  Vector-memory instructions issue at ~1 per 20 clocks per CU whatever their width
+// (scripts/ubench/vmemrate.hip), and this kernel family is bound by that rate: the 4+1 split
+// needs 2 loads for an R0 pixel and 6 for the bilinear 2x2 footprint of R1 instead of the 5 and
+// 10 of a five-plane layout, at the same 20 bytes per pixel.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0, const float* __restrict__ R1,
                                                    int np, int h, int w, int x, int y, float dx, float dy,
@@ -620,15 +627,19 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
   const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
   float r2, r3, r4, r5, r6;
   fx -= x1; fy -= y1;
-  const float q0 = R0[o], q1 = R0[np + o], q2 = R0[2 * np + o], q3 = R0[3 * np + o], q4 = R0[4 * np + o];
+  const float4 q = reinterpret_cast<const float4*>(R0)[o];
+  const float q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w, q4 = R0[4 * (size_t)np + o];
   if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     const int gi = y1 * w + x1;
-    r2 = a00 * R1[gi] + a01 * R1[gi + 1] + a10 * R1[gi + w] + a11 * R1[gi + w + 1];
-    r3 = a00 * R1[np + gi] + a01 * R1[np + gi + 1] + a10 * R1[np + gi + w] + a11 * R1[np + gi + w + 1];
-    r4 = a00 * R1[2 * np + gi] + a01 * R1[2 * np + gi + 1] + a10 * R1[2 * np + gi + w] + a11 * R1[2 * np + gi + w + 1];
-    r5 = a00 * R1[3 * np + gi] + a01 * R1[3 * np + gi + 1] + a10 * R1[3 * np + gi + w] + a11 * R1[3 * np + gi + w + 1];
-    r6 = a00 * R1[4 * np + gi] + a01 * R1[4 * np + gi + 1] + a10 * R1[4 * np + gi + w] + a11 * R1[4 * np + gi + w + 1];
+    const float4* __restrict__ Q = reinterpret_cast<const float4*>(R1);
+    const float* __restrict__ S = R1 + 4 * (size_t)np;
+    const float4 t0 = Q[gi], t1 = Q[gi + 1], b0 = Q[gi + w], b1 = Q[gi + w + 1];
+    r2 = a00 * t0.x + a01 * t1.x + a10 * b0.x + a11 * b1.x;
+    r3 = a00 * t0.y + a01 * t1.y + a10 * b0.y + a11 * b1.y;
+    r4 = a00 * t0.z + a01 * t1.z + a10 * b0.z + a11 * b1.z;
+    r5 = a00 * t0.w + a01 * t1.w + a10 * b0.w + a11 * b1.w;
+    r6 = a00 * S[gi] + a01 * S[gi + 1] + a10 * S[gi + w] + a11 * S[gi + w + 1];
     r4 = (q2 + r4) * 0.5f;
     r5 = (q3 + r5) * 0.5f;
     r6 = (q4 + r6) * 0.25f;
@@ -660,24 +671,29 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
 
 // UpdateMatrices split in two so that a thread can put the loads of several rows in flight
 // before consuming any (memory-level parallelism): um_issue computes the gather address and
-// issues the 5 R0 loads and the 10 8-byte R1 loads (two horizontally adjacent floats each);
-// um_finish does the arithmetic, bit-identical to update_matrices_px.
+// issues the 2 R0 loads (float4 + float) and the 6 R1 loads (four float4 + two 8-byte pairs of
+// channel 4); um_finish does the arithmetic, bit-identical to update_matrices_px.
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct UmLoads {
-  float q[5];
-  f2u t[5], b[5];  // (R1[gi], R1[gi+1]) and (R1[gi+w], R1[gi+w+1]) per channel
+  float4 q;            // R0 channels 0..3
+  float qs;            // R0 channel 4
+  float4 t0, t1, b0, b1;  // R1 channels 0..3 at (gi, gi+1, gi+w, gi+w+1)
+  f2u ts, bs;          // R1 channel 4 at (gi, gi+1) and (gi+w, gi+w+1)
   float fx, fy;
   bool inb;
 };
 
-// Loads address the planes as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
+// Loads address an expansion as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
 // compiler can use the SGPR-base addressing form (one VGPR per address, no 64-bit VALU math).
 __device__ __forceinline__ float ldf(const float* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 __device__ __forceinline__ f2u ldf2(const float* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const float* __restrict__ R1, int np, int h,
@@ -687,18 +703,18 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   fx -= x1; fy -= y1;
   L.fx = fx; L.fy = fy;
   L.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-  int gi = L.inb ? y1 * w + x1 : 0;  // out of range: harmless in-plane address, result unused
-  const int wo = L.inb ? w : 0;
-  const int o = y * w + x;
-  const unsigned plane = 4u * (unsigned)np;
-  unsigned bo = 4u * (unsigned)o, bt = 4u * (unsigned)gi, bb = 4u * (unsigned)(gi + wo);
-#pragma unroll
-  for (int c = 0; c < 5; ++c) {
-    L.q[c] = ldf(R0, bo);
-    L.t[c] = ldf2(R1, bt);
-    L.b[c] = ldf2(R1, bb);
-    bo += plane; bt += plane; bb += plane;
-  }
+  const unsigned gi = L.inb ? (unsigned)(y1 * w + x1) : 0u;  // out of range: harmless address, result unused
+  const unsigned gb = gi + (L.inb ? (unsigned)w : 0u);
+  const unsigned o = (unsigned)(y * w + x);
+  const unsigned single = 16u * (unsigned)np;  // byte offset of the channel-4 plane
+  L.q = ldf4(R0, 16u * o);
+  L.qs = ldf(R0, single + 4u * o);
+  L.t0 = ldf4(R1, 16u * gi);
+  L.t1 = ldf4(R1, 16u * gi + 16u);
+  L.b0 = ldf4(R1, 16u * gb);
+  L.b1 = ldf4(R1, 16u * gb + 16u);
+  L.ts = ldf2(R1, single + 4u * gi);
+  L.bs = ldf2(R1, single + 4u * gb);
 }
 
 __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x, int y, float2 f, float m[5]) {
@@ -706,22 +722,22 @@ __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x,
   float r2, r3, r4, r5, r6;
   if (L.inb) {
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    r2 = a00 * L.t[0].x + a01 * L.t[0].y + a10 * L.b[0].x + a11 * L.b[0].y;
-    r3 = a00 * L.t[1].x + a01 * L.t[1].y + a10 * L.b[1].x + a11 * L.b[1].y;
-    r4 = a00 * L.t[2].x + a01 * L.t[2].y + a10 * L.b[2].x + a11 * L.b[2].y;
-    r5 = a00 * L.t[3].x + a01 * L.t[3].y + a10 * L.b[3].x + a11 * L.b[3].y;
-    r6 = a00 * L.t[4].x + a01 * L.t[4].y + a10 * L.b[4].x + a11 * L.b[4].y;
-    r4 = (L.q[2] + r4) * 0.5f;
-    r5 = (L.q[3] + r5) * 0.5f;
-    r6 = (L.q[4] + r6) * 0.25f;
+    r2 = a00 * L.t0.x + a01 * L.t1.x + a10 * L.b0.x + a11 * L.b1.x;
+    r3 = a00 * L.t0.y + a01 * L.t1.y + a10 * L.b0.y + a11 * L.b1.y;
+    r4 = a00 * L.t0.z + a01 * L.t1.z + a10 * L.b0.z + a11 * L.b1.z;
+    r5 = a00 * L.t0.w + a01 * L.t1.w + a10 * L.b0.w + a11 * L.b1.w;
+    r6 = a00 * L.ts.x + a01 * L.ts.y + a10 * L.bs.x + a11 * L.bs.y;
+    r4 = (L.q.z + r4) * 0.5f;
+    r5 = (L.q.w + r5) * 0.5f;
+    r6 = (L.qs + r6) * 0.25f;
   } else {
     r2 = r3 = 0.f;
-    r4 = L.q[2];
-    r5 = L.q[3];
-    r6 = L.q[4] * 0.5f;
+    r4 = L.q.z;
+    r5 = L.q.w;
+    r6 = L.qs * 0.5f;
   }
-  r2 = (L.q[0] - r2) * 0.5f;
-  r3 = (L.q[1] - r3) * 0.5f;
+  r2 = (L.q.x - r2) * 0.5f;
+  r3 = (L.q.y - r3) * 0.5f;
   r2 += r4 * dy + r6 * dx;
   r3 += r6 * dy + r5 * dx;
   constexpr int BORDER = 5;
@@ -741,7 +757,7 @@ __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x,
 // Initial matrices of a level; the flow is zero (coarsest level), a given field, or the
 // previous level's flow resized with INTER_LINEAR and multiplied by 1/pyr_scale.
 struct UMArgs {
-  const float* R;            // frame-indexed planar expansions of this level: frame f at R + f*5*np
+  const float* R;            // frame-indexed expansions of this level (R layout): frame f at R + f*5*np
   const int* pairs;          // device (n_pairs x 2) frame slots, or null => R0 = R, R1 = R1_direct
   const float* R1_direct;
   const float* flow;         // (h,w,2) per pair or null
@@ -1129,7 +1145,7 @@ __global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
 // The values of M are bit-identical to the materialised ones, so results do not change.
 // ---------------------------------------------------------------------------------------------
 struct IterArgs {
-  const float* R;           // frame-indexed planar expansions of this level, or direct R0
+  const float* R;           // frame-indexed expansions of this level (R layout), or direct R0
   const int* pairs;         // device (n_pairs x 2) frame slots, or null => R0 = R, R1 = R1_direct
   const float* R1_direct;
   const float* flow_in;     // per pair (h,w,2) or null
@@ -1384,281 +1400,6 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_flow_iter_t: the same iteration with the R0 rows and an R1 tile brought into LDS by wide
-// LDS-DMA loads (global_load_lds, 16 B per lane = one 256-column row segment per wave
-// instruction) instead of 15 narrow per-lane loads per pixel.  Measured on k_flow_iter: the
-// vector-memory *instruction* pipeline, not HBM, was the limiter (load issue = 57 % of a
-// batch).  Per batch a workgroup now issues ~19 memory instructions per wave instead of 48.
-//   R0T  [RB][5][256]      the entering rows of R0 for the strip
-//   R1T  [T_TR][5][T_TC]   rows tyA.. / columns txA.. of R1, where (txA,tyA) is the minimum of
-//                          the gather origins of the batch (reduced over the workgroup one batch
-//                          ahead from the prefetched flows); lanes whose 2x2 footprint falls
-//                          outside the tile (large flow spread) take per-lane global loads.
-// Requires w % 4 == 0 (16-byte aligned row segments); other widths use k_flow_iter.
-// ---------------------------------------------------------------------------------------------
-constexpr int T_TR = 6, T_TC = 288;
-
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int M, int RB, int MODE>
-__global__ __launch_bounds__(B2_T, 2) void k_flow_iter_t(IterArgs a) {
-  constexpr int W = 2 * M + 1;
-  constexpr int NSEG = B2_OUT / RB;
-  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % RB == 0 && RB * NSEG <= B2_T, "bad batch geometry");
-  // one LDS object (a second one makes hipcc drain vmcnt before unrelated ds_reads)
-  constexpr int OFF_V = 0, OFF_F = OFF_V + RB * 5 * B2_T, OFF_R0 = OFF_F + RB * B2_T * 2,
-                OFF_R1 = OFF_R0 + RB * 5 * B2_T, OFF_RED = OFF_R1 + T_TR * 5 * T_TC, SMEM = OFF_RED + 4;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
-  float(*V)[5][B2_T] = reinterpret_cast<float(*)[5][B2_T]>(smem + OFF_V);
-  float2(*F)[B2_T] = reinterpret_cast<float2(*)[B2_T]>(smem + OFF_F);
-  float(*R0T)[5][B2_T] = reinterpret_cast<float(*)[5][B2_T]>(smem + OFF_R0);
-  float(*R1T)[5][T_TC] = reinterpret_cast<float(*)[5][T_TC]>(smem + OFF_R1);
-  int* red = reinterpret_cast<int*>(smem + OFF_RED);
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int h = a.h, w = a.w;
-  const int np = h * w;
-  const int pr = blockIdx.z;
-  const int sx0 = (int)blockIdx.x * B2_OUT - B2_HALO;
-  const int x = sx0 + tid;
-  const int xc = d_clamp(x, 0, w - 1);
-  const int lxc = xc - sx0;  // this thread's (clamped) column inside the strip tiles
-  const int y0 = blockIdx.y * a.rows_per_seg;
-  const int y1 = min(h, y0 + a.rows_per_seg);
-  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
-
-  const float* __restrict__ R0;
-  const float* __restrict__ R1;
-  if (a.pairs) {
-    R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
-    R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
-  } else {
-    R0 = a.R;
-    R1 = a.R1_direct;
-  }
-  const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
-  const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
-  float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
-  const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
-
-  // ---- ring / column-sum initialisation (per-lane loads; once per segment) ----
-  float ring[W][5];
-#pragma unroll
-  for (int s0 = 0; s0 < W; s0 += 3) {
-    UmLoads Li[3];
-    float2 f[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int yy = d_clamp(y0 - M + s0 + i, 0, h - 1);
-      f[i] = iter_flow_at<MODE>(a, fin, C, cx, xc, yy);
-      um_issue(R0, R1, np, h, w, xc, yy, f[i], Li[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) um_finish(Li[i], h, w, xc, d_clamp(y0 - M + s0 + i, 0, h - 1), f[i], ring[s0 + i]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  double vs[5];
-  if (y0 == 0) {
-#pragma unroll
-    for (int c = 0; c < 5; ++c) vs[c] = (double)(ring[M][c] * (float)(M + 2));
-#pragma unroll
-    for (int yy = 1; yy < M; ++yy)
-#pragma unroll
-      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[M + yy][c];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const float d = ring[2 * M][c] - ring[M][c];
-      vs[c] += d;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 5; ++c) vs[c] = 0;
-#pragma unroll
-    for (int s = 0; s < W; ++s)
-#pragma unroll
-      for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
-  }
-
-  // gather origin of one (column, row, flow): returns false when the bilinear footprint leaves the image
-  auto origin = [&](int yy, float2 f, int& x1, int& y1i) -> bool {
-    const float gx = xc + f.x, gy = yy + f.y;
-    x1 = (int)floorf(gx); y1i = (int)floorf(gy);
-    return (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1i < (unsigned)(h - 1);
-  };
-  // workgroup minimum of the gather origins of a batch -> red[0..1]
-  auto reduce_origin = [&](const float2* fb, int ybase) {
-    int mx = 0x7fffffff, my = 0x7fffffff;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      int x1, y1i;
-      if (origin(d_clamp(ybase + r + M + 1, 0, h - 1), fb[r], x1, y1i)) { mx = min(mx, x1); my = min(my, y1i); }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o)); my = min(my, __shfl_xor(my, o)); }
-    if (lane == 0) { atomicMin(&red[0], mx); atomicMin(&red[1], my); }
-  };
-  // DMA of the R0 rows and the R1 tile of the batch whose first entering row is ybase + M + 1
-  auto issue_tiles = [&](int ybase, int txA, int tyA) {
-    for (int p = wv; p < RB * 5; p += 4) {
-      const int r = p / 5, c = p - r * 5;
-      const int row = d_clamp(ybase + r + M + 1, 0, h - 1);
-      const int col = sx0 + 4 * lane;
-      if (col >= 0 && col < w) glds16(R0 + c * np + row * w + col, &R0T[r][c][0]);
-    }
-    if (txA != 0x7fffffff) {
-      for (int p = wv; p < T_TR * 5; p += 4) {
-        const int rr = p / 5, c = p - rr * 5;
-        const int row = tyA + rr;
-        if (row < h) {
-          const float* g = R1 + c * np + row * w + txA;
-          if (txA + 4 * lane < w) glds16(g + 4 * lane, &R1T[rr][c][0]);
-          if (lane < (T_TC - 256) / 4 && txA + 256 + 4 * lane < w) glds16(g + 256 + 4 * lane, &R1T[rr][c][256]);
-        }
-      }
-    }
-  };
-
-  float2 fl[RB], fn[RB];
-#pragma unroll
-  for (int r = 0; r < RB; ++r) fl[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
-  if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
-  __syncthreads();
-  reduce_origin(fl, y0);
-  __syncthreads();
-  int txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3), tyA = red[1];
-  issue_tiles(y0, txA, tyA);
-#pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
-
-#ifdef ST_PROF
-  int pslot = 0;
-  const bool pon = a.prof && tid == 64 && blockIdx.x == 3 && blockIdx.y == 1 && (blockIdx.z == 0 || blockIdx.z == 20);
-  long long* pbuf = a.prof + (blockIdx.z == 0 ? 0 : 4096);
-#endif
-#pragma unroll 1
-  for (int ybb = y0; ybb < y1; ybb += RB) {
-    {
-      {
-        PSTAMP();
-        __syncthreads();  // (A) tiles of this batch have landed (vmcnt drained by the barrier); red consumed
-        PSTAMP();
-        if (tid == 0) { red[0] = 0x7fffffff; red[1] = 0x7fffffff; }
-        // ---- phase 1: UpdateMatrices of the entering rows from the LDS tiles, slide the column sums ----
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const int yy = d_clamp(ybb + r + M + 1, 0, h - 1);
-          UmLoads L;
-          int x1, y1i;
-          L.inb = origin(yy, fl[r], x1, y1i);
-          {
-            const float gx = xc + fl[r].x, gy = yy + fl[r].y;
-            L.fx = gx - x1; L.fy = gy - y1i;
-          }
-#pragma unroll
-          for (int c = 0; c < 5; ++c) L.q[c] = R0T[r][c][lxc];
-          const int lx = x1 - txA, ly = y1i - tyA;
-          const bool intile = L.inb && lx >= 0 && lx + 1 < T_TC && ly >= 0 && ly + 1 < T_TR;
-          if (intile) {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-              L.t[c].x = R1T[ly][c][lx]; L.t[c].y = R1T[ly][c][lx + 1];
-              L.b[c].x = R1T[ly + 1][c][lx]; L.b[c].y = R1T[ly + 1][c][lx + 1];
-            }
-          } else if (L.inb) {
-            const int gi = y1i * w + x1;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-              L.t[c].x = R1[c * np + gi]; L.t[c].y = R1[c * np + gi + 1];
-              L.b[c].x = R1[c * np + gi + w]; L.b[c].y = R1[c * np + gi + w + 1];
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) { L.t[c].x = L.t[c].y = L.b[c].x = L.b[c].y = 0.f; }
-          }
-          float m[5];
-          um_finish(L, h, w, xc, yy, fl[r], m);
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            V[r][c][tid] = (float)vs[c];
-            const float d = m[c] - ring[r][c];
-            vs[c] += d;
-            ring[r][c] = m[c];
-          }
-        }
-        {
-          float tmp[RB][5];
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) tmp[r][c] = ring[r][c];
-#pragma unroll
-          for (int j = 0; j + RB < W; ++j)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) ring[j][c] = ring[j + RB][c];
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
-        }
-        PSTAMP();
-        __syncthreads();  // (A2) red reset visible before the new minima arrive
-        reduce_origin(fn, ybb + RB);
-        __syncthreads();  // (B) V visible, tiles free, red complete
-        PSTAMP();
-        txA = red[0] == 0x7fffffff ? 0x7fffffff : (red[0] & ~3);
-        tyA = red[1];
-        issue_tiles(ybb + RB, txA, tyA);
-#pragma unroll
-        for (int r = 0; r < RB; ++r) fl[r] = fn[r];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
-        PSTAMP();
-        // ---- phase 2: horizontal window + solve ----
-        if (tid < RB * NSEG) {
-          const int r = tid / NSEG, sg = tid - r * NSEG;
-          const int j0 = B2_HALO + sg * RB;
-          double t[5];
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            const float* vp = &V[r][c][j0 - M];
-            double acc = vp[0];
-#pragma unroll
-            for (int i = 1; i < W; ++i) acc += (double)vp[i];
-            t[c] = acc;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            if (i > 0) {
-#pragma unroll
-              for (int c = 0; c < 5; ++c) t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
-            }
-            const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
-            const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        PSTAMP();
-        __syncthreads();  // (C)
-        // ---- phase 3: coalesced flow store ----
-        if (writer) {
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            const int y = ybb + r;
-            if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
 int check_params(st_ctx* ctx, const st_fb_params& p, int h, int w) {
@@ -1843,17 +1584,9 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
   a.prof = (a.h >= 1000) ? prof_buf : nullptr;
 #endif
-  // ST_ITER_TILE=1 selects the experimental LDS-tiled variant (slower, kept for A/B runs)
-  static const bool tile = getenv("ST_ITER_TILE") && atoi(getenv("ST_ITER_TILE")) != 0;
-  if (tile && a.w % 4 == 0 && a.h >= 2) {
-    if (a.coarse) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_flow_iter_t<7, 3, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
-  } else {
-    if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
-  }
+  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
 #ifdef ST_PROF
   if (a.prof && getenv("ST_PROF_DUMP")) {

@@ -254,21 +254,22 @@ class HipContext:
         return out
 
     def polyexp(self, img, poly_n=5, poly_sigma=1.2):
-        """(h,w) f32 -> planar (5,h,w) f32."""
+        """(h,w) f32 -> R (h,w,5) f32, OpenCV's interleaved layout (unpacked from the device layout)."""
         self._bind()
         _require_cuda(img, torch.float32, "img")
         h, w = img.shape
-        out = torch.empty((5, h, w), dtype=torch.float32, device=self.device)
+        out = torch.empty(5 * h * w, dtype=torch.float32, device=self.device)
         self._check(self._L.st_fb_polyexp(self._h, ctypes.c_void_p(img.data_ptr()), h, w, poly_n, poly_sigma,
                                           ctypes.c_void_p(out.data_ptr())))
-        return out
+        return unpack_r(out, h, w)
 
     def update_matrices(self, r0, r1, flow=None, coarse_flow=None, pyr_scale=0.5):
-        """Planar (5,h,w) R0,R1 (+ flow (h,w,2) or coarse flow (ch,cw,2)) -> planar M (5,h,w)."""
+        """R0,R1 (h,w,5) (+ flow (h,w,2) or coarse flow (ch,cw,2)) -> planar M (5,h,w)."""
         self._bind()
         _require_cuda(r0, torch.float32, "r0")
         _require_cuda(r1, torch.float32, "r1")
-        _, h, w = r0.shape
+        h, w, _ = r0.shape
+        r0, r1 = pack_r(r0), pack_r(r1)
         out = torch.empty((5, h, w), dtype=torch.float32, device=self.device)
         fp = cp = None
         ch = cw = 0
@@ -284,10 +285,13 @@ class HipContext:
         return out
 
     def update_flow_blur(self, r0, r1, m, block_size=15, update=True):
-        """One FarnebackUpdateFlow_Blur pass.  Returns (flow (h,w,2), M' (5,h,w) or None)."""
+        """One FarnebackUpdateFlow_Blur pass over planar M (5,h,w) (R0, R1: (h,w,5), needed when
+        update=True).  Returns (flow (h,w,2), M' (5,h,w) or None)."""
         self._bind()
         _require_cuda(m, torch.float32, "m")
         _, h, w = m.shape
+        r0 = pack_r(r0) if r0 is not None else None
+        r1 = pack_r(r1) if r1 is not None else None
         flow = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
         mout = torch.empty_like(m) if update else None
         self._check(self._L.st_fb_update_flow_blur(
@@ -303,7 +307,8 @@ class HipContext:
         self._bind()
         _require_cuda(r0, torch.float32, "r0")
         _require_cuda(r1, torch.float32, "r1")
-        _, h, w = r0.shape
+        h, w, _ = r0.shape
+        r0, r1 = pack_r(r0), pack_r(r1)
         out = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
         fp = cp = None
         ch = cw = 0
@@ -318,6 +323,18 @@ class HipContext:
                                                  fp, cp, ch, cw, pyr_scale, h, w, block_size,
                                                  ctypes.c_void_p(out.data_ptr())))
         return out
+
+
+def pack_r(r):
+    """(h,w,5) polynomial expansion -> the device layout of the st_fb_* stage entry points:
+    h*w float4 (channels 0..3) followed by h*w floats (channel 4)."""
+    return torch.cat([r[..., :4].reshape(-1), r[..., 4].reshape(-1)]).contiguous()
+
+
+def unpack_r(flat, h, w):
+    """Inverse of :func:`pack_r`."""
+    n = h * w
+    return torch.cat([flat[:4 * n].view(h, w, 4), flat[4 * n:].view(h, w, 1)], dim=2).contiguous()
 
 
 def fb_levels(h, w, params=None):

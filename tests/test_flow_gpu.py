@@ -82,7 +82,7 @@ def test_pyramid_1080p_geometry_and_parity(hip_ctx):
 def test_polyexp_bit_exact(hip_ctx, h, w):
     I = (smooth_texture(h * w, h, w) * 1.0).astype(np.float32)
     got = hip_ctx.polyexp(cu(I)).cpu().numpy()
-    ref = planar5(oracle.polyexp(I))
+    ref = oracle.polyexp(I)
     np.testing.assert_array_equal(got, ref)
 
 
@@ -94,13 +94,13 @@ def test_polyexp_exact_quadratic(hip_ctx):
     R = hip_ctx.polyexp(cu(I.astype(np.float32))).cpu().numpy()
     yy, xx = 20, 25
     exp = [by + 2 * cyy * (yy - 30) + cxy * (xx - 40), bx + 2 * cxx * (xx - 40) + cxy * (yy - 30), cyy, cxx, cxy]
-    np.testing.assert_allclose(R[:, yy, xx], exp, atol=2e-6)
+    np.testing.assert_allclose(R[yy, xx, :], exp, atol=2e-6)
 
 
 def test_polyexp_n7(hip_ctx):
     I = smooth_texture(3, 90, 120).astype(np.float32)
     got = hip_ctx.polyexp(cu(I), 7, 1.5).cpu().numpy()
-    np.testing.assert_array_equal(got, planar5(oracle.polyexp(I, 7, 1.5)))
+    np.testing.assert_array_equal(got, oracle.polyexp(I, 7, 1.5))
 
 
 # ---------------------------------------------------------------- A5 UpdateMatrices
@@ -119,10 +119,10 @@ def test_update_matrices_bit_exact(hip_ctx, h, w):
     flow = (rng.standard_normal((h, w, 2)) * 3).astype(np.float32)
     flow[0, 0] = (-50, -50)      # far outside -> else-branch
     flow[-1, -1] = (0, 0)        # last row/col quirk
-    got = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1)), flow=cu(flow)).cpu().numpy()
+    got = hip_ctx.update_matrices(cu(R0), cu(R1), flow=cu(flow)).cpu().numpy()
     np.testing.assert_array_equal(got, planar5(oracle.update_matrices(R0, R1, flow)))
     # zero flow
-    got0 = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1))).cpu().numpy()
+    got0 = hip_ctx.update_matrices(cu(R0), cu(R1)).cpu().numpy()
     np.testing.assert_array_equal(got0, planar5(oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))))
 
 
@@ -131,7 +131,7 @@ def test_update_matrices_with_flow_upsample_bit_exact(hip_ctx, h, w, ch, cw):
     R0, R1 = _expansions(h + 1, h, w)
     coarse = (np.random.default_rng(ch).standard_normal((ch, cw, 2)) * 2).astype(np.float32)
     up = oracle.resize_linear(coarse, h, w) * np.float32(2.0)
-    got = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R1)), coarse_flow=cu(coarse), pyr_scale=0.5).cpu().numpy()
+    got = hip_ctx.update_matrices(cu(R0), cu(R1), coarse_flow=cu(coarse), pyr_scale=0.5).cpu().numpy()
     np.testing.assert_array_equal(got, planar5(oracle.update_matrices(R0, R1, up)))
 
 
@@ -139,7 +139,7 @@ def test_update_matrices_identical_frames_quirk(hip_ctx):
     """R0 == R1 and zero flow: h1 = h2 = 0 inside, non-zero on the last row / column (A5 quirk)."""
     h, w = 60, 70
     R0, _ = _expansions(9, h, w)
-    M = hip_ctx.update_matrices(cu(planar5(R0)), cu(planar5(R0))).cpu().numpy()
+    M = hip_ctx.update_matrices(cu(R0), cu(R0)).cpu().numpy()
     assert np.abs(M[3:, :-1, :-1]).max() == 0
     assert np.abs(M[3:, -1, :]).max() > 0 and np.abs(M[3:, :, -1]).max() > 0
 
@@ -151,7 +151,7 @@ def test_update_flow_blur_parity(hip_ctx, h, w, update):
     R0, R1 = _expansions(h + 2, h, w)
     M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
     ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 15, update)
-    flow, Mn = hip_ctx.update_flow_blur(cu(planar5(R0)), cu(planar5(R1)), cu(planar5(M)), 15, update)
+    flow, Mn = hip_ctx.update_flow_blur(cu(R0), cu(R1), cu(planar5(M)), 15, update)
     flow = flow.cpu().numpy()
     assert np.abs(flow - ref_flow).max() <= 1e-4
     if update:
@@ -176,7 +176,7 @@ def test_update_flow_blur_other_window(hip_ctx):
 def test_flow_iteration_parity(hip_ctx, h, w):
     """k_flow_iter == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources."""
     R0, R1 = _expansions(h + 3, h, w)
-    r0, r1 = cu(planar5(R0)), cu(planar5(R1))
+    r0, r1 = cu(R0), cu(R1)
     rng = np.random.default_rng(h)
     # (a) zero flow
     M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
