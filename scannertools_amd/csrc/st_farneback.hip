@@ -680,8 +680,6 @@ struct UmLoads {
   float qs;            // R0 channel 4
   float4 t0, t1, b0, b1;  // R1 channels 0..3 at (gi, gi+1, gi+w, gi+w+1)
   f2u ts, bs;          // R1 channel 4 at (gi, gi+1) and (gi+w, gi+w+1)
-  float fx, fy;
-  bool inb;
 };
 
 // Loads address an expansion as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
@@ -700,11 +698,9 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
                                          int w, int x, int y, float2 f, UmLoads& L) {
   float fx = x + f.x, fy = y + f.y;
   const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-  fx -= x1; fy -= y1;
-  L.fx = fx; L.fy = fy;
-  L.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-  const unsigned gi = L.inb ? (unsigned)(y1 * w + x1) : 0u;  // out of range: harmless address, result unused
-  const unsigned gb = gi + (L.inb ? (unsigned)w : 0u);
+  const bool inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+  const unsigned gi = inb ? (unsigned)(y1 * w + x1) : 0u;  // out of range: harmless address, result unused
+  const unsigned gb = gi + (inb ? (unsigned)w : 0u);
   const unsigned o = (unsigned)(y * w + x);
   const unsigned single = 16u * (unsigned)np;  // byte offset of the channel-4 plane
   L.q = ldf4(R0, 16u * o);
@@ -718,9 +714,14 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
 }
 
 __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x, int y, float2 f, float m[5]) {
-  const float dx = f.x, dy = f.y, fx = L.fx, fy = L.fy;
+  // the gather geometry is recomputed from the flow rather than carried in registers across the batch
+  const float dx = f.x, dy = f.y;
+  float fx = x + dx, fy = y + dy;
+  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  fx -= x1; fy -= y1;
+  const bool inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
   float r2, r3, r4, r5, r6;
-  if (L.inb) {
+  if (inb) {
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     r2 = a00 * L.t0.x + a01 * L.t1.x + a10 * L.b0.x + a11 * L.b1.x;
     r3 = a00 * L.t0.y + a01 * L.t1.y + a10 * L.b0.y + a11 * L.b1.y;
@@ -1179,34 +1180,67 @@ __device__ __forceinline__ CoarseX coarse_x(const IterArgs& a, int x) {
   return cx;
 }
 
+// Fetch of the input flow vector of pixel (x, y), split in two so that the fused iteration can
+// request it a batch ahead and do the up-sampling arithmetic only when the data has arrived:
+// flow_issue puts the loads in flight (the field's vector, or the 2x2 coarse neighbourhood as two
+// 16-byte loads), flow_finish turns them into the vector.
+typedef float f4u8 __attribute__((ext_vector_type(4), aligned(8)));
+struct FlowRaw {
+  f4u8 pa, pb;  // coarse rows ya / yb at columns (sx, sx+1); field mode: pa.xy is the vector
+};
+
 template <int MODE = FLOW_ANY>
-__device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
-                                               const float* __restrict__ C, const CoarseX& cx, int x, int y) {
+__device__ __forceinline__ void flow_issue(const IterArgs& a, const float* __restrict__ fin,
+                                           const float* __restrict__ C, const CoarseX& cx, int x, int y, FlowRaw& r) {
+  if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
+    const float fy = (float)((y + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
+    if (cx.pair) {
+      // the two horizontally adjacent coarse vectors in ONE 16-byte load (8-byte aligned)
+      r.pa = *reinterpret_cast<const f4u8*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(ya * a.cw + cx.sx));
+      r.pb = *reinterpret_cast<const f4u8*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(yb * a.cw + cx.sx));
+    } else {
+      float2 p = ld_flow(C, ya * a.cw + cx.sx);
+      r.pa.x = p.x; r.pa.y = p.y; r.pa.z = 0.f; r.pa.w = 0.f;
+      p = ld_flow(C, yb * a.cw + cx.sx);
+      r.pb.x = p.x; r.pb.y = p.y; r.pb.z = 0.f; r.pb.w = 0.f;
+    }
+  } else if (MODE == FLOW_FIELD || (MODE == FLOW_ANY && fin)) {
+    const float2 p = ld_flow(fin, y * a.w + x);
+    r.pa.x = p.x; r.pa.y = p.y;
+  }
+}
+
+template <int MODE = FLOW_ANY>
+__device__ __forceinline__ float2 flow_finish(const IterArgs& a, const float* __restrict__ fin,
+                                              const float* __restrict__ C, const CoarseX& cx, int y, const FlowRaw& r) {
   if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
     // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
     float fy = (float)((y + 0.5) * a.scale_y - 0.5);
-    int sy = (int)floorf(fy);
+    const int sy = (int)floorf(fy);
     fy -= sy;
-    const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
     const float a1 = cx.a1, a0 = cx.a0, b0 = 1.f - fy, b1 = fy;
     float2 ta, tb;
     if (cx.pair) {
-      // the two horizontally adjacent coarse vectors in ONE 16-byte load (8-byte aligned)
-      typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-      const f4u pa = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(ya * a.cw + cx.sx));
-      const f4u pb = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(yb * a.cw + cx.sx));
-      ta.x = pa.x * a0 + pa.z * a1; ta.y = pa.y * a0 + pa.w * a1;
-      tb.x = pb.x * a0 + pb.z * a1; tb.y = pb.y * a0 + pb.w * a1;
+      ta.x = r.pa.x * a0 + r.pa.z * a1; ta.y = r.pa.y * a0 + r.pa.w * a1;
+      tb.x = r.pb.x * a0 + r.pb.z * a1; tb.y = r.pb.y * a0 + r.pb.w * a1;
     } else {
-      float2 p = ld_flow(C, ya * a.cw + cx.sx);
-      ta.x = p.x * 1.f; ta.y = p.y * 1.f;
-      p = ld_flow(C, yb * a.cw + cx.sx);
-      tb.x = p.x * 1.f; tb.y = p.y * 1.f;
+      ta.x = r.pa.x * 1.f; ta.y = r.pa.y * 1.f;
+      tb.x = r.pb.x * 1.f; tb.y = r.pb.y * 1.f;
     }
     return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
   }
-  if (MODE == FLOW_FIELD || (MODE == FLOW_ANY && fin)) return ld_flow(fin, y * a.w + x);
+  if (MODE == FLOW_FIELD || (MODE == FLOW_ANY && fin)) return make_float2(r.pa.x, r.pa.y);
   return make_float2(0.f, 0.f);
+}
+
+template <int MODE = FLOW_ANY>
+__device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
+                                               const float* __restrict__ C, const CoarseX& cx, int x, int y) {
+  FlowRaw r;
+  flow_issue<MODE>(a, fin, C, cx, x, y, r);
+  return flow_finish<MODE>(a, fin, C, cx, y, r);
 }
 
 template <int M, int RB, typename VT, int MODE>
@@ -1346,8 +1380,11 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
         }
+        // flows of the batch after next: requested here, turned into vectors after phase 2 (the
+        // up-sampling arithmetic of the level transition must not wait on loads issued just now)
+        FlowRaw raw[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1));
+        for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
         PSTAMP();
         __syncthreads();
         PSTAMP();
@@ -1382,6 +1419,8 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           }
           }
         }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
         PSTAMP();
         __syncthreads();
         PSTAMP();
