@@ -512,6 +512,233 @@ __global__ __launch_bounds__(256) void k_pyr_dec(PyrDecArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// All four pyramid levels of the reference's default geometry in ONE pass over the gray frame
+// (levels 0..3 = blur 3/3/9/19 taps + decimation by 1/2/4/8; frame sides multiples of 8).  The
+// per-level kernels above read the gray frame four times and, marching one source row per trip
+// with one or two loads in flight, are bound by memory latency; here a workgroup owns a strip of
+// 1024 source columns, stages 8 source rows per barrier through LDS (one aligned dword per thread
+// and row, the next batch's loads in flight while the current one is consumed) and every thread
+// feeds the row-filter rings of all four levels from the staged bytes:
+//   level 0: thread t -> columns 4t..4t+3          level 1: outputs 2t, 2t+1
+//   level 2: output t                               level 3: output u = 32*wave + lane%32, the two
+//                                                   blurred columns split over lane halves
+// Arithmetic (operand order, association) is that of k_pyr0 / k_pyr_dec, so the results are
+// bit-identical to theirs.
+// ---------------------------------------------------------------------------------------------
+struct PyrFusedArgs {
+  const uint8_t* gray;          // n x (h*w)
+  float* img0; float* img1; float* img2; float* img3;  // n x (h>>k)*(w>>k)
+  int h, w, rows_per_seg;       // rows_per_seg: source rows per segment, multiple of 8
+  int strip_w;                  // source columns per workgroup strip
+  // taps of levels 0..3 (3, 3, 9, 19), first half only: cv::getGaussianKernel is exactly symmetric
+  // (k[i] == k[n-1-i]), and 19 scalars instead of 34 stay within the scalar register file
+  float k0[2], k1[2], k2[5], k3[10];
+};
+
+// pyr_rowfilter / pyr_colfilter with the taps given by their first half (kh[i] = k[i], i <= KS/2)
+template <int KS>
+__device__ __forceinline__ float pf_rowfilter(const float* __restrict__ b, const float* __restrict__ kh) {
+  constexpr int r = KS / 2;
+  if (KS == 3) return b[1] * kh[1] + (b[0] + b[2]) * kh[0];
+  float v = kh[0] * b[0];
+#pragma unroll
+  for (int i = 1; i < KS; ++i) v += kh[i <= r ? i : KS - 1 - i] * b[i];
+  return v;
+}
+template <int KS>
+__device__ __forceinline__ float pf_colfilter(const float* __restrict__ c, const float* __restrict__ kh) {
+  constexpr int r = KS / 2;
+  if (KS == 3) return (c[0] + c[2]) * kh[0] + c[1] * kh[1];
+  float s = kh[r] * c[r];
+#pragma unroll
+  for (int i = 1; i <= r; ++i) s += kh[r - i] * (c[r + i] + c[r - i]);
+  return s;
+}
+
+constexpr int PF_RB = 8;          // source rows per barrier
+constexpr int PF_ROWDW = 260;     // staged row: 8 halo bytes + 1024 + 8 halo bytes, as dwords
+
+// four source bytes at columns col0..col0+3 with BORDER_REFLECT_101 (frame borders only: rare)
+__device__ __forceinline__ unsigned pf_load4_border(const uint8_t* __restrict__ row, int col0, int w) {
+  unsigned v = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) v |= (unsigned)row[d_reflect101(col0 + k, w)] << (8 * k);
+  return v;
+}
+__device__ __forceinline__ unsigned pf_load4(const uint8_t* __restrict__ row, int col0, int w) {
+  if (col0 >= 0 && col0 + 3 < w) return *reinterpret_cast<const unsigned*>(row + col0);
+  if (col0 >= w + 8 || col0 < -8) return 0u;  // never read
+  return pf_load4_border(row, col0, w);
+}
+
+__device__ __forceinline__ float pf_byte(unsigned d, int k) { return (float)((d >> (8 * k)) & 0xffu); }
+
+__global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
+  __shared__ unsigned srow[2][PF_RB][PF_ROWDW];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int h = a.h, w = a.w;
+  const int SW = a.strip_w;           // source columns per strip: multiple of 8, <= 1024
+  const int X0 = blockIdx.x * SW;
+  const int Y0 = blockIdx.y * a.rows_per_seg, Y1 = min(h, Y0 + a.rows_per_seg);
+  const size_t np = (size_t)h * w;
+  const uint8_t* __restrict__ g = a.gray + (size_t)blockIdx.z * np;
+  float* __restrict__ o0 = a.img0 + (size_t)blockIdx.z * np;
+  float* __restrict__ o1 = a.img1 + (size_t)blockIdx.z * (np >> 2);
+  float* __restrict__ o2 = a.img2 + (size_t)blockIdx.z * (np >> 4);
+  float* __restrict__ o3 = a.img3 + (size_t)blockIdx.z * (np >> 6);
+  const int u = wv * 32 + (lane & 31), half = lane >> 5;  // level-3 output and blurred column
+  const bool live = 4 * t < SW && X0 + 4 * t < w;          // this thread's columns exist
+  const bool live3 = 8 * u < SW && X0 + 8 * u < w;
+  // the 4 halo dwords of each of the 8 staged rows are fetched by threads 0..31 (row t/4, dword t%4)
+  const int hq = t & 3, hrow = (t >> 2) & 7;
+  const int hcol = hq < 2 ? X0 - 8 + 4 * hq : X0 + SW + 4 * (hq - 2);
+  const int hidx = hq < 2 ? hq : 2 + (SW >> 2) + (hq - 2);
+
+  float hm[4], hc[4];                 // level 0: row-filtered rows y-2, y-1
+  float r1A[2][4], r1B[2][4];         // level 1: KS+1 = 4 row-filtered rows per output and column
+  float r2A[10], r2B[10];             // level 2: KS+1 = 10
+  float r3[20];                       // level 3: KS+1 = 20 (one blurred column per lane half)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { hm[j] = hc[j] = 0.f; r1A[0][j] = r1A[1][j] = r1B[0][j] = r1B[1][j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) r2A[j] = r2B[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 20; ++j) r3[j] = 0.f;
+
+  unsigned pre[PF_RB], preh = 0u;
+  auto fetch = [&](int ybase) {
+#pragma unroll
+    for (int r = 0; r < PF_RB; ++r)
+      pre[r] = pf_load4(g + (size_t)d_reflect101(ybase + r, h) * w, X0 + 4 * t, w);
+    if (t < 32) preh = pf_load4(g + (size_t)d_reflect101(ybase + hrow, h) * w, hcol, w);
+  };
+  auto stash = [&](int buf) {
+    if (4 * t < SW) {  // threads beyond the strip would overwrite its right halo
+#pragma unroll
+      for (int r = 0; r < PF_RB; ++r) srow[buf][r][2 + t] = pre[r];
+    }
+    if (t < 32) srow[buf][hrow][hidx] = preh;
+  };
+
+  // source rows Y0-8 .. Y1+7 feed the outputs of [Y0, Y1) at every level (level 3 reaches 6 rows
+  // above and 5 below its block of 8)
+  const int nb = (Y1 - Y0) / PF_RB + 2;
+  fetch(Y0 - PF_RB);
+  stash(0);
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    const int ybase = Y0 - PF_RB + b * PF_RB;
+    const int buf = b & 1;
+    if (b + 1 < nb) fetch(ybase + PF_RB);
+    // fully unrolled: with r a compile-time constant the emission tests below fold away (a rolled
+    // loop measured 20 % slower although its body fits the instruction cache more easily)
+#pragma unroll
+    for (int r = 0; r < PF_RB; ++r) {
+      const int y = ybase + r;  // source row entering (unreflected index)
+      const unsigned* __restrict__ s = srow[buf][r];
+      // bytes of columns X0+4t-4 .. X0+4t+7
+      const unsigned d0 = s[t + 1], d1 = s[t + 2], d2 = s[t + 3];
+      float bb[12];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { bb[k] = pf_byte(d0, k); bb[4 + k] = pf_byte(d1, k); bb[8 + k] = pf_byte(d2, k); }
+      // ---- level 0 (k_pyr0)
+      {
+        float hp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hp[j] = bb[4 + j] * a.k0[1] + (bb[3 + j] + bb[5 + j]) * a.k0[0];
+        const int yo = y - 1;
+        if (live && yo >= Y0 && yo < Y1) {
+          float4 v;
+          v.x = (hm[0] + hp[0]) * a.k0[0] + hc[0] * a.k0[1];
+          v.y = (hm[1] + hp[1]) * a.k0[0] + hc[1] * a.k0[1];
+          v.z = (hm[2] + hp[2]) * a.k0[0] + hc[2] * a.k0[1];
+          v.w = (hm[3] + hp[3]) * a.k0[0] + hc[3] * a.k0[1];
+          *reinterpret_cast<float4*>(o0 + (size_t)yo * w + X0 + 4 * t) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hm[j] = hc[j]; hc[j] = hp[j]; }
+      }
+      // ---- level 1 (k_pyr_dec<2,3>): outputs 2t+e, blurred columns 4t+2e and 4t+2e+1
+      {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float nA = pf_rowfilter<3>(bb + 3 + 2 * e, a.k1), nB = pf_rowfilter<3>(bb + 4 + 2 * e, a.k1);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { r1A[e][j] = r1A[e][j + 1]; r1B[e][j] = r1B[e][j + 1]; }
+          r1A[e][3] = nA; r1B[e][3] = nB;
+        }
+        if ((r & 1) == 0) {  // y = 2*dy + 2
+          const int dy = (y - 2) >> 1;
+          if (live && dy >= (Y0 >> 1) && dy < (Y1 >> 1)) {
+            float2 v;
+            {
+              const float b00 = pf_colfilter<3>(r1A[0], a.k1), b01 = pf_colfilter<3>(r1B[0], a.k1);
+              const float b10 = pf_colfilter<3>(r1A[0] + 1, a.k1), b11 = pf_colfilter<3>(r1B[0] + 1, a.k1);
+              v.x = ((b00 + b01) + (b10 + b11)) * 0.25f;
+            }
+            {
+              const float b00 = pf_colfilter<3>(r1A[1], a.k1), b01 = pf_colfilter<3>(r1B[1], a.k1);
+              const float b10 = pf_colfilter<3>(r1A[1] + 1, a.k1), b11 = pf_colfilter<3>(r1B[1] + 1, a.k1);
+              v.y = ((b00 + b01) + (b10 + b11)) * 0.25f;
+            }
+            *reinterpret_cast<float2*>(o1 + (size_t)dy * (w >> 1) + (X0 >> 1) + 2 * t) = v;
+          }
+        }
+      }
+      // ---- level 2 (k_pyr_dec<4,9>): output t, blurred columns 4t+1 and 4t+2, window from 4t-3
+      {
+        const float nA = pf_rowfilter<9>(bb + 1, a.k2), nB = pf_rowfilter<9>(bb + 2, a.k2);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { r2A[j] = r2A[j + 1]; r2B[j] = r2B[j + 1]; }
+        r2A[9] = nA; r2B[9] = nB;
+        if ((r & 3) == 2) {  // y = 4*dy + 6
+          const int dy = (y - 6) >> 2;
+          if (live && dy >= (Y0 >> 2) && dy < (Y1 >> 2)) {
+            const float b00 = pf_colfilter<9>(r2A, a.k2), b01 = pf_colfilter<9>(r2B, a.k2);
+            const float b10 = pf_colfilter<9>(r2A + 1, a.k2), b11 = pf_colfilter<9>(r2B + 1, a.k2);
+            const float q0 = b00 * 0.5f + b01 * 0.5f, q1 = b10 * 0.5f + b11 * 0.5f;
+            o2[(size_t)dy * (w >> 2) + (X0 >> 2) + t] = q0 * 0.5f + q1 * 0.5f;
+          }
+        }
+      }
+      // ---- level 3 (k_pyr_dec<8,19>): output u, blurred column 8u+3+half, window from 8u-6+half
+      {
+        // dwords covering columns X0+8u-8 .. X0+8u+15, realigned by `half` bytes so that both lane
+        // halves run the same code: cb[k] = column X0+8u-8+half+k
+        unsigned dw[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dw[q] = s[2 * u + q];
+        float cb[21];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const unsigned d = __builtin_amdgcn_alignbyte(dw[q + 1 < 6 ? q + 1 : 5], dw[q], (unsigned)half);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * q + k < 21) cb[4 * q + k] = pf_byte(d, k);
+        }
+        const float n3 = pf_rowfilter<19>(cb + 2, a.k3);
+#pragma unroll
+        for (int j = 0; j < 19; ++j) r3[j] = r3[j + 1];
+        r3[19] = n3;
+        if (r == 5) {  // y = 8*dy + 13
+          const int dy = (y - 13) >> 3;
+          if (dy >= (Y0 >> 3) && dy < (Y1 >> 3)) {  // uniform over the workgroup
+            const float c0 = pf_colfilter<19>(r3, a.k3), c1 = pf_colfilter<19>(r3 + 1, a.k3);
+            const float p0 = __shfl_xor(c0, 32), p1 = __shfl_xor(c1, 32);  // the other blurred column
+            if (half == 0 && live3) {
+              const float q0 = c0 * 0.5f + p0 * 0.5f, q1 = c1 * 0.5f + p1 * 0.5f;
+              o3[(size_t)dy * (w >> 3) + (X0 >> 3) + u] = q0 * 0.5f + q1 * 0.5f;
+            }
+          }
+        }
+      }
+    }
+    if (b + 1 < nb) stash(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
 // vertically filtered values go through LDS for the horizontal pass.
@@ -1555,6 +1782,52 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
   return ST_OK;
 }
 
+// The one-pass pyramid applies to the reference's default geometry: four levels, each exactly half
+// the previous one (sides multiples of 8), kernel sizes 3/3/9/19.  ST_PYR_UNFUSED=1 forces the
+// per-level kernels (A/B runs).
+bool pyr_fused_ok(int h, int w, const st_fb_params& p) {
+  static const bool off = getenv("ST_PYR_UNFUSED") != nullptr || getenv("ST_PYR_GENERIC") != nullptr;
+  if (off || fb_levels(h, w, p) != 3 || (h & 7) || (w & 7)) return false;
+  static const int ks[4] = {3, 3, 9, 19};
+  for (int k = 0; k <= 3; ++k) {
+    const LevelGeom g = fb_level_geom(h, w, p, k);
+    if (g.lh != (h >> k) || g.lw != (w >> k) || g.ksize != ks[k]) return false;
+  }
+  return true;
+}
+
+// imgs[k]: n x (h>>k)*(w>>k) floats
+int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const st_fb_params& p, float* const imgs[4]) {
+  PyrFusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gray = gray; a.img0 = imgs[0]; a.img1 = imgs[1]; a.img2 = imgs[2]; a.img3 = imgs[3];
+  a.h = h; a.w = w;
+  float* taps[4] = {a.k0, a.k1, a.k2, a.k3};
+  for (int k = 0; k <= 3; ++k) {
+    const LevelGeom g = fb_level_geom(h, w, p, k);
+    float full[kMaxTaps];
+    gaussian_kernel(g.ksize, g.sigma, full);
+    for (int i = 0; i <= g.ksize / 2; ++i) {
+      if (full[i] != full[g.ksize - 1 - i]) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "pyr: asymmetric Gaussian taps");
+      taps[k][i] = full[i];
+    }
+  }
+  // equal strips of at most 1024 columns (1920 -> 2 x 960 rather than 1024 + 896)
+  const int strips = (w + 1023) / 1024;
+  a.strip_w = ((w + strips - 1) / strips + 7) / 8 * 8;
+  // each segment re-reads 16 rows of context, but the launch needs a few rounds of workgroups per
+  // CU to balance (3 resident per CU): 8 per CU measured best at 257 frames of 1080p
+  long long segs = ((long long)ctx->num_cus * 8 + (long long)strips * n - 1) / ((long long)strips * n);
+  int rows = (int)((h + segs - 1) / segs);
+  rows = (rows + 7) / 8 * 8;
+  if (rows < 64) rows = h < 64 ? h : 64;
+  a.rows_per_seg = rows;
+  st_timed t(ctx, ST_K_PYR);
+  hipLaunchKernelGGL(k_pyr_fused, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
 int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R) {
   PolyArgs a;
   a.img = img; a.R = R; a.h = h; a.w = w;
@@ -1674,7 +1947,9 @@ size_t pass_bytes(int h, int w, const st_fb_params& p, int nf, int npairs) {
   }
   size_t b = 0;
   b += st_align_up(np0 * nf);                        // gray
-  b += st_align_up(sizeof(float) * np0 * nf);        // I (reused per level)
+  b += st_align_up(sizeof(float) * np0 * nf);        // I (reused per level; level 0 when the pyramid is one pass)
+  if (pyr_fused_ok(h, w, p))
+    for (int k = 1; k <= 3; ++k) b += st_align_up(sizeof(float) * (np0 >> (2 * k)) * nf);  // I_1..I_3
   for (int k = 0; k <= levels; ++k) {
     LevelGeom g = fb_level_geom(h, w, p, k);
     b += st_align_up(sizeof(float) * 5 * (size_t)g.lh * g.lw * nf);  // R_k
@@ -1692,6 +1967,13 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   ST_TRY(st_ws_reserve(ctx, pass_bytes(h, w, p, nf, npairs)));
   uint8_t* gray = (uint8_t*)st_ws_alloc(ctx, np0 * nf);
   float* img = (float*)st_ws_alloc(ctx, sizeof(float) * np0 * nf);
+  const bool pyr1 = pyr_fused_ok(h, w, p);
+  float* imgs[4] = {img, nullptr, nullptr, nullptr};
+  if (pyr1)
+    for (int k = 1; k <= 3; ++k) {
+      imgs[k] = (float*)st_ws_alloc(ctx, sizeof(float) * (np0 >> (2 * k)) * nf);
+      if (!imgs[k]) return st_set_error(ctx, ST_ERR_OOM, "farneback: scratch plan exhausted");
+    }
   std::vector<float*> R(levels + 1);
   std::vector<LevelGeom> geom(levels + 1);
   size_t maxCoarse = 1;
@@ -1721,9 +2003,10 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   bool aligned4 = true;
   for (int i = 0; i < nf; ++i) aligned4 = aligned4 && ((uintptr_t)frames[i] & 3) == 0;
   ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
+  if (pyr1) ST_TRY(launch_pyr_fused(ctx, gray, nf, h, w, p, imgs));
   for (int k = levels; k >= 0; --k) {
-    ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
-    ST_TRY(launch_polyexp(ctx, img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
+    if (!pyr1) ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
+    ST_TRY(launch_polyexp(ctx, pyr1 ? imgs[k] : img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
   }
   // per-pair stages, coarse to fine
   if (fused) {
@@ -1886,6 +2169,19 @@ ST_EXPORT int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w
   ST_TRY(check_params(ctx, p, h, w));
   LevelGeom g = fb_level_geom(h, w, p, level);
   if (g.ksize > kMaxTaps - 1 || g.lh < 1 || g.lw < 1) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "pyr: level %d unsupported", level);
+  if (pyr_fused_ok(h, w, p) && level <= 3) {
+    // the production path builds all four levels in one pass; run exactly that and hand out one
+    const size_t np0 = (size_t)h * w;
+    size_t bytes = 0;
+    for (int k = 0; k <= 3; ++k) bytes += st_align_up(sizeof(float) * (np0 >> (2 * k)));
+    ST_TRY(st_ws_reserve(ctx, bytes));
+    float* imgs[4];
+    for (int k = 0; k <= 3; ++k) {
+      imgs[k] = k == level ? img_dev : (float*)st_ws_alloc(ctx, sizeof(float) * (np0 >> (2 * k)));
+      if (!imgs[k]) return st_set_error(ctx, ST_ERR_OOM, "pyr: scratch exhausted");
+    }
+    return launch_pyr_fused(ctx, gray_dev, 1, h, w, p, imgs);
+  }
   return launch_pyr(ctx, gray_dev, 1, h, w, g, img_dev);
 }
 

@@ -6,7 +6,8 @@ from scannertools_amd import _native
 from scannertools_amd.hip import HipContext
 ctx = HipContext(0)
 g = torch.Generator(device="cuda").manual_seed(0)
-fr = torch.randint(0, 256, (33, 1080, 1920, 3), dtype=torch.uint8, device="cuda", generator=g)
+NF = int(os.environ.get("NF", 33))
+fr = torch.randint(0, 256, (NF, 1080, 1920, 3), dtype=torch.uint8, device="cuda", generator=g)
 out = ctx.optical_flow(fr)
 ids = [_native.K_GRAY, _native.K_PYR, _native.K_POLYEXP, _native.K_BLUR_UPDATE]
 ctx.timing_enable(ids); ctx.timing_reset()

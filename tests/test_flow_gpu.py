@@ -67,6 +67,18 @@ def test_pyramid_levels_bit_exact(hip_ctx, h, w):
         np.testing.assert_array_equal(got, ref, err_msg="level %d" % k)
 
 
+@pytest.mark.parametrize("h,w", [(256, 256), (264, 1032), (512, 2056), (328, 1024), (2160, 3840)])
+def test_pyramid_one_pass_kernel_bit_exact(hip_ctx, h, w):
+    """Frames whose sides are multiples of 8 (>= 256) take the one-pass four-level kernel: single
+    strips, a second strip of 8 columns, three strips, several vertical segments, 4K."""
+    assert oracle.fb_levels(h, w) == 3
+    gray = np.random.default_rng(h + w).integers(0, 256, (h, w), dtype=np.uint8)
+    for k in range(4):
+        got = hip_ctx.pyr_image(cu(gray), k).cpu().numpy()
+        assert got.shape == (h >> k, w >> k)
+        np.testing.assert_array_equal(got, oracle.fb_pyr_image(gray, k), err_msg="level %d" % k)
+
+
 def test_pyramid_1080p_geometry_and_parity(hip_ctx):
     h, w = 1080, 1920
     assert oracle.fb_levels(h, w) == 3
