@@ -78,7 +78,8 @@ enum st_kernel_id {
   ST_K_BLUR_UPDATE = 5, /* box blur + 2x2 solve (+ fused UpdateMatrices): the dominant kernel */
   ST_K_FLOW_HIST = 6,
   ST_K_DRAW_FLOW = 7,   /* max-reduction + render launches of one st_draw_flow_batch call */
-  ST_K_COUNT = 8
+  ST_K_BLUR_OP = 8,     /* the Blur op's box filter (not the Farneback blur, which is ST_K_BLUR_UPDATE) */
+  ST_K_COUNT = 9
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -190,6 +191,16 @@ int st_flow_hist_strided(st_ctx* ctx, const float* base_dev, size_t frame_stride
  * cast.  frames: (h, w, 3) uint8; flows: (h, w, 2) float32, 8-byte aligned; out: (h, 2w, 3) uint8. */
 int st_draw_flow_batch(st_ctx* ctx, const uint8_t* const* frames_dev, const float* const* flows_dev,
                        int n, int h, int w, uint8_t* const* out_dev);
+
+/* ---- Sibling imgproc ops ---------------------------------------------
+ * Blur: replaces BlurKernel::execute (scannertools_cpp/imgproc/blur_kernel_cpu.cpp:50-81), the
+ * reference's own box filter: window [-left, +right] around each interior pixel with
+ * left = ceil(kernel_size/2.0) - 1, right = kernel_size/2, per channel
+ * out = sum / (left + right + 1)^2 in unsigned integer arithmetic; BlurArgs.sigma is ignored, as in
+ * the reference.  frames / out: n device pointers to (h, w, 3) uint8; out must not alias its input.
+ * Border pixels (which the reference leaves uninitialised) are set to 0.  kernel_size in [1, 31]. */
+int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w,
+                           int kernel_size, uint8_t* const* out_dev);
 
 #ifdef __cplusplus
 }

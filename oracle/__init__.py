@@ -219,6 +219,16 @@ def draw_flow(frame, flow):
     return out
 
 
+def box_blur(frame, kernel_size):
+    """(h,w,3) uint8 -> (h,w,3) uint8: the Blur op (blur_kernel_cpu.cpp:36-81); border pixels 0."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, c = frame.shape
+    assert c == 3
+    out = np.empty_like(frame)
+    lib().orc_box_blur_u8c3(_p(frame), h, w, int(kernel_size), _p(out))
+    return out
+
+
 def shot_boundaries(histograms):
     """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
     each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices

@@ -656,3 +656,28 @@ ORC_API void orc_draw_flow(const uint8_t* frame, const float* flow, int h, int w
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Blur op -- BlurKernel::execute,
+ * /root/reference/scannertools/scannertools_cpp/imgproc/blur_kernel_cpu.cpp:36-81.  The reference
+ * implements the filter itself (no OpenCV): a k x k box sum over the window
+ * [-filter_left, +filter_right] with filter_left = ceil(k/2.0) - 1, filter_right = k/2, unsigned
+ * integer division by (filter_left + filter_right + 1)^2, 3 interleaved U8 channels; `sigma` is
+ * parsed and never used.  Only interior pixels (y in [left, h-right), x in [left, w-right)) are
+ * written; the reference leaves the border of its freshly allocated frame uninitialised -- this
+ * restatement (and the HIP kernel) writes 0 there.  Pinned by definition: the arithmetic is spelled
+ * out in the reference source and is integer.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_box_blur_u8c3(const uint8_t* src, int h, int w, int kernel_size, uint8_t* dst) {
+  const int left = (int)ceil(kernel_size / 2.0) - 1, right = kernel_size / 2;
+  const unsigned div = (unsigned)((right + left + 1) * (right + left + 1));
+  memset(dst, 0, (size_t)h * w * 3);
+  for (int y = left; y < h - right; ++y)
+    for (int x = left; x < w - right; ++x)
+      for (int c = 0; c < 3; ++c) {
+        uint32_t value = 0;
+        for (int ry = -left; ry < right + 1; ++ry)
+          for (int rx = -left; rx < right + 1; ++rx) value += src[((size_t)(y + ry) * w + (x + rx)) * 3 + c];
+        dst[((size_t)y * w + x) * 3 + c] = (uint8_t)(value / div);
+      }
+}

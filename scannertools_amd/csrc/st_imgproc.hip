@@ -1,0 +1,149 @@
+// Sibling imgproc ops of the hot path.
+//
+// Blur replaces BlurKernel::execute
+// (/root/reference/scannertools/scannertools_cpp/imgproc/blur_kernel_cpu.cpp:50-81): the
+// reference's own k x k box filter over interleaved U8x3 frames -- window [-left, +right] with
+// left = ceil(k/2.0) - 1, right = k/2, unsigned integer division by k^2, interior pixels only
+// (the reference leaves the border of its output frame uninitialised; 0 is written here).
+// The O(k^2) per-pixel loop becomes two separable integer running sums (exact: sums are integers,
+// one division at the end), 3 B/px read + 3 B/px written.
+#include "st_internal.h"
+
+namespace {
+
+constexpr int BL_T = 256;        // threads; a thread owns 4 consecutive bytes of a frame row
+constexpr int BL_ROWS = 16;      // output rows per workgroup tile
+constexpr int BL_MAXK = 31;
+constexpr int BL_TILEB = 4 * BL_T;  // tile width in bytes
+
+struct BlurArgsK {
+  const uint8_t* const* src;  // device table of (h, w, 3) frames
+  uint8_t* const* dst;
+  int h, w, k, left, right;
+  int H;           // staged bytes ahead of the tile: 3*left rounded up to a multiple of 4
+  int row_dwords;  // staged dwords per row
+  unsigned div;
+};
+
+// LDS: staged source rows as bytes, then their horizontal sums as 4 x u16 per thread
+__global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
+  extern __shared__ unsigned smem[];
+  const int t = threadIdx.x;
+  const int nrows = BL_ROWS + a.k - 1;                   // staged rows of this tile
+  unsigned* stage = smem;                                // [nrows][row_dwords]
+  uint2* hs = reinterpret_cast<uint2*>(smem + (size_t)nrows * a.row_dwords);  // [nrows][BL_T]
+  const int nb = 3 * a.w;                                // bytes per frame row
+  const long long total = (long long)nb * a.h;
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ dst = a.dst[blockIdx.z];
+  const int B0 = blockIdx.x * BL_TILEB;                  // first byte (within a row) of the tile
+  const int Y0 = blockIdx.y * BL_ROWS;                   // first output row of the tile
+
+  // ---- stage rows Y0-left .. Y0+BL_ROWS-1+right: LDS byte i of a row <-> row byte B0 - H + i.
+  // Unaligned dword loads; bytes of a neighbouring row or outside the frame only feed border
+  // outputs, which are forced to 0 below.
+  for (int r = 0; r < nrows; ++r) {
+    const int y = Y0 - a.left + r;
+    const int yc = y < 0 ? 0 : (y >= a.h ? a.h - 1 : y);
+    for (int d = t; d < a.row_dwords; d += BL_T) {
+      const long long g = (long long)yc * nb + B0 - a.H + 4 * d;
+      unsigned v;
+      if (g >= 0 && g + 4 <= total) {
+        typedef unsigned u32u __attribute__((aligned(1)));
+        v = *reinterpret_cast<const u32u*>(src + g);
+      } else {  // the dword straddles an end of the frame buffer: byte-wise, missing bytes read as 0
+        v = 0;
+        for (int j = 0; j < 4; ++j)
+          if (g + j >= 0 && g + j < total) v |= (unsigned)src[g + j] << (8 * j);
+      }
+      stage[(size_t)r * a.row_dwords + d] = v;
+    }
+  }
+  __syncthreads();
+  // ---- horizontal sums of every staged row for this thread's 4 bytes
+  const uint8_t* sb = reinterpret_cast<const uint8_t*>(stage);
+  for (int r = 0; r < nrows; ++r) {
+    const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + a.H + 4 * t;
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int i = -a.left; i <= a.right; ++i) {
+      s0 += row[3 * i]; s1 += row[3 * i + 1]; s2 += row[3 * i + 2]; s3 += row[3 * i + 3];
+    }
+    hs[(size_t)r * BL_T + t] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+  }
+  // (each thread reads back only its own sums: no barrier needed)
+  // ---- vertical running sums, divide, store
+  const int b = B0 + 4 * t;  // first byte of this thread within the row
+  if (b >= nb) return;
+  unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  for (int r = 0; r < a.k - 1; ++r) {
+    const uint2 q = hs[(size_t)r * BL_T + t];
+    v0 += q.x & 0xffffu; v1 += q.x >> 16; v2 += q.y & 0xffffu; v3 += q.y >> 16;
+  }
+  const int lo = 3 * a.left, hi = 3 * (a.w - a.right);  // interior bytes of a row: [lo, hi)
+  for (int r = 0; r < BL_ROWS; ++r) {
+    const int y = Y0 + r;
+    if (y >= a.h) break;
+    const uint2 qn = hs[(size_t)(r + a.k - 1) * BL_T + t];
+    v0 += qn.x & 0xffffu; v1 += qn.x >> 16; v2 += qn.y & 0xffffu; v3 += qn.y >> 16;
+    const bool yin = y >= a.left && y < a.h - a.right;
+    unsigned o[4] = {v0 / a.div, v1 / a.div, v2 / a.div, v3 / a.div};
+    uint8_t* out = dst + (size_t)y * nb + b;
+    unsigned packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (yin && b + j >= lo && b + j < hi) packed |= o[j] << (8 * j);
+    if (b + 3 < nb) {
+      typedef unsigned u32u __attribute__((aligned(1)));  // rows start at any byte when 3*w % 4 != 0
+      *reinterpret_cast<u32u*>(out) = packed;
+    } else {
+      for (int j = 0; b + j < nb; ++j) out[j] = (uint8_t)(packed >> (8 * j));
+    }
+    const uint2 qo = hs[(size_t)r * BL_T + t];
+    v0 -= qo.x & 0xffffu; v1 -= qo.x >> 16; v2 -= qo.y & 0xffffu; v3 -= qo.y >> 16;
+  }
+}
+
+}  // namespace
+
+ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int kernel_size,
+                                     uint8_t* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || h <= 0 || w <= 0 || (long long)h * w > 200000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "blur: bad arguments (n=%d h=%d w=%d)", n, h, w);
+  if (kernel_size < 1 || kernel_size > BL_MAXK)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: kernel_size %d outside [1, %d]", kernel_size, BL_MAXK);
+  if (n == 0) return ST_OK;
+  if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "blur: null argument");
+  for (int i = 0; i < n; ++i) {
+    if (!frames_dev[i] || !out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "blur: row %d is null", i);
+    if (frames_dev[i] == out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "blur: row %d aliases its output", i);
+  }
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const uint8_t** d_src = (const uint8_t**)st_ws_alloc(ctx, tb);
+  uint8_t** d_dst = (uint8_t**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  BlurArgsK a;
+  a.h = h; a.w = w; a.k = kernel_size;
+  a.left = (kernel_size + 1) / 2 - 1;  // ceil(k/2.0) - 1
+  a.right = kernel_size / 2;
+  a.H = (3 * a.left + 3) / 4 * 4;
+  a.row_dwords = (a.H + BL_TILEB + 3 * a.right + 3 + 3) / 4;
+  a.div = (unsigned)((a.left + a.right + 1) * (a.left + a.right + 1));
+  const int nrows = BL_ROWS + kernel_size - 1;
+  const size_t lds = (size_t)nrows * a.row_dwords * 4 + (size_t)nrows * BL_T * sizeof(uint2);
+  if (lds > 160 * 1024) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: kernel_size %d needs %zu B of LDS", kernel_size, lds);
+  ST_HIP(ctx, hipFuncSetAttribute((const void*)k_box_blur_u8c3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nb = 3 * w;
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.src = d_src + f0; a.dst = d_dst + f0;
+    dim3 grid((nb + BL_TILEB - 1) / BL_TILEB, (h + BL_ROWS - 1) / BL_ROWS, nf);
+    if (grid.y > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: frame too tall");
+    st_timed t(ctx, ST_K_BLUR_OP);
+    hipLaunchKernelGGL(k_box_blur_u8c3, grid, dim3(BL_T), lds, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}

@@ -12,7 +12,7 @@ installable here, so this module reproduces exactly that surface for in-memory f
     out = NamedStream(sc, 'hist'); sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
     next(out.load())
 
-C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``) are looked up in the kernel registry of
+C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``, ``Blur``) are looked up in the kernel registry of
 ``libscannertools_imgproc.so`` and executed by its mini engine (scanner_shim/shim.cpp): the same
 ``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``, ``DrawFlow``) are the
 functions of this package.  What is deliberately absent: the database, video decode, the
@@ -302,6 +302,17 @@ class NamedVideoStream:
     def len(self):
         return len(self._frames())
 
+    def load(self, rows=None, ty=None):
+        """Frames of the stream: an ingested video, or frames an op wrote to it as an output
+        stream (scannertools/tests/test_all.py:185-190 writes Blur's output to one)."""
+        if self.name in self.sc._tables and self.name not in self.sc._videos:
+            data, _ = self.sc._tables[self.name]
+        else:
+            data = self._frames()
+        sel = range(len(data)) if rows is None else rows
+        for i in sel:
+            yield data[i]
+
 
 class NamedStream:
     def __init__(self, sc, name):
@@ -374,6 +385,13 @@ class _Ops:
     def OpticalFlow(self, frame, stencil=None, device=None, batch=None):
         """sc.ops.OpticalFlow(frame=..., stencil=[-1,0], device=...) (tests/test_all.py:166)."""
         return _CppOpNode(self.sc, "OpticalFlow", frame, device, batch, stencil, b"")
+
+    def Blur(self, frame, kernel_size, sigma=0.0, device=None, batch=None):
+        """sc.ops.Blur(frame=..., kernel_size=3, sigma=0.1) (tests/test_all.py:184); arguments travel
+        as a serialised BlurArgs message, as Scanner passes them."""
+        from . import _proto
+        args = _proto.encode([(1, "int32", int(kernel_size)), (2, "float", float(sigma))])
+        return _CppOpNode(self.sc, "Blur", frame, device, batch, None, args)
 
     def FlowHistogram(self, flow, device=None, batch=None):
         """db.ops.FlowHistogram(flow=flow, device=DeviceType.CPU) (old/histograms.py:74-77)."""

@@ -184,6 +184,27 @@ class HipContext:
         self._check(self._L.st_draw_flow_batch(self._h, tf, tg, n, h, w, to))
         return out
 
+    # -- sibling imgproc ops ----------------------------------------------------------------
+    def box_blur(self, frames, kernel_size, out=None):
+        """Blur op (blur_kernel_cpu.cpp:50-81): k x k integer box filter of (n,h,w,3) uint8 frames
+        (a tensor or a list of (h,w,3) tensors); border pixels are 0."""
+        self._bind()
+        fr = list(frames) if isinstance(frames, (list, tuple)) else list(frames.unbind(0))
+        n = len(fr)
+        if n == 0:
+            return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
+        h, w, _ = fr[0].shape
+        for f in fr:
+            _require_cuda(f, torch.uint8, "frame")
+            if tuple(f.shape) != (h, w, 3):
+                raise ValueError("all frames must be (h,w,3) with equal shape")
+        if out is None:
+            out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device)
+        tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_box_blur_u8c3_batch(self._h, tf, n, h, w, int(kernel_size), to))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.

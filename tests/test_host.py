@@ -160,14 +160,24 @@ def test_imgproc_library_registrations():
     regs = engine.registered_kernels()
     ops = {(name, dev) for name, dev, _, _ in regs}
     assert {("Histogram", 0), ("Histogram", 1), ("OpticalFlow", 0), ("OpticalFlow", 1),
-            ("FlowHistogram", 0), ("FlowHistogram", 1)} <= ops
+            ("FlowHistogram", 0), ("FlowHistogram", 1), ("Blur", 0), ("Blur", 1)} <= ops
     for name, dev, kind, can_batch in regs:
         assert can_batch                                           # .batch() as in histogram_kernel_cpu.cpp:54-57
         assert kind == (3 if name == "OpticalFlow" else 1)         # StenciledBatched / Batched
     assert engine.op_info("OpticalFlow")["stencil"] == [0, 1]      # optical_flow_kernel_cpu.cpp:51-54
     assert engine.op_info("OpticalFlow")["frame_output"] and not engine.op_info("Histogram")["frame_output"]
     assert not engine.op_info("FlowHistogram")["frame_output"]     # flow_histogram_kernel_cpu.cpp:62
+    assert engine.op_info("Blur")["frame_output"]                  # blur_kernel_cpu.cpp:96
     assert engine.op_info("NoSuchOp") is None
+
+
+def test_proto_writer_matches_wire_format():
+    """BlurArgs{kernel_size: 3, sigma: 0.1} as protoc would serialise it."""
+    from scannertools_amd import _proto
+    import struct
+    assert _proto.encode([(1, "int32", 3), (2, "float", 0.1)]) == b"\x08\x03\x15" + struct.pack("<f", 0.1)
+    assert _proto.encode([(1, "int32", 0), (2, "float", 0.0)]) == b""       # proto3 omits defaults
+    assert _proto.encode([(1, "int32", 300), (5, "string", "INTER_LINEAR")]) == b"\x08\xac\x02\x2a\x0cINTER_LINEAR"
 
 
 def test_engine_reports_missing_gpu_cleanly():

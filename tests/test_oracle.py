@@ -168,3 +168,17 @@ def test_flow_hist_oracle_known_answers():
     dd = deg.astype(np.float64) * (64 / 360.0)
     hd = np.bincount(np.floor(dd[dd < 64]).astype(int), minlength=64)
     np.testing.assert_array_equal(oracle.flow_hist(f), np.stack([hm, hd]))
+
+
+def test_box_blur_oracle_matches_definition():
+    """Blur op restatement vs a direct numpy evaluation of blur_kernel_cpu.cpp:62-79."""
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    for k in (1, 2, 3, 4, 7):
+        left, right = int(np.ceil(k / 2.0)) - 1, k // 2
+        ref = np.zeros_like(f)
+        for y in range(left, 13 - right):
+            for x in range(left, 17 - right):
+                win = f[y - left:y + right + 1, x - left:x + right + 1].astype(np.uint32).sum((0, 1))
+                ref[y, x] = win // ((left + right + 1) ** 2)
+        np.testing.assert_array_equal(oracle.box_blur(f, k), ref)
