@@ -20,18 +20,18 @@ struct BlurArgsK {
   const uint8_t* const* src;  // device table of (h, w, 3) frames
   uint8_t* const* dst;
   int h, w, k, left, right;
-  int H;           // staged bytes ahead of the tile: 3*left rounded up to a multiple of 4
+  int H;           // staged bytes ahead of the tile = 3*left, so a thread's window starts dword aligned in LDS
   int row_dwords;  // staged dwords per row
-  unsigned div;
+  int win_dwords;  // dwords covering the 4 + 3*(k-1) bytes a thread's four horizontal sums read
+  unsigned magic;  // ceil(2^32 / k^2): sum / k^2 == umulhi(sum, magic) for sum < 2^18 (exact, see host side)
 };
 
-// LDS: staged source rows as bytes, then their horizontal sums as 4 x u16 per thread
+// LDS: the staged source rows of the tile, as bytes
 __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   extern __shared__ unsigned smem[];
   const int t = threadIdx.x;
   const int nrows = BL_ROWS + a.k - 1;                   // staged rows of this tile
   unsigned* stage = smem;                                // [nrows][row_dwords]
-  uint2* hs = reinterpret_cast<uint2*>(smem + (size_t)nrows * a.row_dwords);  // [nrows][BL_T]
   const int nb = 3 * a.w;                                // bytes per frame row
   const long long total = (long long)nb * a.h;
   const uint8_t* __restrict__ src = a.src[blockIdx.z];
@@ -62,44 +62,47 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   __syncthreads();
   // ---- horizontal sums of every staged row for this thread's 4 bytes
   const uint8_t* sb = reinterpret_cast<const uint8_t*>(stage);
-  for (int r = 0; r < nrows; ++r) {
-    const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + a.H + 4 * t;
-    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int i = -a.left; i <= a.right; ++i) {
-      s0 += row[3 * i]; s1 += row[3 * i + 1]; s2 += row[3 * i + 2]; s3 += row[3 * i + 3];
+  // horizontal sums of staged row r for this thread's 4 bytes: window byte j is staged byte
+  // 4t + j, output byte c sums j = c + 3i, i = 0..k-1
+  auto hsum = [&](int r, unsigned s[4]) {
+    const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + 4 * t;
+    s[0] = s[1] = s[2] = s[3] = 0;
+    for (int i = 0; i < a.k; ++i) {
+      s[0] += row[3 * i]; s[1] += row[3 * i + 1]; s[2] += row[3 * i + 2]; s[3] += row[3 * i + 3];
     }
-    hs[(size_t)r * BL_T + t] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-  }
-  // (each thread reads back only its own sums: no barrier needed)
-  // ---- vertical running sums, divide, store
+  };
+  // ---- vertical running sums, divide, store.  The row that leaves the window is summed again
+  // from the staged bytes rather than kept: only the source rows live in LDS (18 KB for k = 3),
+  // so eight workgroups share a CU and their load phases overlap each other's arithmetic.
   const int b = B0 + 4 * t;  // first byte of this thread within the row
   if (b >= nb) return;
-  unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-  for (int r = 0; r < a.k - 1; ++r) {
-    const uint2 q = hs[(size_t)r * BL_T + t];
-    v0 += q.x & 0xffffu; v1 += q.x >> 16; v2 += q.y & 0xffffu; v3 += q.y >> 16;
-  }
   const int lo = 3 * a.left, hi = 3 * (a.w - a.right);  // interior bytes of a row: [lo, hi)
-  for (int r = 0; r < BL_ROWS; ++r) {
-    const int y = Y0 + r;
+  unsigned v[4] = {0, 0, 0, 0};
+  for (int r = 0; r < nrows; ++r) {
+    unsigned hn[4];
+    hsum(r, hn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += hn[j];
+    const int ro = r - (a.k - 1);  // output row of the tile completed by staged row r
+    if (ro < 0) continue;
+    const int y = Y0 + ro;
     if (y >= a.h) break;
-    const uint2 qn = hs[(size_t)(r + a.k - 1) * BL_T + t];
-    v0 += qn.x & 0xffffu; v1 += qn.x >> 16; v2 += qn.y & 0xffffu; v3 += qn.y >> 16;
     const bool yin = y >= a.left && y < a.h - a.right;
-    unsigned o[4] = {v0 / a.div, v1 / a.div, v2 / a.div, v3 / a.div};
     uint8_t* out = dst + (size_t)y * nb + b;
     unsigned packed = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (yin && b + j >= lo && b + j < hi) packed |= o[j] << (8 * j);
+      if (yin && b + j >= lo && b + j < hi) packed |= (a.magic ? __umulhi(v[j], a.magic) : v[j]) << (8 * j);
     if (b + 3 < nb) {
       typedef unsigned u32u __attribute__((aligned(1)));  // rows start at any byte when 3*w % 4 != 0
       *reinterpret_cast<u32u*>(out) = packed;
     } else {
       for (int j = 0; b + j < nb; ++j) out[j] = (uint8_t)(packed >> (8 * j));
     }
-    const uint2 qo = hs[(size_t)r * BL_T + t];
-    v0 -= qo.x & 0xffffu; v1 -= qo.x >> 16; v2 -= qo.y & 0xffffu; v3 -= qo.y >> 16;
+    unsigned ho[4];
+    hsum(ro, ho);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] -= ho[j];
   }
 }
 
@@ -128,11 +131,15 @@ ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_d
   a.h = h; a.w = w; a.k = kernel_size;
   a.left = (kernel_size + 1) / 2 - 1;  // ceil(k/2.0) - 1
   a.right = kernel_size / 2;
-  a.H = (3 * a.left + 3) / 4 * 4;
-  a.row_dwords = (a.H + BL_TILEB + 3 * a.right + 3 + 3) / 4;
-  a.div = (unsigned)((a.left + a.right + 1) * (a.left + a.right + 1));
+  a.H = 3 * a.left;
+  a.win_dwords = (4 + 3 * (kernel_size - 1) + 3) / 4;
+  a.row_dwords = BL_T + a.win_dwords;  // every thread reads win_dwords dwords from dword t on
+  // k^2 <= 961 and sums <= 961 * 255 < 2^18: with magic = floor(2^32 / d) + 1 the error term
+  // sum * (magic * d - 2^32) <= 2^18 * 961 < 2^32, so umulhi(sum, magic) == sum / d exactly
+  const unsigned div = (unsigned)(kernel_size * kernel_size);
+  a.magic = div == 1 ? 0u : (unsigned)((1ull << 32) / div) + 1u;
   const int nrows = BL_ROWS + kernel_size - 1;
-  const size_t lds = (size_t)nrows * a.row_dwords * 4 + (size_t)nrows * BL_T * sizeof(uint2);
+  const size_t lds = (size_t)nrows * a.row_dwords * 4;
   if (lds > 160 * 1024) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: kernel_size %d needs %zu B of LDS", kernel_size, lds);
   ST_HIP(ctx, hipFuncSetAttribute((const void*)k_box_blur_u8c3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nb = 3 * w;
