@@ -79,7 +79,8 @@ enum st_kernel_id {
   ST_K_FLOW_HIST = 6,
   ST_K_DRAW_FLOW = 7,   /* max-reduction + render launches of one st_draw_flow_batch call */
   ST_K_BLUR_OP = 8,     /* the Blur op's box filter (not the Farneback blur, which is ST_K_BLUR_UPDATE) */
-  ST_K_COUNT = 9
+  ST_K_RESIZE = 9,
+  ST_K_COUNT = 10
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -201,6 +202,16 @@ int st_draw_flow_batch(st_ctx* ctx, const uint8_t* const* frames_dev, const floa
  * Border pixels (which the reference leaves uninitialised) are set to 0.  kernel_size in [1, 31]. */
 int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w,
                            int kernel_size, uint8_t* const* out_dev);
+
+/* Resize: replaces the cv::resize(img, out, Size(out_w, out_h), 0, 0, interpolation) call of
+ * ResizeKernel::execute (scannertools_cpp/imgproc/resize_kernel.cpp:68-73) for U8 frames of 1..4
+ * channels.  interpolation takes cv::InterpolationFlags values; ST_INTER_LINEAR (the op's default,
+ * resize_kernel.cpp:31) and ST_INTER_NEAREST are implemented, others return ST_ERR_UNSUPPORTED.
+ * The target size is the caller's business (ResizeArgs width/height/min/preserve_aspect,
+ * resize_kernel.cpp:44-62, is evaluated by the kernel class). */
+enum st_interpolation { ST_INTER_NEAREST = 0, ST_INTER_LINEAR = 1 };
+int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
+                       int out_h, int out_w, int interpolation, uint8_t* const* out_dev);
 
 #ifdef __cplusplus
 }

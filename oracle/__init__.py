@@ -229,6 +229,26 @@ def box_blur(frame, kernel_size):
     return out
 
 
+INTER_NEAREST, INTER_LINEAR = 0, 1
+
+
+def resize_target(frame_w, frame_h, width=0, height=0, min=False, preserve_aspect=False):
+    """Target (width, height) as ResizeKernel::execute derives it (resize_kernel.cpp:44-62)."""
+    tw, th = ctypes.c_int(), ctypes.c_int()
+    lib().orc_resize_target(frame_w, frame_h, width, height, int(min), int(preserve_aspect), ctypes.byref(tw), ctypes.byref(th))
+    return tw.value, th.value
+
+
+def resize_u8(frame, width, height, interpolation=INTER_LINEAR):
+    """(h,w,c) uint8 -> (height,width,c) uint8: cv::resize restated for 8-bit frames."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, c = frame.shape
+    out = np.empty((height, width, c), np.uint8)
+    if lib().orc_resize_u8(_p(frame), h, w, c, _p(out), height, width, interpolation):
+        raise ValueError("unsupported interpolation %r" % interpolation)
+    return out
+
+
 def shot_boundaries(histograms):
     """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
     each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices

@@ -681,3 +681,104 @@ ORC_API void orc_box_blur_u8c3(const uint8_t* src, int h, int w, int kernel_size
         dst[((size_t)y * w + x) * 3 + c] = (uint8_t)(value / div);
       }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Resize op -- ResizeKernel::execute,
+ * /root/reference/scannertools/scannertools_cpp/imgproc/resize_kernel.cpp:38-88: target size from
+ * ResizeArgs (width/height, preserve_aspect, min), then cv::resize(img, out, Size(w, h), 0, 0,
+ * interpolation) on the U8 frame (default INTER_LINEAR; the legacy flow-histogram pipeline resizes
+ * to 426 x 240, old/histograms.py:64-68).
+ * OpenCV (un-vendored) arithmetic restated for CV_8UC(cn), imgproc/src/resize.cpp:
+ *   INTER_LINEAR : half-pixel centres fx = (float)((dx+0.5)*scale - 0.5); 11-bit fixed-point
+ *                  weights saturate_cast<short>(w * 2048) (round half to even); horizontal pass
+ *                  S[sx]*a0 + S[sx+cn]*a1 in int (single tap * 2048 at the right edge);
+ *                  vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2
+ *                  (VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>); source rows clipped
+ *                  to [0, h-1].  Exact 2x2 decimation is rerouted to INTER_AREA:
+ *                  (S00 + S01 + S10 + S11 + 2) >> 2 (ResizeAreaFastVec).
+ *   INTER_NEAREST: sx = min(floor(dx * scale_x), sw-1), sy likewise (resizeNN).
+ * Equal sizes are a plain copy.  PARITY UNPINNED against real OpenCV output (integer arithmetic,
+ * pinned only by identities: constant images, exact 2x means, separability).
+ * ------------------------------------------------------------------------------------------ */
+static inline short orc_sat_short_round(float v) {
+  long r = lrintf(v);  /* cvRound: round half to even (default FP environment) */
+  return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+ORC_API void orc_resize_target(int fw, int fh, int width, int height, int min_flag, int preserve_aspect, int* tw, int* th) {
+  /* resize_kernel.cpp:44-62 */
+  int target_width = width, target_height = height;
+  if (preserve_aspect) {
+    if (target_width == 0) target_width = fw * target_height / fh;
+    else target_height = fh * target_width / fw;
+  }
+  if (min_flag) {
+    if (fw <= target_width && fh <= target_height) { target_width = fw; target_height = fh; }
+  }
+  *tw = target_width; *th = target_height;
+}
+
+/* interpolation: 0 = INTER_NEAREST, 1 = INTER_LINEAR (cv::InterpolationFlags values) */
+ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int interpolation) {
+  if (interpolation != 0 && interpolation != 1) return 1;
+  if (sh == dh && sw == dw) { memcpy(dst, src, (size_t)sh * sw * cn); return 0; }
+  const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  if (interpolation == 0) {
+    for (int y = 0; y < dh; ++y) {
+      int sy = imin((int)floor(y * scale_y), sh - 1);
+      for (int x = 0; x < dw; ++x) {
+        int sx = imin((int)floor(x * scale_x), sw - 1);
+        for (int c = 0; c < cn; ++c) dst[((size_t)y * dw + x) * cn + c] = src[((size_t)sy * sw + sx) * cn + c];
+      }
+    }
+    return 0;
+  }
+  if (sw == 2 * dw && sh == 2 * dh) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x)
+        for (int c = 0; c < cn; ++c) {
+          const uint8_t* S0 = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+          const uint8_t* S1 = S0 + (size_t)sw * cn;
+          dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((S0[0] + S0[cn] + S1[0] + S1[cn] + 2) >> 2);
+        }
+    return 0;
+  }
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 2 * dw);
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = orc_sat_short_round((1.f - fx) * 2048);
+    ialpha[2 * dx + 1] = orc_sat_short_round(fx * 2048);
+  }
+  int* rows[2];
+  rows[0] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  rows[1] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor_f(fy);
+    fy -= sy;
+    const short b0 = orc_sat_short_round((1.f - fy) * 2048), b1 = orc_sat_short_round(fy * 2048);
+    for (int k = 0; k < 2; ++k) {
+      int yy = imin(imax(sy + k, 0), sh - 1);
+      const uint8_t* S = src + (size_t)yy * sw * cn;
+      for (int dx = 0; dx < dw; ++dx) {
+        int sx = xofs[dx];
+        for (int c = 0; c < cn; ++c) {
+          if (sx + 1 < sw) rows[k][dx * cn + c] = S[sx * cn + c] * ialpha[2 * dx] + S[(sx + 1) * cn + c] * ialpha[2 * dx + 1];
+          else rows[k][dx * cn + c] = S[sx * cn + c] * 2048;
+        }
+      }
+    }
+    uint8_t* D = dst + (size_t)dy * dw * cn;
+    for (int i = 0; i < dw * cn; ++i)
+      D[i] = (uint8_t)((((b0 * (rows[0][i] >> 4)) >> 16) + ((b1 * (rows[1][i] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(rows[0]); free(rows[1]); free(xofs); free(ialpha);
+  return 0;
+}

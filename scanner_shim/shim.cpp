@@ -275,7 +275,12 @@ SHIM_EXPORT void* stshim_kernel_create(const char* op, int device_type, int devi
     for (auto& c : ek->op->inputs) cfg.input_columns.push_back(c.name);
     for (auto& c : ek->op->outputs) cfg.output_columns.push_back(c.name);
   }
-  if (args && n_args) cfg.args.assign(args, args + n_args);
+  // ops declared with stream_protobuf_name() receive their arguments per stream through
+  // new_stream(), the others in KernelConfig::args (protobuf_name())
+  const bool stream_args = ek->op && !ek->op->stream_protobuf_name.empty();
+  std::vector<u8> arg_bytes;
+  if (args && n_args) arg_bytes.assign(args, args + n_args);
+  if (!stream_args) cfg.args = arg_bytes;
   ek->kernel.reset(found->constructor(cfg));
   Result res;
   ek->kernel->validate(&res);
@@ -285,6 +290,7 @@ SHIM_EXPORT void* stshim_kernel_create(const char* op, int device_type, int devi
     return nullptr;
   }
   ek->kernel->reset();
+  if (stream_args) ek->kernel->new_stream(arg_bytes);
   return ek;
 }
 

@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("ST_HIP_LIB") or os.path.join(_HERE, "lib", "libscanne
 CSRC = os.path.join(_HERE, "csrc")
 
 ST_OK, ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_OOM, ST_ERR_UNSUPPORTED = range(5)
-K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_COUNT = range(10)
-KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op"]
+INTER_NEAREST, INTER_LINEAR = 0, 1  # cv::InterpolationFlags values the Resize op implements
+K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_COUNT = range(11)
+KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize"]
 
 
 class StError(RuntimeError):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "st_flow_hist_strided": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
     "st_draw_flow_batch": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _i, _c.POINTER(_vp)]),
     "st_box_blur_u8c3_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _c.POINTER(_vp)]),
+    "st_resize_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
 }
 
 _LIB = None

@@ -7,6 +7,12 @@
 // (the reference leaves the border of its output frame uninitialised; 0 is written here).
 // The O(k^2) per-pixel loop becomes two separable integer running sums (exact: sums are integers,
 // one division at the end), 3 B/px read + 3 B/px written.
+//
+// Resize replaces the cv::resize call of ResizeKernel::execute
+// (/root/reference/scannertools/scannertools_cpp/imgproc/resize_kernel.cpp:68-73) for U8 frames:
+// INTER_LINEAR (OpenCV's 11-bit fixed-point weights and its two-stage integer rounding, exact 2x2
+// decimation rerouted to the INTER_AREA mean) and INTER_NEAREST; arithmetic as restated in
+// oracle/oracle.c (orc_resize_u8), one thread per output pixel, weights recomputed per thread.
 #include "st_internal.h"
 
 namespace {
@@ -106,6 +112,66 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   }
 }
 
+// ---- Resize -------------------------------------------------------------------------------------
+enum { RS_NEAREST = 0, RS_LINEAR = 1, RS_AREA2 = 2, RS_COPY = 3 };
+
+struct ResizeArgsK {
+  const uint8_t* const* src;
+  uint8_t* const* dst;
+  int sh, sw, dh, dw, cn, mode;
+  double scale_x, scale_y;  // source / destination size ratios as cv::resize computes them
+};
+
+// saturate_cast<short>(float): cvRound = round half to even, then saturation
+__device__ __forceinline__ int rs_coef(float v) {
+  const float r = rintf(v);
+  return r < -32768.f ? -32768 : (r > 32767.f ? 32767 : (int)r);
+}
+
+__global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= a.dw) return;
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ D = a.dst[blockIdx.z] + ((size_t)dy * a.dw + dx) * a.cn;
+  const int cn = a.cn;
+  const size_t srow = (size_t)a.sw * cn;
+  if (a.mode == RS_COPY) {
+    const uint8_t* S = src + (size_t)dy * srow + (size_t)dx * cn;
+    for (int c = 0; c < cn; ++c) D[c] = S[c];
+  } else if (a.mode == RS_NEAREST) {
+    int sx = (int)floor(dx * a.scale_x), sy = (int)floor(dy * a.scale_y);
+    sx = sx < a.sw - 1 ? sx : a.sw - 1;
+    sy = sy < a.sh - 1 ? sy : a.sh - 1;
+    const uint8_t* S = src + (size_t)sy * srow + (size_t)sx * cn;
+    for (int c = 0; c < cn; ++c) D[c] = S[c];
+  } else if (a.mode == RS_AREA2) {
+    const uint8_t* S0 = src + (size_t)(2 * dy) * srow + (size_t)(2 * dx) * cn;
+    const uint8_t* S1 = S0 + srow;
+    for (int c = 0; c < cn; ++c) D[c] = (uint8_t)((S0[c] + S0[cn + c] + S1[c] + S1[cn + c] + 2) >> 2);
+  } else {
+    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; }
+    const int a0 = rs_coef((1.f - fx) * 2048), a1 = rs_coef(fx * 2048);
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const int b0 = rs_coef((1.f - fy) * 2048), b1 = rs_coef(fy * 2048);
+    const int y0 = sy < 0 ? 0 : (sy > a.sh - 1 ? a.sh - 1 : sy);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > a.sh - 1 ? a.sh - 1 : sy + 1);
+    const uint8_t* S0 = src + (size_t)y0 * srow + (size_t)sx * cn;
+    const uint8_t* S1 = src + (size_t)y1 * srow + (size_t)sx * cn;
+    const bool two = sx + 1 < a.sw;  // the right edge takes a single tap * 2048
+    for (int c = 0; c < cn; ++c) {
+      const int r0 = two ? S0[c] * a0 + S0[cn + c] * a1 : S0[c] * 2048;
+      const int r1 = two ? S1[c] * a0 + S1[cn + c] * a1 : S1[c] * 2048;
+      D[c] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+  }
+}
+
 }  // namespace
 
 ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int kernel_size,
@@ -150,6 +216,43 @@ ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_d
     if (grid.y > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: frame too tall");
     st_timed t(ctx, ST_K_BLUR_OP);
     hipLaunchKernelGGL(k_box_blur_u8c3, grid, dim3(BL_T), lds, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+
+ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
+                                 int out_h, int out_w, int interpolation, uint8_t* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0 || channels < 1 || channels > 4 ||
+      (long long)h * w > 200000000LL || (long long)out_h * out_w > 200000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "resize: bad arguments (n=%d %dx%dx%d -> %dx%d)", n, h, w, channels, out_h, out_w);
+  if (interpolation != ST_INTER_NEAREST && interpolation != ST_INTER_LINEAR)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: interpolation %d (INTER_NEAREST = 0 and INTER_LINEAR = 1 are implemented)", interpolation);
+  if (out_h > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: output taller than 65535 rows");
+  if (n == 0) return ST_OK;
+  if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "resize: null argument");
+  for (int i = 0; i < n; ++i)
+    if (!frames_dev[i] || !out_dev[i] || frames_dev[i] == out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "resize: row %d is null or aliased", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const uint8_t** d_src = (const uint8_t**)st_ws_alloc(ctx, tb);
+  uint8_t** d_dst = (uint8_t**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ResizeArgsK a;
+  a.sh = h; a.sw = w; a.dh = out_h; a.dw = out_w; a.cn = channels;
+  const double inv_sx = (double)out_w / w, inv_sy = (double)out_h / h;
+  a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
+  if (h == out_h && w == out_w) a.mode = RS_COPY;
+  else if (interpolation == ST_INTER_NEAREST) a.mode = RS_NEAREST;
+  else if (w == 2 * out_w && h == 2 * out_h) a.mode = RS_AREA2;
+  else a.mode = RS_LINEAR;
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.src = d_src + f0; a.dst = d_dst + f0;
+    st_timed t(ctx, ST_K_RESIZE);
+    hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;

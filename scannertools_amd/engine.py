@@ -12,7 +12,7 @@ installable here, so this module reproduces exactly that surface for in-memory f
     out = NamedStream(sc, 'hist'); sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
     next(out.load())
 
-C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``, ``Blur``) are looked up in the kernel registry of
+C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``, ``Blur``, ``Resize``) are looked up in the kernel registry of
 ``libscannertools_imgproc.so`` and executed by its mini engine (scanner_shim/shim.cpp): the same
 ``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``, ``DrawFlow``) are the
 functions of this package.  What is deliberately absent: the database, video decode, the
@@ -392,6 +392,15 @@ class _Ops:
         from . import _proto
         args = _proto.encode([(1, "int32", int(kernel_size)), (2, "float", float(sigma))])
         return _CppOpNode(self.sc, "Blur", frame, device, batch, None, args)
+
+    def Resize(self, frame, width=0, height=0, min=False, preserve_aspect=False, interpolation="", device=None,
+               batch=None):
+        """db.ops.Resize(frame=..., width=426, height=240, device=...) (old/histograms.py:64-68); the
+        keyword arguments are the fields of the per-stream ResizeArgs message."""
+        from . import _proto
+        args = _proto.encode([(1, "int32", int(width)), (2, "int32", int(height)), (3, "bool", bool(min)),
+                              (4, "bool", bool(preserve_aspect)), (5, "string", interpolation)])
+        return _CppOpNode(self.sc, "Resize", frame, device, batch, None, args)
 
     def FlowHistogram(self, flow, device=None, batch=None):
         """db.ops.FlowHistogram(flow=flow, device=DeviceType.CPU) (old/histograms.py:74-77)."""

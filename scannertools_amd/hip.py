@@ -205,6 +205,26 @@ class HipContext:
         self._check(self._L.st_box_blur_u8c3_batch(self._h, tf, n, h, w, int(kernel_size), to))
         return out
 
+    def resize(self, frames, width, height, interpolation=_native.INTER_LINEAR, out=None):
+        """Resize op (resize_kernel.cpp:68-73): (n,h,w,c) uint8 frames (a tensor or a list of (h,w,c)
+        tensors) -> (n,height,width,c) uint8, cv::resize semantics for 8-bit frames."""
+        self._bind()
+        fr = list(frames) if isinstance(frames, (list, tuple)) else list(frames.unbind(0))
+        n = len(fr)
+        if n == 0:
+            return torch.zeros((0, height, width, 3), dtype=torch.uint8, device=self.device)
+        h, w, c = fr[0].shape
+        for f in fr:
+            _require_cuda(f, torch.uint8, "frame")
+            if tuple(f.shape) != (h, w, c):
+                raise ValueError("all frames must have the same (h,w,c) shape")
+        if out is None:
+            out = torch.empty((n, height, width, c), dtype=torch.uint8, device=self.device)
+        tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_resize_u8_batch(self._h, tf, n, h, w, c, int(height), int(width), int(interpolation), to))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.

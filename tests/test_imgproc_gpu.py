@@ -78,3 +78,79 @@ def test_blur_op_like_the_reference_test(device):
     for i, f in enumerate(loaded):
         np.testing.assert_array_equal(f, oracle.box_blur(frames[i], 3))
     assert sc.live_device_buffers() == 0
+
+
+# ---- Resize ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sh,sw,dh,dw", [(480, 640, 240, 426), (1080, 1920, 240, 426), (48, 64, 24, 32),
+                                         (37, 53, 80, 91), (100, 100, 1, 1), (9, 7, 9, 7), (64, 48, 16, 12),
+                                         (33, 47, 66, 94), (240, 426, 1080, 1920)])
+def test_resize_linear_matches_oracle(hip_ctx, sh, sw, dh, dw):
+    """Down- and up-scaling, the legacy pipeline's 426x240, exact 2x (INTER_AREA mean), exact 4x
+    (stays linear), identity."""
+    frames = random_frames(sh + sw + dh, 2, sh, sw)
+    got = hip_ctx.resize(torch.from_numpy(frames).cuda(), dw, dh).cpu().numpy()
+    assert got.shape == (2, dh, dw, 3) and got.dtype == np.uint8
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh))
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_resize_channels_nearest_and_identities(hip_ctx, cn):
+    from scannertools_amd._native import INTER_NEAREST, StError
+    rng = np.random.default_rng(cn)
+    f = rng.integers(0, 256, (2, 90, 120, cn), dtype=np.uint8)
+    for (dw, dh) in ((50, 40), (240, 180), (60, 45)):
+        got = hip_ctx.resize(torch.from_numpy(f).cuda(), dw, dh).cpu().numpy()
+        np.testing.assert_array_equal(got[1], oracle.resize_u8(f[1], dw, dh))
+        got = hip_ctx.resize(torch.from_numpy(f).cuda(), dw, dh, INTER_NEAREST).cpu().numpy()
+        np.testing.assert_array_equal(got[0], oracle.resize_u8(f[0], dw, dh, oracle.INTER_NEAREST))
+    const = np.full((1, 33, 71, cn), 201, np.uint8)
+    assert (hip_ctx.resize(torch.from_numpy(const).cuda(), 19, 100).cpu().numpy() == 201).all()
+    with pytest.raises(StError):
+        hip_ctx.resize(torch.from_numpy(f).cuda(), 10, 10, interpolation=2)      # INTER_CUBIC: not implemented
+
+
+@pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
+def test_legacy_flow_histogram_pipeline(device):
+    """old/histograms.py:63-78: Resize(426x240) -> OpticalFlow -> FlowHistogram, every stage checked."""
+    sc = Client()
+    frames, _ = texture_stream(11, 6, 480, 640, max_step=4)
+    sc.ingest_frames('v', frames)
+    frame = sc.io.Input([NamedVideoStream(sc, 'v')])
+    small = sc.ops.Resize(frame=frame, width=426, height=240, device=device, batch=4)
+    flow = sc.ops.OpticalFlow(frame=small, device=device, batch=4)
+    fh = sc.ops.FlowHistogram(flow=flow, device=device)
+    from scannertools_amd.engine import NamedStream
+    o_small, o_flow, o_fh = NamedStream(sc, 's'), NamedStream(sc, 'f'), NamedStream(sc, 'h')
+    sc.run([sc.io.Output(small, [o_small]), sc.io.Output(flow, [o_flow]), sc.io.Output(fh, [o_fh])],
+           PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    smalls = list(o_small.load())
+    assert len(smalls) == 6 and smalls[0].shape == (240, 426, 3)
+    for i, s in enumerate(smalls):
+        np.testing.assert_array_equal(s, oracle.resize_u8(frames[i], 426, 240))
+    for i, (fl, h) in enumerate(zip(o_flow.load(), o_fh.load())):
+        ref = oracle.optical_flow_rgb(smalls[i], smalls[min(i + 1, 5)])
+        assert np.abs(fl - ref).max() <= 5e-3
+        np.testing.assert_array_equal(np.stack(h), oracle.flow_hist(fl))
+
+
+def test_resize_op_target_size_rules():
+    """preserve_aspect / min of ResizeArgs (resize_kernel.cpp:44-62) through the kernel class."""
+    sc = Client()
+    frames = random_frames(1, 3, 120, 200)
+    sc.ingest_frames('v', frames)
+    frame = sc.io.Input([NamedVideoStream(sc, 'v')])
+    from scannertools_amd.engine import NamedStream
+    cases = [dict(width=100, height=0, preserve_aspect=True), dict(width=0, height=30, preserve_aspect=True),
+             dict(width=400, height=300, min=True), dict(width=50, height=60, min=True),
+             dict(width=64, height=32, interpolation="INTER_NEAREST")]
+    for i, kw in enumerate(cases):
+        out = NamedStream(sc, 'r%d' % i)
+        sc.run(sc.io.Output(sc.ops.Resize(frame=frame, device=DeviceType.GPU, **kw), [out]), PerfParams.estimate(),
+               cache_mode=CacheMode.Overwrite)
+        tw, th = oracle.resize_target(200, 120, kw.get("width", 0), kw.get("height", 0), kw.get("min", False),
+                                      kw.get("preserve_aspect", False))
+        interp = oracle.INTER_NEAREST if kw.get("interpolation") == "INTER_NEAREST" else oracle.INTER_LINEAR
+        for j, got in enumerate(out.load()):
+            assert got.shape == (th, tw, 3)
+            np.testing.assert_array_equal(got, oracle.resize_u8(frames[j], tw, th, interp))

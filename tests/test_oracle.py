@@ -182,3 +182,30 @@ def test_box_blur_oracle_matches_definition():
                 win = f[y - left:y + right + 1, x - left:x + right + 1].astype(np.uint32).sum((0, 1))
                 ref[y, x] = win // ((left + right + 1) ** 2)
         np.testing.assert_array_equal(oracle.box_blur(f, k), ref)
+
+
+def test_resize_oracle_identities():
+    """cv::resize restatement for 8-bit frames: constants are preserved by the fixed-point
+    arithmetic, exact 2x decimation is the rounded 2x2 mean, nearest picks floor(x*scale), identity
+    copies, target-size rules of the Resize kernel."""
+    rng = np.random.default_rng(0)
+    f = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    const = np.full((48, 64, 3), 137, np.uint8)
+    for (w, h) in ((32, 24), (21, 13), (100, 77), (64, 48), (53, 30), (1, 1)):
+        assert (oracle.resize_u8(const, w, h) == 137).all()
+        assert oracle.resize_u8(f, w, h).shape == (h, w, 3)
+    ref = ((f[0::2, 0::2].astype(int) + f[0::2, 1::2] + f[1::2, 0::2] + f[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    np.testing.assert_array_equal(oracle.resize_u8(f, 32, 24), ref)
+    np.testing.assert_array_equal(oracle.resize_u8(f, 64, 48), f)
+    near = oracle.resize_u8(f, 20, 10, oracle.INTER_NEAREST)
+    np.testing.assert_array_equal(near, f[(np.arange(10) * 4.8).astype(int)][:, (np.arange(20) * 3.2).astype(int)])
+    # a horizontal ramp stays monotone and inside the source range when up-scaled
+    ramp = np.tile(np.arange(64, dtype=np.uint8)[None, :, None] * 4, (8, 1, 3))
+    up = oracle.resize_u8(ramp, 256, 8)
+    assert (np.diff(up[0, :, 0].astype(int)) >= 0).all() and up.min() == 0 and up.max() == 252
+    assert oracle.resize_target(1920, 1080, width=426, height=240) == (426, 240)
+    assert oracle.resize_target(1920, 1080, width=0, height=240, preserve_aspect=True) == (426, 240)
+    assert oracle.resize_target(1920, 1080, width=426, height=0, preserve_aspect=True) == (426, 239)
+    assert oracle.resize_target(320, 200, width=426, height=240, min=True) == (320, 200)
+    with pytest.raises(ValueError):
+        oracle.resize_u8(f, 10, 10, 2)
