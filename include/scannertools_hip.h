@@ -80,7 +80,8 @@ enum st_kernel_id {
   ST_K_DRAW_FLOW = 7,   /* max-reduction + render launches of one st_draw_flow_batch call */
   ST_K_BLUR_OP = 8,     /* the Blur op's box filter (not the Farneback blur, which is ST_K_BLUR_UPDATE) */
   ST_K_RESIZE = 9,
-  ST_K_COUNT = 10
+  ST_K_CVT_COLOR = 10,
+  ST_K_COUNT = 11
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -212,6 +213,22 @@ int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n,
 enum st_interpolation { ST_INTER_NEAREST = 0, ST_INTER_LINEAR = 1 };
 int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                        int out_h, int out_w, int interpolation, uint8_t* const* out_dev);
+
+/* ConvertColor: replaces the cv::cvtColor(img, out, code) call of ConvertColorKernel::execute
+ * (scannertools_cpp/imgproc/convert_color_kernel.cpp:268-271) for U8 frames.  code takes
+ * cv::ColorConversionCodes values; implemented: the ones below (the reference's name table at
+ * convert_color_kernel.cpp:10-209 lists many more, which return ST_ERR_UNSUPPORTED).  gray_bits
+ * selects the luma table width as in st_fb_params (15: OpenCV 4.x, 14: <= 3.4.2).
+ * st_cvt_color_out_channels() gives the channel count of the output frame (-1: unsupported). */
+enum st_color_code {
+  ST_COLOR_BGR2RGB = 4, ST_COLOR_RGB2BGR = 4,
+  ST_COLOR_BGR2GRAY = 6, ST_COLOR_RGB2GRAY = 7,
+  ST_COLOR_GRAY2BGR = 8, ST_COLOR_GRAY2RGB = 8,
+  ST_COLOR_BGR2HSV = 40
+};
+int st_cvt_color_out_channels(int code, int in_channels);
+int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
+                          int code, int gray_bits, uint8_t* const* out_dev);
 
 #ifdef __cplusplus
 }

@@ -249,6 +249,21 @@ def resize_u8(frame, width, height, interpolation=INTER_LINEAR):
     return out
 
 
+COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR, COLOR_GRAY2RGB, COLOR_BGR2HSV = 4, 4, 6, 7, 8, 8, 40
+
+
+def cvt_color(frame, code, gray_bits=15):
+    """(h,w,c) uint8 -> (h,w,c') uint8: cv::cvtColor restated for the codes above."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, c = frame.shape
+    oc = lib().orc_cvt_out_channels(int(code), c)
+    if oc < 0:
+        raise ValueError("unsupported conversion %r for %d channels" % (code, c))
+    out = np.empty((h, w, oc), np.uint8)
+    assert lib().orc_cvt_color_u8(_p(frame), h, w, c, int(code), gray_bits, _p(out)) == 0
+    return out
+
+
 def shot_boundaries(histograms):
     """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
     each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices

@@ -782,3 +782,71 @@ ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* d
   free(rows[0]); free(rows[1]); free(xofs); free(ialpha);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * ConvertColor op -- ConvertColorKernel::execute,
+ * /root/reference/scannertools/scannertools_cpp/imgproc/convert_color_kernel.cpp:252-285:
+ * cv::cvtColor(img, out, code) on U8 frames, code chosen by name from the table at :10-209.
+ * Restated codes (cv::ColorConversionCodes values): BGR2RGB/RGB2BGR (4), BGR2GRAY (6),
+ * RGB2GRAY (7), GRAY2BGR/GRAY2RGB (8), BGR2HSV (40).  8-bit arithmetic of OpenCV
+ * (imgproc/src/color*.cpp): gray = (c_b*B + c_g*G + c_r*R + half) >> bits with the 14/15-bit
+ * tables of orc_gray_u8; RGB2HSV_b with hsv_shift = 12: v = max, s = (diff*sdiv[v] + 2^11) >> 12,
+ * h = sector offset + difference, scaled by hdiv180[diff], +180 if negative, where
+ * sdiv[i] = cvRound((255 << 12)/(1.*i)), hdiv180[i] = cvRound((180 << 12)/(6.*i)), both 0 at i = 0.
+ * PARITY UNPINNED against real OpenCV output (integer arithmetic; pinned by primaries, grays and
+ * hue-sector identities in tests/).
+ * ------------------------------------------------------------------------------------------ */
+enum { ORC_BGR2RGB = 4, ORC_BGR2GRAY = 6, ORC_RGB2GRAY = 7, ORC_GRAY2BGR = 8, ORC_BGR2HSV = 40 };
+
+ORC_API int orc_cvt_out_channels(int code, int in_channels) {
+  switch (code) {
+    case ORC_BGR2RGB: return in_channels == 3 ? 3 : -1;
+    case ORC_BGR2GRAY: case ORC_RGB2GRAY: return in_channels == 3 ? 1 : -1;
+    case ORC_GRAY2BGR: return in_channels == 1 ? 3 : -1;
+    case ORC_BGR2HSV: return in_channels == 3 ? 3 : -1;
+    default: return -1;
+  }
+}
+
+ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code, int gray_bits, uint8_t* dst) {
+  if (orc_cvt_out_channels(code, cn) < 0) return 1;
+  const size_t n = (size_t)h * w;
+  if (code == ORC_BGR2RGB) {
+    for (size_t i = 0; i < n; ++i) { dst[3 * i] = src[3 * i + 2]; dst[3 * i + 1] = src[3 * i + 1]; dst[3 * i + 2] = src[3 * i]; }
+  } else if (code == ORC_BGR2GRAY || code == ORC_RGB2GRAY) {
+    int cb, cg, cr, bits = gray_bits;
+    if (bits == 14) { cb = 1868; cg = 9617; cr = 4899; } else { bits = 15; cb = 3735; cg = 19235; cr = 9798; }
+    const int rnd = 1 << (bits - 1);
+    const int bi = code == ORC_BGR2GRAY ? 0 : 2;  /* byte holding blue */
+    for (size_t i = 0; i < n; ++i)
+      dst[i] = (uint8_t)((src[3 * i + bi] * cb + src[3 * i + 1] * cg + src[3 * i + (bi ^ 2)] * cr + rnd) >> bits);
+  } else if (code == ORC_GRAY2BGR) {
+    for (size_t i = 0; i < n; ++i) dst[3 * i] = dst[3 * i + 1] = dst[3 * i + 2] = src[i];
+  } else {  /* BGR2HSV, hrange 180 */
+    const int hsv_shift = 12;
+    int sdiv[256], hdiv[256];
+    sdiv[0] = hdiv[0] = 0;
+    for (int i = 1; i < 256; ++i) {
+      sdiv[i] = (int)lrint((255 << hsv_shift) / (1. * i));
+      hdiv[i] = (int)lrint((180 << hsv_shift) / (6. * i));
+    }
+    for (size_t i = 0; i < n; ++i) {
+      const int b = src[3 * i], g = src[3 * i + 1], r = src[3 * i + 2];
+      int v = b, vmin = b;
+      if (g > v) v = g;
+      if (r > v) v = r;
+      if (g < vmin) vmin = g;
+      if (r < vmin) vmin = r;
+      const int diff = v - vmin;
+      const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+      const int s = (diff * sdiv[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
+      int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+      hh = (hh * hdiv[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
+      hh += hh < 0 ? 180 : 0;
+      dst[3 * i] = (uint8_t)(hh < 0 ? 0 : (hh > 255 ? 255 : hh));
+      dst[3 * i + 1] = (uint8_t)s;
+      dst[3 * i + 2] = (uint8_t)v;
+    }
+  }
+  return 0;
+}

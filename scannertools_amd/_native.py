@@ -14,8 +14,11 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ST_OK, ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_OOM, ST_ERR_UNSUPPORTED = range(5)
 INTER_NEAREST, INTER_LINEAR = 0, 1  # cv::InterpolationFlags values the Resize op implements
-K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_COUNT = range(11)
-KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize"]
+# cv::ColorConversionCodes values the ConvertColor op implements
+COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COLOR_RGB2GRAY": 7,
+               "COLOR_GRAY2BGR": 8, "COLOR_GRAY2RGB": 8, "COLOR_BGR2HSV": 40}
+K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_COUNT = range(12)
+KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color"]
 
 
 class StError(RuntimeError):
@@ -71,6 +74,8 @@ SIGNATURES = {
     "st_draw_flow_batch": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _i, _c.POINTER(_vp)]),
     "st_box_blur_u8c3_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _c.POINTER(_vp)]),
     "st_resize_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
+    "st_cvt_color_out_channels": (_i, [_i, _i]),
+    "st_cvt_color_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
 }
 
 _LIB = None

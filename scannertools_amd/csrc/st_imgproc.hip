@@ -13,6 +13,11 @@
 // INTER_LINEAR (OpenCV's 11-bit fixed-point weights and its two-stage integer rounding, exact 2x2
 // decimation rerouted to the INTER_AREA mean) and INTER_NEAREST; arithmetic as restated in
 // oracle/oracle.c (orc_resize_u8), one thread per output pixel, weights recomputed per thread.
+//
+// ConvertColor replaces the cv::cvtColor call of ConvertColorKernel::execute
+// (/root/reference/scannertools/scannertools_cpp/imgproc/convert_color_kernel.cpp:268-271) for the
+// 8-bit codes BGR2RGB/RGB2BGR, BGR2GRAY, RGB2GRAY, GRAY2BGR/GRAY2RGB and BGR2HSV (OpenCV's
+// integer tables, oracle/oracle.c orc_cvt_color_u8).
 #include "st_internal.h"
 
 namespace {
@@ -172,6 +177,52 @@ __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
   }
 }
 
+// ---- ConvertColor ---------------------------------------------------------------------------------
+struct CvtArgsK {
+  const uint8_t* const* src;
+  uint8_t* const* dst;
+  long long npix;
+  int code;                // cv::ColorConversionCodes value
+  int cb, cg, cr, rnd, shift, bi;  // gray weights (bi = byte holding blue)
+};
+
+__global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
+  __shared__ int sdiv[256], hdiv[256];
+  const int t = threadIdx.x;
+  if (a.code == ST_COLOR_BGR2HSV) {
+    // RGB2HSV_b tables: saturate_cast<int>((255 << 12)/(1.*i)), saturate_cast<int>((180 << 12)/(6.*i))
+    sdiv[t] = t ? (int)rint((255 << 12) / (1. * t)) : 0;
+    hdiv[t] = t ? (int)rint((180 << 12) / (6. * t)) : 0;
+    __syncthreads();
+  }
+  const uint8_t* __restrict__ src = a.src[blockIdx.y];
+  uint8_t* __restrict__ dst = a.dst[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + t; i < a.npix; i += (long long)gridDim.x * 256) {
+    if (a.code == ST_COLOR_BGR2RGB) {
+      const uint8_t c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
+      dst[3 * i] = c2; dst[3 * i + 1] = c1; dst[3 * i + 2] = c0;
+    } else if (a.code == ST_COLOR_BGR2GRAY || a.code == ST_COLOR_RGB2GRAY) {
+      const int b = src[3 * i + a.bi], g = src[3 * i + 1], r = src[3 * i + (a.bi ^ 2)];
+      dst[i] = (uint8_t)((b * a.cb + g * a.cg + r * a.cr + a.rnd) >> a.shift);
+    } else if (a.code == ST_COLOR_GRAY2BGR) {
+      const uint8_t v = src[i];
+      dst[3 * i] = v; dst[3 * i + 1] = v; dst[3 * i + 2] = v;
+    } else {  // BGR2HSV, hue range 180
+      const int b = src[3 * i], g = src[3 * i + 1], r = src[3 * i + 2];
+      const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+      const int diff = v - vmin;
+      const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+      const int sv = (diff * sdiv[v] + (1 << 11)) >> 12;
+      int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+      hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+      hh += hh < 0 ? 180 : 0;
+      dst[3 * i] = (uint8_t)(hh < 0 ? 0 : (hh > 255 ? 255 : hh));
+      dst[3 * i + 1] = (uint8_t)sv;
+      dst[3 * i + 2] = (uint8_t)v;
+    }
+  }
+}
+
 }  // namespace
 
 ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int kernel_size,
@@ -253,6 +304,50 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
     a.src = d_src + f0; a.dst = d_dst + f0;
     st_timed t(ctx, ST_K_RESIZE);
     hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+
+ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
+  switch (code) {
+    case ST_COLOR_BGR2RGB: case ST_COLOR_BGR2HSV: return in_channels == 3 ? 3 : -1;
+    case ST_COLOR_BGR2GRAY: case ST_COLOR_RGB2GRAY: return in_channels == 3 ? 1 : -1;
+    case ST_COLOR_GRAY2BGR: return in_channels == 1 ? 3 : -1;
+    default: return -1;
+  }
+}
+
+ST_EXPORT int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
+                                    int code, int gray_bits, uint8_t* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || h <= 0 || w <= 0 || (long long)h * w > 200000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: bad arguments (n=%d h=%d w=%d)", n, h, w);
+  if (st_cvt_color_out_channels(code, channels) < 0)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "cvt_color: conversion code %d on %d-channel frames is not implemented", code, channels);
+  if (gray_bits != 14 && gray_bits != 15) return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: gray_bits must be 14 or 15");
+  if (n == 0) return ST_OK;
+  if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: null argument");
+  for (int i = 0; i < n; ++i)
+    if (!frames_dev[i] || !out_dev[i] || frames_dev[i] == out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: row %d is null or aliased", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const uint8_t** d_src = (const uint8_t**)st_ws_alloc(ctx, tb);
+  uint8_t** d_dst = (uint8_t**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  CvtArgsK a;
+  a.npix = (long long)h * w; a.code = code;
+  if (gray_bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }
+  a.shift = gray_bits; a.rnd = 1 << (gray_bits - 1);
+  a.bi = code == ST_COLOR_RGB2GRAY ? 2 : 0;
+  long long bx = (a.npix + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.src = d_src + f0; a.dst = d_dst + f0;
+    st_timed t(ctx, ST_K_CVT_COLOR);
+    hipLaunchKernelGGL(k_cvt_color_u8, dim3((unsigned)bx, nf), dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;

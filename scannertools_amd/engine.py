@@ -12,7 +12,7 @@ installable here, so this module reproduces exactly that surface for in-memory f
     out = NamedStream(sc, 'hist'); sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
     next(out.load())
 
-C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``, ``Blur``, ``Resize``) are looked up in the kernel registry of
+C++ ops (``Histogram``, ``OpticalFlow``, ``FlowHistogram``, ``Blur``, ``Resize``, ``ConvertColor``) are looked up in the kernel registry of
 ``libscannertools_imgproc.so`` and executed by its mini engine (scanner_shim/shim.cpp): the same
 ``execute()`` bodies a real Scanner worker would call.  Python ops (``ShotBoundaries``, ``DrawFlow``) are the
 functions of this package.  What is deliberately absent: the database, video decode, the
@@ -401,6 +401,12 @@ class _Ops:
         args = _proto.encode([(1, "int32", int(width)), (2, "int32", int(height)), (3, "bool", bool(min)),
                               (4, "bool", bool(preserve_aspect)), (5, "string", interpolation)])
         return _CppOpNode(self.sc, "Resize", frame, device, batch, None, args)
+
+    def ConvertColor(self, frame, conversion, device=None, batch=None):
+        """sc.ops.ConvertColor(frame=..., conversion='COLOR_RGB2GRAY', device=...): the keyword is the
+        field of the per-stream ConvertColorArgs message (convert_color_kernel.cpp:224-241)."""
+        from . import _proto
+        return _CppOpNode(self.sc, "ConvertColor", frame, device, batch, None, _proto.encode([(1, "string", conversion)]))
 
     def FlowHistogram(self, flow, device=None, batch=None):
         """db.ops.FlowHistogram(flow=flow, device=DeviceType.CPU) (old/histograms.py:74-77)."""

@@ -225,6 +225,33 @@ class HipContext:
         self._check(self._L.st_resize_u8_batch(self._h, tf, n, h, w, c, int(height), int(width), int(interpolation), to))
         return out
 
+    def cvt_color(self, frames, code, gray_bits=15, out=None):
+        """ConvertColor op (convert_color_kernel.cpp:268-271): cv::cvtColor on (n,h,w,c) uint8 frames;
+        ``code`` is a cv::ColorConversionCodes value or one of the names in _native.COLOR_CODES."""
+        self._bind()
+        if isinstance(code, str):
+            if code not in _native.COLOR_CODES:
+                raise ValueError("conversion %r is not implemented" % code)
+            code = _native.COLOR_CODES[code]
+        fr = list(frames) if isinstance(frames, (list, tuple)) else list(frames.unbind(0))
+        n = len(fr)
+        if n == 0:
+            return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
+        h, w, c = fr[0].shape
+        for f in fr:
+            _require_cuda(f, torch.uint8, "frame")
+            if tuple(f.shape) != (h, w, c):
+                raise ValueError("all frames must have the same (h,w,c) shape")
+        oc = self._L.st_cvt_color_out_channels(int(code), c)
+        if oc < 0:
+            raise ValueError("conversion code %d on %d-channel frames is not implemented" % (code, c))
+        if out is None:
+            out = torch.empty((n, h, w, oc), dtype=torch.uint8, device=self.device)
+        tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cvt_color_u8_batch(self._h, tf, n, h, w, c, int(code), int(gray_bits), to))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.

@@ -1,0 +1,134 @@
+// ConvertColor op for Scanner on MI355X.
+//
+// Drop-in for the reference's kernel
+//   ConvertColorKernel  /root/reference/scannertools/scannertools_cpp/imgproc/convert_color_kernel.cpp:213-309
+// Same op declaration (frame_input("frame") -> frame_output("frame"),
+// stream_protobuf_name("ConvertColorArgs")), same per-stream argument (ConvertColorArgs{conversion = 1},
+// scannertools_imgproc.proto:29-31: the name of a cv::ColorConversionCodes constant).  The per-frame
+// cv::cvtColor / cvc::cvtColor calls are replaced by ONE st_cvt_color_u8_batch() call per execute().
+// Implemented names: COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR,
+// COLOR_GRAY2RGB, COLOR_BGR2HSV; an unknown name invalidates the stream as in the reference
+// (:231-236), a name of the reference's table that is not implemented here is reported the same way
+// instead of being run on the CPU.  SCANNERTOOLS_GRAY_BITS (15 default, 14) selects the luma table
+// width of the OpenCV build being replaced.
+#include <cstdlib>
+#include <map>
+
+#include "scanner/api/kernel.h"
+#include "scanner/api/op.h"
+#include "scanner/util/hip.h"
+#include "scanner/util/memory.h"
+#include "proto_lite.h"
+#include "scannertools_hip.h"
+#include "stage.h"
+
+namespace scanner {
+namespace {
+const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
+    {u8"COLOR_BGR2RGB", ST_COLOR_BGR2RGB},   {u8"COLOR_RGB2BGR", ST_COLOR_RGB2BGR},
+    {u8"COLOR_BGR2GRAY", ST_COLOR_BGR2GRAY}, {u8"COLOR_RGB2GRAY", ST_COLOR_RGB2GRAY},
+    {u8"COLOR_GRAY2BGR", ST_COLOR_GRAY2BGR}, {u8"COLOR_GRAY2RGB", ST_COLOR_GRAY2RGB},
+    {u8"COLOR_BGR2HSV", ST_COLOR_BGR2HSV},
+};
+}
+
+template <bool STAGED>
+class ConvertColorKernelHIPImpl : public BatchedKernel {
+ public:
+  ConvertColorKernelHIPImpl(const KernelConfig& config)
+    : BatchedKernel(config), device_(config.devices[0]), gpu_(STAGED ? staging_device_id() : config.devices[0].id),
+      stage_(gpu_) {
+    valid_.set_success(true);
+    const char* gb = getenv("SCANNERTOOLS_GRAY_BITS");
+    gray_bits_ = gb && atoi(gb) == 14 ? 14 : 15;
+    if (!STAGED && device_.type != DeviceType::GPU) {
+      RESULT_ERROR(&valid_, "ConvertColorKernelHIP runs on DeviceType::GPU only");
+      return;
+    }
+    int st = st_ctx_create(gpu_, &ctx_);
+    if (st != ST_OK) RESULT_ERROR(&valid_, "st_ctx_create(%d) failed: %s (no CPU fallback exists)", gpu_, st_status_string(st));
+  }
+  ~ConvertColorKernelHIPImpl() {
+    if (ctx_) st_ctx_destroy(ctx_);
+  }
+  void validate(Result* result) override {
+    result->set_msg(valid_.msg());
+    result->set_success(valid_.success());
+  }
+
+  void new_stream(const std::vector<u8>& args) override {
+    std::vector<proto_lite::Field> fields;
+    std::string conversion;
+    if (proto_lite::parse(args.data(), args.size(), &fields))
+      for (auto& f : fields)
+        if (f.number == 1 && f.wire == 2) conversion = f.bytes;
+    if (COLOR_CONVERSION_TYPES.count(conversion) > 0) {
+      code_ = COLOR_CONVERSION_TYPES.at(conversion);
+    } else {
+      // convert_color_kernel.cpp:231-236
+      std::string err = "ConvertColor: invalid color conversion argument provided: " + conversion;
+      RESULT_ERROR(&valid_, "%s", err.c_str());
+      code_ = -1;
+    }
+  }
+
+  void execute(const BatchedElements& input_columns, BatchedElements& output_columns) override {
+    auto& frame_col = input_columns[0];
+    i32 input_count = (i32)num_rows(frame_col);
+    if (input_count == 0) return;
+    LOG_IF(FATAL, code_ < 0) << valid_.msg();
+    const Frame* frame = frame_col[0].as_const_frame();
+    LOG_IF(FATAL, frame->type != FrameType::U8) << "ConvertColor expects U8 frames";
+    const int out_channels = st_cvt_color_out_channels(code_, frame->channels());
+    LOG_IF(FATAL, out_channels < 0) << "ConvertColor: conversion " << code_ << " does not apply to "
+                                    << frame->channels() << "-channel frames";
+    FrameInfo info(frame->height(), frame->width(), out_channels, FrameType::U8);
+    std::vector<Frame*> output_frames = new_frames(device_, info, input_count);
+    src_.resize(input_count);
+    dst_.resize(input_count);
+    const size_t in_bytes = frame->size(), out_bytes = info.size();
+    if (STAGED) {
+      const size_t in_stride = DeviceStage::align(in_bytes), out_stride = DeviceStage::align(out_bytes);
+      u8* dev = stage_.reserve((in_stride + out_stride) * input_count);
+      for (i32 i = 0; i < input_count; ++i) {
+        stage_.upload(dev + in_stride * i, frame_col[i].as_const_frame()->data, in_bytes);
+        src_[i] = dev + in_stride * i;
+        dst_[i] = dev + in_stride * input_count + out_stride * i;
+      }
+    } else {
+      for (i32 i = 0; i < input_count; ++i) {
+        src_[i] = frame_col[i].as_const_frame()->data;
+        dst_[i] = output_frames[i]->data;
+      }
+    }
+    int st = st_cvt_color_u8_batch(ctx_, src_.data(), input_count, frame->height(), frame->width(), frame->channels(),
+                                   code_, gray_bits_, dst_.data());
+    LOG_IF(FATAL, st != ST_OK) << "st_cvt_color_u8_batch: " << st_ctx_last_error(ctx_);
+    st = st_ctx_sync(ctx_);
+    LOG_IF(FATAL, st != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(ctx_);
+    if (STAGED)
+      for (i32 i = 0; i < input_count; ++i) stage_.download(output_frames[i]->data, dst_[i], out_bytes);
+    for (i32 i = 0; i < input_count; ++i) insert_frame(output_columns[0], output_frames[i]);
+  }
+
+ private:
+  DeviceHandle device_;
+  int gpu_;
+  DeviceStage stage_;
+  int code_ = -1;
+  int gray_bits_ = 15;
+  Result valid_;
+  st_ctx* ctx_ = nullptr;
+  std::vector<const uint8_t*> src_;
+  std::vector<uint8_t*> dst_;
+};
+
+using ConvertColorKernelHIP = ConvertColorKernelHIPImpl<false>;
+using ConvertColorKernelHIPStaged = ConvertColorKernelHIPImpl<true>;
+
+REGISTER_OP(ConvertColor).frame_input("frame").frame_output("frame").stream_protobuf_name("ConvertColorArgs");
+
+REGISTER_KERNEL(ConvertColor, ConvertColorKernelHIPStaged).device(DeviceType::CPU).batch().num_devices(1);
+
+REGISTER_KERNEL(ConvertColor, ConvertColorKernelHIP).device(DeviceType::GPU).batch().num_devices(1);
+}

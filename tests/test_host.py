@@ -161,7 +161,7 @@ def test_imgproc_library_registrations():
     ops = {(name, dev) for name, dev, _, _ in regs}
     assert {("Histogram", 0), ("Histogram", 1), ("OpticalFlow", 0), ("OpticalFlow", 1),
             ("FlowHistogram", 0), ("FlowHistogram", 1), ("Blur", 0), ("Blur", 1),
-            ("Resize", 0), ("Resize", 1)} <= ops
+            ("Resize", 0), ("Resize", 1), ("ConvertColor", 0), ("ConvertColor", 1)} <= ops
     for name, dev, kind, can_batch in regs:
         assert can_batch                                           # .batch() as in histogram_kernel_cpu.cpp:54-57
         assert kind == (3 if name == "OpticalFlow" else 1)         # StenciledBatched / Batched

@@ -154,3 +154,57 @@ def test_resize_op_target_size_rules():
         for j, got in enumerate(out.load()):
             assert got.shape == (th, tw, 3)
             np.testing.assert_array_equal(got, oracle.resize_u8(frames[j], tw, th, interp))
+
+
+# ---- ConvertColor -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,code", [("COLOR_BGR2RGB", 4), ("COLOR_RGB2BGR", 4), ("COLOR_BGR2GRAY", 6),
+                                       ("COLOR_RGB2GRAY", 7), ("COLOR_BGR2HSV", 40)])
+@pytest.mark.parametrize("h,w", [(1, 1), (37, 53), (480, 640)])
+def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
+    frames = random_frames(h + w + code, 2, h, w)
+    got = hip_ctx.cvt_color(torch.from_numpy(frames).cuda(), name).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], oracle.cvt_color(frames[i], code))
+    if "GRAY" in name:
+        g14 = hip_ctx.cvt_color(torch.from_numpy(frames).cuda(), code, gray_bits=14).cpu().numpy()
+        np.testing.assert_array_equal(g14[0], oracle.cvt_color(frames[0], code, gray_bits=14))
+
+
+def test_cvt_color_exhaustive_hsv_and_known_answers(hip_ctx):
+    """Every (b,g,r) with 5-bit components + all saturated ramps through BGR2HSV; primaries."""
+    v = (np.arange(32) * 8 + 3).astype(np.uint8)
+    grid = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, 32, 1024, 3)
+    got = hip_ctx.cvt_color(torch.from_numpy(np.ascontiguousarray(grid)).cuda(), "COLOR_BGR2HSV").cpu().numpy()
+    np.testing.assert_array_equal(got[0], oracle.cvt_color(grid[0], oracle.COLOR_BGR2HSV))
+    px = np.array([[[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128]]]], np.uint8)
+    hsv = hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2HSV").cpu().numpy()[0, 0]
+    assert hsv.tolist() == [[120, 255, 255], [60, 255, 255], [0, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128]]
+    gray = hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2GRAY").cpu().numpy()[0, 0, :, 0]
+    assert gray.tolist() == [29, 150, 76, 255, 0, 128]
+    g = np.random.default_rng(0).integers(0, 256, (1, 9, 11, 1), dtype=np.uint8)
+    rgb = hip_ctx.cvt_color(torch.from_numpy(g).cuda(), "COLOR_GRAY2RGB").cpu().numpy()
+    assert rgb.shape == (1, 9, 11, 3) and (rgb == g).all()
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2XYZ")
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.from_numpy(g).cuda(), "COLOR_BGR2HSV")             # needs 3 channels
+
+
+@pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
+def test_hsv_histogram_pipeline(device):
+    """old/histograms.py:21-40 (compute_hsv_histograms): colour conversion -> Histogram, plus a
+    gray conversion whose single-channel output changes the frame shape."""
+    from scannertools_amd.engine import NamedStream
+    sc = Client()
+    frames = random_frames(9, 5, 60, 80)
+    sc.ingest_frames('v', frames)
+    frame = sc.io.Input([NamedVideoStream(sc, 'v')])
+    hsv = sc.ops.ConvertColor(frame=frame, conversion='COLOR_BGR2HSV', device=device, batch=3)
+    hist = sc.ops.Histogram(frame=hsv, device=device, batch=2)
+    gray = sc.ops.ConvertColor(frame=frame, conversion='COLOR_RGB2GRAY', device=device)
+    o_hist, o_gray = NamedStream(sc, 'hh'), NamedStream(sc, 'gg')
+    sc.run([sc.io.Output(hist, [o_hist]), sc.io.Output(gray, [o_gray])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    for i, (hh, gg) in enumerate(zip(o_hist.load(), o_gray.load())):
+        np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(oracle.cvt_color(frames[i], oracle.COLOR_BGR2HSV), 16))
+        assert gg.shape == (60, 80, 1)
+        np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))

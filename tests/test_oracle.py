@@ -209,3 +209,27 @@ def test_resize_oracle_identities():
     assert oracle.resize_target(320, 200, width=426, height=240, min=True) == (320, 200)
     with pytest.raises(ValueError):
         oracle.resize_u8(f, 10, 10, 2)
+
+
+def test_cvt_color_oracle_known_answers():
+    """cv::cvtColor restatement: OpenCV's documented 8-bit values for primaries and grays, the
+    HSV definition (against colorsys, within the table rounding), channel swaps."""
+    import colorsys
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128],
+                    [10, 200, 90], [255, 255, 0]]], np.uint8)                       # B, G, R order
+    hsv = oracle.cvt_color(px, oracle.COLOR_BGR2HSV)[0]
+    assert hsv[:6].tolist() == [[120, 255, 255], [60, 255, 255], [0, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128]]
+    rng = np.random.default_rng(1)
+    f = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    got = oracle.cvt_color(f, oracle.COLOR_BGR2HSV).reshape(-1, 3).astype(float)
+    for (b, g, r), (hh, ss, vv) in zip(f.reshape(-1, 3)[:200], got[:200]):
+        h, s, v = colorsys.rgb_to_hsv(r / 255., g / 255., b / 255.)
+        assert vv == max(b, g, r) and abs(ss - s * 255) <= 1.01
+        dh = abs(hh - h * 180)
+        assert min(dh, 180 - dh) <= 1.01 or s * 255 < 8               # hue is ill-conditioned near gray
+    assert oracle.cvt_color(px, oracle.COLOR_BGR2GRAY)[0, :6, 0].tolist() == [29, 150, 76, 255, 0, 128]
+    assert oracle.cvt_color(px, oracle.COLOR_RGB2GRAY)[0, :6, 0].tolist() == [76, 150, 29, 255, 0, 128]
+    np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_BGR2RGB), f[..., ::-1])
+    np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_BGR2GRAY)[..., 0], oracle.gray_u8(f))
+    with pytest.raises(ValueError):
+        oracle.cvt_color(f, 32)
