@@ -6,8 +6,10 @@ import this package, and only as the checker / CPU baseline.  Nothing under
 missing instead of falling back to this code.
 
 ``oracle.c`` restates the OpenCV algorithms the reference ops call (see its header for the
-reference call sites and the parity status: Histogram pinned by definition, OpticalFlow
-PARITY UNPINNED against real OpenCV output); ``shot_boundaries`` restates
+reference call sites and the parity status: Histogram pinned by definition, DrawFlow pinned by
+golden vectors from the reference's vis.py, Blur pinned by the reference source itself;
+OpticalFlow, FlowHistogram, Resize and ConvertColor PARITY UNPINNED against real OpenCV
+output); ``shot_boundaries`` restates
 ``/root/reference/scannertools/scannertools/shot_detection.py:11-28`` and is pinned by the
 fixtures under ``tests/golden/`` that were produced by importing that file.
 """

@@ -28,6 +28,12 @@
  *               OpenCV build exists here to emit golden vectors.  The oracle is pinned
  *               only by analytic known-answer tests (polynomial expansion of exact
  *               quadratics, recovered integer translations, zero-flow identities).
+ * The later sections restate the ops either side of the path (each with its own header):
+ *   DrawFlow    : pinned by golden vectors produced by importing the reference's vis.py.
+ *   Blur        : pinned by the reference source itself (blur_kernel_cpu.cpp spells out the
+ *                 integer arithmetic; no OpenCV involved).
+ *   FlowHistogram, Resize, ConvertColor: PARITY UNPINNED against real OpenCV output
+ *                 (cartToPolar/calcHist, resize, cvtColor restated; known answers only).
  */
 #include <math.h>
 #include <stdint.h>
