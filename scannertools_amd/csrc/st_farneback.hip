@@ -1566,12 +1566,20 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #else
 #define PSTAMP() do {} while (0)
 #endif
-  // One batch per trip; the ring is kept statically indexed by shifting it RB rows per batch
-  // (60 register moves) instead of unrolling the loop over the ring period: the unrolled body
-  // was ~100 KB of code and thrashed the 64 KB instruction cache.
+  // One ring period (W rows = W/RB batches) per trip of the outer loop, the batches inside it
+  // unrolled: batch bb replaces ring slots RB*bb .. RB*bb+RB-1, all indices are compile-time
+  // constants and the ring never moves (shifting it cost 60 register moves per batch).  The body
+  // is ~10 KB per batch since the flow source is a template parameter, so the five copies fit the
+  // 64 KB instruction cache (the first unrolled version, 100 KB, did not).
+  // (The level-transition instance keeps the rolled, shifting form: unrolled it spills.)
+  constexpr bool UNR = MODE != FLOW_COARSE;
+  constexpr int NB = UNR ? W / RB : 1;
 #pragma unroll 1
-  for (int ybb = y0; ybb < y1; ybb += RB) {
-    {
+  for (int ybase = y0; ybase < y1; ybase += NB * RB) {
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int ybb = ybase + bb * RB;
+      if (ybb >= y1) break;  // uniform over the workgroup
       {
         PSTAMP();
         // ---- phase 3 of the PREVIOUS batch first: its flow rows go out ahead of this batch's
@@ -1590,14 +1598,14 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             V[r][c][tid] = (VT)vs[c];
-            const float d = m[c] - ring[r][c];
+            const float d = m[c] - ring[bb * RB + r][c];
             vs[c] += d;
-            ring[r][c] = m[c];  // parked in the slot it frees; rotated into place below
+            ring[bb * RB + r][c] = m[c];  // rolled form: parked in the slot it frees, rotated below
           }
           fl[r] = fn[r];
           um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
         }
-        {
+        if (!UNR) {
           float tmp[RB][5];
 #pragma unroll
           for (int r = 0; r < RB; ++r)
