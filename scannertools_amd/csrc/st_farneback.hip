@@ -155,6 +155,19 @@ __device__ __forceinline__ int d_reflect101(int p, int len) {
 }
 __device__ __forceinline__ int d_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// 1/x for the 2x2 solve of the fused iteration: hardware estimate + two Newton steps (6
+// instructions, within an ulp or two of the IEEE quotient) instead of the ~35-instruction correctly
+// rounded division.  x = det + 1e-3 > 0.  The box-filter stage is compared under a tolerance (its
+// running sums already associate differently from the reference), so the last bit of the double
+// reciprocal is not part of the contract; the stage-level kernels keep the exact division.
+__device__ __forceinline__ double d_rcp_pos(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 // ---------------------------------------------------------------------------------------------
 // A2: 8-bit luma with OpenCV's BGR table applied to RGB bytes (reference quirk).
 // ---------------------------------------------------------------------------------------------
@@ -1653,7 +1666,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
             }
             const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
             const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
             F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
             __builtin_amdgcn_sched_barrier(0);
           }
