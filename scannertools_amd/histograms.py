@@ -1,0 +1,45 @@
+"""Front-ends of the histogram pipelines: mirrors of ``compute_histograms``,
+``compute_hsv_histograms`` and ``compute_flow_histograms``
+(/root/reference/scannertools/scannertools/old/histograms.py:6-81), i.e. of their ``build_pipeline``
+graphs; the job machinery around them (Database, sinks, megabatches) is out of scope (SURVEY
+section 8).  Each function returns one NamedStream per video.
+"""
+from . import types as _types
+from .engine import CacheMode, DeviceType, NamedStream, NamedVideoStream, PerfParams
+
+
+def _run(sc, name, suffix, build):
+    frame = sc.io.Input([NamedVideoStream(sc, name)])
+    out = NamedStream(sc, '%s_%s' % (name, suffix))
+    sc.run(sc.io.Output(build(frame), [out]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    return out
+
+
+def compute_histograms(sc, videos, device=DeviceType.GPU, batch=64):
+    """old/histograms.py:10-15: Histogram(frame, device, batch); rows read with
+    scannertools_amd.types.histograms (3 x int32[16])."""
+    return [_run(sc, v, 'hist', lambda f: sc.ops.Histogram(frame=f, device=device, batch=batch)) for v in videos]
+
+
+def compute_hsv_histograms(sc, videos, device=DeviceType.GPU, batch=64):
+    """old/histograms.py:32-37: RGB -> HSV conversion, then Histogram.  The reference's
+    ConvertToHSVCPP op is cv::cvtColor(COLOR_RGB2HSV) (old/cpp_ops/imgproc.cpp:41); with the
+    ConvertColor op of this library that is COLOR_RGB2BGR followed by COLOR_BGR2HSV."""
+    def build(f):
+        bgr = sc.ops.ConvertColor(frame=f, conversion='COLOR_RGB2BGR', device=device, batch=batch)
+        hsv = sc.ops.ConvertColor(frame=bgr, conversion='COLOR_BGR2HSV', device=device, batch=batch)
+        return sc.ops.Histogram(frame=hsv, device=device, batch=batch)
+    return [_run(sc, v, 'hsv_hist', build) for v in videos]
+
+
+def compute_flow_histograms(sc, videos, device=DeviceType.GPU, batch=32, width=426, height=240):
+    """old/histograms.py:63-78: Resize(426 x 240) -> OpticalFlow -> FlowHistogram; rows read with
+    scannertools_amd.types.flow_histograms (2 x int32[64])."""
+    def build(f):
+        small = sc.ops.Resize(frame=f, device=device, width=width, height=height, batch=batch)
+        flow = sc.ops.OpticalFlow(frame=small, device=device, batch=batch)
+        return sc.ops.FlowHistogram(flow=flow, device=device, batch=batch)
+    return [_run(sc, v, 'flow_hist', build) for v in videos]
+
+
+flow_hist_reader = _types.flow_histograms  # old/histograms.py:43-46

@@ -173,3 +173,34 @@ def test_cache_mode_error(sc):
         sc.run(sc.io.Output(hist, [out]), PerfParams.estimate())
     with pytest.raises(KeyError):
         NamedStream(sc, 'never_written').len()
+
+
+def test_front_end_runners(sc):
+    """compute_flow / compute_histograms / compute_hsv_histograms / compute_flow_histograms: the
+    graphs of old/optical_flow.py and old/histograms.py, checked row by row."""
+    import scannertools_amd.imgproc  # noqa: F401  (loads the op library, like scannertools.imgproc)
+    from scannertools_amd.histograms import compute_flow_histograms, compute_histograms, compute_hsv_histograms
+    from scannertools_amd.optical_flow import compute_flow
+    frames = sc._videos['test1']
+    pick = [0, 5, 6, 20, 59]
+    (flow,) = compute_flow(sc, ['test1'], frames=[pick], batch=4)
+    assert flow.len() == len(pick)
+    for i, fl in enumerate(flow.load()):
+        ref = oracle.optical_flow_rgb(frames[pick[i]], frames[pick[min(i + 1, len(pick) - 1)]])
+        assert fl.shape == (120, 160, 2) and np.abs(fl - ref).max() <= 5e-3
+    (hist,) = compute_histograms(sc, ['test1'])
+    for i, h in enumerate(hist.load()):
+        np.testing.assert_array_equal(np.stack(h), oracle.hist_u8c3(frames[i], 16))
+    (hsv,) = compute_hsv_histograms(sc, ['test1'], batch=16)
+    for i, h in enumerate(hsv.load()):
+        ref = oracle.cvt_color(np.ascontiguousarray(frames[i][..., ::-1]), oracle.COLOR_BGR2HSV)     # RGB2HSV
+        np.testing.assert_array_equal(np.stack(h), oracle.hist_u8c3(ref, 16))
+    (fh,) = compute_flow_histograms(sc, ['test1'], width=80, height=60)
+    assert fh.len() == 60
+    small = [oracle.resize_u8(f, 80, 60) for f in frames]
+    for i, h in enumerate(fh.load()):
+        if i in (0, 17, 59):
+            flow_ref = oracle.optical_flow_rgb(small[i], small[min(i + 1, 59)])
+            assert abs(int(np.stack(h)[0].sum()) - 80 * 60) <= 0 and np.stack(h)[1].sum() == 80 * 60
+            # histogram of the oracle's flow agrees except for vectors that straddle a bin edge
+            assert np.abs(np.stack(h) - oracle.flow_hist(flow_ref)).sum() <= 8
