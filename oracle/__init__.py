@@ -231,7 +231,7 @@ def box_blur(frame, kernel_size):
     return out
 
 
-INTER_NEAREST, INTER_LINEAR = 0, 1
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA = 0, 1, 2, 3
 
 
 def resize_target(frame_w, frame_h, width=0, height=0, min=False, preserve_aspect=False):
@@ -252,6 +252,7 @@ def resize_u8(frame, width, height, interpolation=INTER_LINEAR):
 
 
 COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR, COLOR_GRAY2RGB, COLOR_BGR2HSV = 4, 4, 6, 7, 8, 8, 40
+COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB = 36, 37, 38, 39
 
 
 def cvt_color(frame, code, gray_bits=15):

@@ -703,6 +703,7 @@ ORC_API void orc_box_blur_u8c3(const uint8_t* src, int h, int w, int kernel_size
  *                  to [0, h-1].  Exact 2x2 decimation is rerouted to INTER_AREA:
  *                  (S00 + S01 + S10 + S11 + 2) >> 2 (ResizeAreaFastVec).
  *   INTER_NEAREST: sx = min(floor(dx * scale_x), sw-1), sy likewise (resizeNN).
+ *   INTER_CUBIC / INTER_AREA: see orc_resize_cubic_u8 / orc_resize_area_u8 below.
  * Equal sizes are a plain copy.  PARITY UNPINNED against real OpenCV output (integer arithmetic,
  * pinned only by identities: constant images, exact 2x means, separability).
  * ------------------------------------------------------------------------------------------ */
@@ -724,12 +725,191 @@ ORC_API void orc_resize_target(int fw, int fh, int width, int height, int min_fl
   *tw = target_width; *th = target_height;
 }
 
-/* interpolation: 0 = INTER_NEAREST, 1 = INTER_LINEAR (cv::InterpolationFlags values) */
+/* cv::interpolateCubic (imgproc/src/resize.cpp), A = -0.75 */
+static void orc_cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static inline uint8_t orc_sat_u8_int(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+static inline uint8_t orc_sat_u8_float(float v) { long r = lrintf(v); return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+
+/* INTER_CUBIC, 8-bit: 4 x 4 taps, 11-bit fixed-point weights, columns outside the row replicate the
+ * edge pixel (HResizeCubic), rows clipped to [0, h-1], result (v + 2^21) >> 22 saturated
+ * (VResizeCubic with FixedPtCast<int, uchar, 22>). */
+static void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw,
+                                double scale_x, double scale_y) {
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 4 * dw);
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= sx;
+    float c[4];
+    orc_cubic_coeffs(fx, c);
+    xofs[dx] = sx;
+    for (int k = 0; k < 4; ++k) ialpha[4 * dx + k] = orc_sat_short_round(c[k] * 2048);
+  }
+  int* rows[4];
+  for (int k = 0; k < 4; ++k) rows[k] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor_f(fy);
+    fy -= sy;
+    float cb[4];
+    orc_cubic_coeffs(fy, cb);
+    short beta[4];
+    for (int k = 0; k < 4; ++k) beta[k] = orc_sat_short_round(cb[k] * 2048);
+    for (int k = 0; k < 4; ++k) {
+      const int yy = imin(imax(sy - 1 + k, 0), sh - 1);
+      const uint8_t* S = src + (size_t)yy * sw * cn;
+      for (int dx = 0; dx < dw; ++dx)
+        for (int c = 0; c < cn; ++c) {
+          int v = 0;
+          for (int j = 0; j < 4; ++j) {
+            const int sxj = imin(imax(xofs[dx] - 1 + j, 0), sw - 1);
+            v += S[sxj * cn + c] * ialpha[4 * dx + j];
+          }
+          rows[k][dx * cn + c] = v;
+        }
+    }
+    uint8_t* D = dst + (size_t)dy * dw * cn;
+    for (int i = 0; i < dw * cn; ++i) {
+      const int v = rows[0][i] * beta[0] + rows[1][i] * beta[1] + rows[2][i] * beta[2] + rows[3][i] * beta[3];
+      D[i] = orc_sat_u8_int((v + (1 << 21)) >> 22);
+    }
+  }
+  for (int k = 0; k < 4; ++k) free(rows[k]);
+  free(xofs); free(ialpha);
+}
+
+/* computeResizeAreaTab: the source cells (index, weight) that one axis of an INTER_AREA
+ * down-scale accumulates into each destination cell. */
+typedef struct { int di, si; float alpha; } orc_area_tab;
+static int orc_area_table(int ssize, int dsize, double scale, orc_area_tab* tab) {
+  int k = 0;
+  for (int dx = 0; dx < dsize; ++dx) {
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = imin(sx2, ssize - 1);
+    sx1 = imin(sx1, sx2);
+    if (sx1 - fsx1 > 1e-3) { tab[k].di = dx; tab[k].si = sx1 - 1; tab[k++].alpha = (float)((sx1 - fsx1) / cellWidth); }
+    for (int sx = sx1; sx < sx2; ++sx) { tab[k].di = dx; tab[k].si = sx; tab[k++].alpha = (float)(1.0 / cellWidth); }
+    if (fsx2 - sx2 > 1e-3) {
+      double w = fsx2 - sx2;
+      if (w > 1.) w = 1.;
+      if (w > cellWidth) w = cellWidth;
+      tab[k].di = dx; tab[k].si = sx2; tab[k++].alpha = (float)(w / cellWidth);
+    }
+  }
+  return k;
+}
+
+/* INTER_AREA, 8-bit.  Down-scaling by integer factors: mean of the iscale_x x iscale_y cell,
+ * (sum + 2) >> 2 for 2 x 2 (ResizeAreaFastVec), saturate_cast<uchar>(sum * (1.f/area)) otherwise
+ * (resizeAreaFast_Invoker).  Other down-scales: float accumulation of fractionally weighted cells,
+ * rows then columns (ResizeArea_Invoker).  Up-scaling (either axis): the bilinear fixed-point path
+ * with INTER_AREA's cell-aligned weights. */
+static void orc_resize_area_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw,
+                               double scale_x, double scale_y, double inv_scale_x, double inv_scale_y) {
+  const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+  const int fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+  if (scale_x >= 1 && scale_y >= 1) {
+    if (fast) {
+      const int area = iscale_x * iscale_y;
+      const float scale = 1.f / area;
+      for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x)
+          for (int c = 0; c < cn; ++c) {
+            int sum = 0;
+            for (int sy = 0; sy < iscale_y; ++sy)
+              for (int sx = 0; sx < iscale_x; ++sx)
+                sum += src[((size_t)(y * iscale_y + sy) * sw + (x * iscale_x + sx)) * cn + c];
+            dst[((size_t)y * dw + x) * cn + c] = area == 4 && iscale_x == 2 ? (uint8_t)((sum + 2) >> 2) : orc_sat_u8_float(sum * scale);
+          }
+      return;
+    }
+    orc_area_tab* xtab = (orc_area_tab*)malloc(sizeof(orc_area_tab) * ((size_t)sw + 2 * dw + 2));
+    orc_area_tab* ytab = (orc_area_tab*)malloc(sizeof(orc_area_tab) * ((size_t)sh + 2 * dh + 2));
+    const int xn = orc_area_table(sw, dw, scale_x, xtab), yn = orc_area_table(sh, dh, scale_y, ytab);
+    float* buf = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+    float* sum = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+    int prev_dy = ytab[0].di;
+    for (int i = 0; i < dw * cn; ++i) sum[i] = 0;
+    for (int j = 0; j < yn; ++j) {
+      const int dy = ytab[j].di, sy = ytab[j].si;
+      const float beta = ytab[j].alpha;
+      const uint8_t* S = src + (size_t)sy * sw * cn;
+      for (int i = 0; i < dw * cn; ++i) buf[i] = 0;
+      for (int k = 0; k < xn; ++k)
+        for (int c = 0; c < cn; ++c) buf[xtab[k].di * cn + c] += S[xtab[k].si * cn + c] * xtab[k].alpha;
+      if (dy != prev_dy) {
+        uint8_t* D = dst + (size_t)prev_dy * dw * cn;
+        for (int i = 0; i < dw * cn; ++i) { D[i] = orc_sat_u8_float(sum[i]); sum[i] = beta * buf[i]; }
+        prev_dy = dy;
+      } else {
+        for (int i = 0; i < dw * cn; ++i) sum[i] += beta * buf[i];
+      }
+    }
+    {
+      uint8_t* D = dst + (size_t)prev_dy * dw * cn;
+      for (int i = 0; i < dw * cn; ++i) D[i] = orc_sat_u8_float(sum[i]);
+    }
+    free(xtab); free(ytab); free(buf); free(sum);
+    return;
+  }
+  /* up-scaling on at least one axis: linear arithmetic, area-mode weights on both axes */
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 2 * dw);
+  for (int dx = 0; dx < dw; ++dx) {
+    int sx = (int)floor(dx * scale_x);
+    float fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);
+    fx = fx <= 0 ? 0.f : fx - floorf(fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = orc_sat_short_round((1.f - fx) * 2048);
+    ialpha[2 * dx + 1] = orc_sat_short_round(fx * 2048);
+  }
+  int* rows[2];
+  rows[0] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  rows[1] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    int sy = (int)floor(dy * scale_y);
+    float fy = (float)((dy + 1) - (sy + 1) * inv_scale_y);
+    fy = fy <= 0 ? 0.f : fy - floorf(fy);
+    const short b0 = orc_sat_short_round((1.f - fy) * 2048), b1 = orc_sat_short_round(fy * 2048);
+    for (int k = 0; k < 2; ++k) {
+      const int yy = imin(imax(sy + k, 0), sh - 1);
+      const uint8_t* S = src + (size_t)yy * sw * cn;
+      for (int dx = 0; dx < dw; ++dx) {
+        const int sx = xofs[dx];
+        for (int c = 0; c < cn; ++c) {
+          if (sx + 1 < sw) rows[k][dx * cn + c] = S[sx * cn + c] * ialpha[2 * dx] + S[(sx + 1) * cn + c] * ialpha[2 * dx + 1];
+          else rows[k][dx * cn + c] = S[sx * cn + c] * 2048;
+        }
+      }
+    }
+    uint8_t* D = dst + (size_t)dy * dw * cn;
+    for (int i = 0; i < dw * cn; ++i)
+      D[i] = (uint8_t)((((b0 * (rows[0][i] >> 4)) >> 16) + ((b1 * (rows[1][i] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(rows[0]); free(rows[1]); free(xofs); free(ialpha);
+}
+
+/* interpolation: cv::InterpolationFlags values 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC,
+ * 3 = INTER_AREA */
 ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int interpolation) {
-  if (interpolation != 0 && interpolation != 1) return 1;
+  if (interpolation < 0 || interpolation > 3) return 1;
   if (sh == dh && sw == dw) { memcpy(dst, src, (size_t)sh * sw * cn); return 0; }
   const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
   const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  if (interpolation == 2) { orc_resize_cubic_u8(src, sh, sw, cn, dst, dh, dw, scale_x, scale_y); return 0; }
+  if (interpolation == 3) { orc_resize_area_u8(src, sh, sw, cn, dst, dh, dw, scale_x, scale_y, inv_sx, inv_sy); return 0; }
   if (interpolation == 0) {
     for (int y = 0; y < dh; ++y) {
       int sy = imin((int)floor(y * scale_y), sh - 1);
@@ -794,7 +974,8 @@ ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* d
  * /root/reference/scannertools/scannertools_cpp/imgproc/convert_color_kernel.cpp:252-285:
  * cv::cvtColor(img, out, code) on U8 frames, code chosen by name from the table at :10-209.
  * Restated codes (cv::ColorConversionCodes values): BGR2RGB/RGB2BGR (4), BGR2GRAY (6),
- * RGB2GRAY (7), GRAY2BGR/GRAY2RGB (8), BGR2HSV (40).  8-bit arithmetic of OpenCV
+ * RGB2GRAY (7), GRAY2BGR/GRAY2RGB (8), BGR2YCrCb (36), RGB2YCrCb (37), YCrCb2BGR (38),
+ * YCrCb2RGB (39) [14-bit RGB2YCrCb_i / YCrCb2RGB_i tables], BGR2HSV (40).  8-bit arithmetic of OpenCV
  * (imgproc/src/color*.cpp): gray = (c_b*B + c_g*G + c_r*R + half) >> bits with the 14/15-bit
  * tables of orc_gray_u8; RGB2HSV_b with hsv_shift = 12: v = max, s = (diff*sdiv[v] + 2^11) >> 12,
  * h = sector offset + difference, scaled by hdiv180[diff], +180 if negative, where
@@ -802,14 +983,16 @@ ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* d
  * PARITY UNPINNED against real OpenCV output (integer arithmetic; pinned by primaries, grays and
  * hue-sector identities in tests/).
  * ------------------------------------------------------------------------------------------ */
-enum { ORC_BGR2RGB = 4, ORC_BGR2GRAY = 6, ORC_RGB2GRAY = 7, ORC_GRAY2BGR = 8, ORC_BGR2HSV = 40 };
+enum { ORC_BGR2RGB = 4, ORC_BGR2GRAY = 6, ORC_RGB2GRAY = 7, ORC_GRAY2BGR = 8, ORC_BGR2YCrCb = 36, ORC_RGB2YCrCb = 37,
+       ORC_YCrCb2BGR = 38, ORC_YCrCb2RGB = 39, ORC_BGR2HSV = 40 };
 
 ORC_API int orc_cvt_out_channels(int code, int in_channels) {
   switch (code) {
     case ORC_BGR2RGB: return in_channels == 3 ? 3 : -1;
     case ORC_BGR2GRAY: case ORC_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ORC_GRAY2BGR: return in_channels == 1 ? 3 : -1;
-    case ORC_BGR2HSV: return in_channels == 3 ? 3 : -1;
+    case ORC_BGR2HSV: case ORC_BGR2YCrCb: case ORC_RGB2YCrCb: case ORC_YCrCb2BGR: case ORC_YCrCb2RGB:
+      return in_channels == 3 ? 3 : -1;
     default: return -1;
   }
 }
@@ -828,6 +1011,31 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
       dst[i] = (uint8_t)((src[3 * i + bi] * cb + src[3 * i + 1] * cg + src[3 * i + (bi ^ 2)] * cr + rnd) >> bits);
   } else if (code == ORC_GRAY2BGR) {
     for (size_t i = 0; i < n; ++i) dst[3 * i] = dst[3 * i + 1] = dst[3 * i + 2] = src[i];
+  } else if (code == ORC_BGR2YCrCb || code == ORC_RGB2YCrCb) {
+    /* RGB2YCrCb_i<uchar>: yuv_shift = 14, {R2YI, G2YI, B2YI, YCRI, YCBI} = {4899, 9617, 1868, 11682, 9241} */
+    const int bidx = code == ORC_BGR2YCrCb ? 0 : 2, sh = 14, delta = 128 * (1 << 14);
+    const int C0 = bidx == 0 ? 1868 : 4899, C1 = 9617, C2 = bidx == 0 ? 4899 : 1868, C3 = 11682, C4 = 9241;
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* p = src + 3 * i;
+      const int Y = (p[0] * C0 + p[1] * C1 + p[2] * C2 + (1 << (sh - 1))) >> sh;
+      const int Cr = ((p[bidx ^ 2] - Y) * C3 + delta + (1 << (sh - 1))) >> sh;
+      const int Cb = ((p[bidx] - Y) * C4 + delta + (1 << (sh - 1))) >> sh;
+      dst[3 * i] = (uint8_t)(Y < 0 ? 0 : (Y > 255 ? 255 : Y));
+      dst[3 * i + 1] = (uint8_t)(Cr < 0 ? 0 : (Cr > 255 ? 255 : Cr));
+      dst[3 * i + 2] = (uint8_t)(Cb < 0 ? 0 : (Cb > 255 ? 255 : Cb));
+    }
+  } else if (code == ORC_YCrCb2BGR || code == ORC_YCrCb2RGB) {
+    /* YCrCb2RGB_i<uchar>: {CR2RI, CR2GI, CB2GI, CB2BI} = {22987, -11698, -5636, 29049} */
+    const int bidx = code == ORC_YCrCb2BGR ? 0 : 2, sh = 14, rnd = 1 << (sh - 1);
+    for (size_t i = 0; i < n; ++i) {
+      const int Y = src[3 * i], Cr = src[3 * i + 1] - 128, Cb = src[3 * i + 2] - 128;
+      const int b = Y + ((Cb * 29049 + rnd) >> sh);
+      const int g = Y + ((Cb * -5636 + Cr * -11698 + rnd) >> sh);
+      const int r = Y + ((Cr * 22987 + rnd) >> sh);
+      dst[3 * i + bidx] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+      dst[3 * i + 1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+      dst[3 * i + (bidx ^ 2)] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
   } else {  /* BGR2HSV, hrange 180 */
     const int hsv_shift = 12;
     int sdiv[256], hdiv[256];

@@ -11,13 +11,17 @@
 // Resize replaces the cv::resize call of ResizeKernel::execute
 // (/root/reference/scannertools/scannertools_cpp/imgproc/resize_kernel.cpp:68-73) for U8 frames:
 // INTER_LINEAR (OpenCV's 11-bit fixed-point weights and its two-stage integer rounding, exact 2x2
-// decimation rerouted to the INTER_AREA mean) and INTER_NEAREST; arithmetic as restated in
+// decimation rerouted to the INTER_AREA mean), INTER_NEAREST, INTER_CUBIC (4x4 fixed-point taps) and
+// INTER_AREA (integer cells, fractional cells in float, cell-aligned bilinear weights when enlarging); arithmetic as restated in
 // oracle/oracle.c (orc_resize_u8), one thread per output pixel, weights recomputed per thread.
 //
 // ConvertColor replaces the cv::cvtColor call of ConvertColorKernel::execute
 // (/root/reference/scannertools/scannertools_cpp/imgproc/convert_color_kernel.cpp:268-271) for the
-// 8-bit codes BGR2RGB/RGB2BGR, BGR2GRAY, RGB2GRAY, GRAY2BGR/GRAY2RGB and BGR2HSV (OpenCV's
-// integer tables, oracle/oracle.c orc_cvt_color_u8).
+// 8-bit codes BGR2RGB/RGB2BGR, BGR2GRAY, RGB2GRAY, GRAY2BGR/GRAY2RGB, BGR/RGB <-> YCrCb and BGR2HSV
+// (OpenCV's integer tables, oracle/oracle.c orc_cvt_color_u8).
+#include <cfloat>
+#include <cmath>
+
 #include "st_internal.h"
 
 namespace {
@@ -118,19 +122,63 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
 }
 
 // ---- Resize -------------------------------------------------------------------------------------
-enum { RS_NEAREST = 0, RS_LINEAR = 1, RS_AREA2 = 2, RS_COPY = 3 };
+enum { RS_NEAREST = 0, RS_LINEAR = 1, RS_AREA2 = 2, RS_COPY = 3, RS_CUBIC = 4, RS_AREA_INT = 5, RS_AREA = 6, RS_LINEAR_AREA = 7 };
 
 struct ResizeArgsK {
   const uint8_t* const* src;
   uint8_t* const* dst;
   int sh, sw, dh, dw, cn, mode;
   double scale_x, scale_y;  // source / destination size ratios as cv::resize computes them
+  double inv_scale_x, inv_scale_y;
+  int iscale_x, iscale_y;   // RS_AREA_INT: integer cell size
 };
 
 // saturate_cast<short>(float): cvRound = round half to even, then saturation
 __device__ __forceinline__ int rs_coef(float v) {
   const float r = rintf(v);
   return r < -32768.f ? -32768 : (r > 32767.f ? 32767 : (int)r);
+}
+
+// cv::interpolateCubic, A = -0.75
+__device__ __forceinline__ void rs_cubic(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__device__ __forceinline__ uint8_t rs_sat_float(float v) {  // saturate_cast<uchar>(float): cvRound
+  const float r = rintf(v);
+  return (uint8_t)(r < 0.f ? 0 : (r > 255.f ? 255 : (int)r));
+}
+
+// One destination cell of computeResizeAreaTab: the source cells [first, first + n) and the weights
+// of the (optional) fractional head, the full cells and the (optional) fractional tail.
+struct AreaCell {
+  int head_si, sx1, sx2;  // head_si < 0: no head; full cells sx1 .. sx2-1; tail at sx2 when tail_w > 0
+  float head_w, full_w, tail_w;
+  bool tail;
+};
+__device__ __forceinline__ AreaCell rs_area_cell(int dx, int ssize, double scale) {
+  AreaCell c;
+  const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+  const double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+  sx1 = sx1 < sx2 ? sx1 : sx2;
+  c.head_si = -1; c.head_w = 0.f;
+  if (sx1 - fsx1 > 1e-3) { c.head_si = sx1 - 1; c.head_w = (float)((sx1 - fsx1) / cellWidth); }
+  c.sx1 = sx1; c.sx2 = sx2; c.full_w = (float)(1.0 / cellWidth);
+  c.tail = fsx2 - sx2 > 1e-3;
+  c.tail_w = 0.f;
+  if (c.tail) {
+    double w = fsx2 - sx2;
+    w = w > 1. ? 1. : w;
+    w = w > cellWidth ? cellWidth : w;
+    c.tail_w = (float)(w / cellWidth);
+  }
+  return c;
 }
 
 __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
@@ -153,16 +201,93 @@ __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
     const uint8_t* S0 = src + (size_t)(2 * dy) * srow + (size_t)(2 * dx) * cn;
     const uint8_t* S1 = S0 + srow;
     for (int c = 0; c < cn; ++c) D[c] = (uint8_t)((S0[c] + S0[cn + c] + S1[c] + S1[cn + c] + 2) >> 2);
-  } else {
+  } else if (a.mode == RS_CUBIC) {
     float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
-    int sx = (int)floorf(fx);
+    const int sx = (int)floorf(fx);
     fx -= sx;
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    float cx[4], cy[4];
+    rs_cubic(fx, cx);
+    rs_cubic(fy, cy);
+    int ax[4], by[4], xs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ax[k] = rs_coef(cx[k] * 2048);
+      by[k] = rs_coef(cy[k] * 2048);
+      const int xx = sx - 1 + k;
+      xs[k] = xx < 0 ? 0 : (xx > a.sw - 1 ? a.sw - 1 : xx);  // columns outside the row: edge pixel
+    }
+    for (int c = 0; c < cn; ++c) {
+      int v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = sy - 1 + k;
+        const uint8_t* S = src + (size_t)(yy < 0 ? 0 : (yy > a.sh - 1 ? a.sh - 1 : yy)) * srow;
+        const int r = S[(size_t)xs[0] * cn + c] * ax[0] + S[(size_t)xs[1] * cn + c] * ax[1] +
+                      S[(size_t)xs[2] * cn + c] * ax[2] + S[(size_t)xs[3] * cn + c] * ax[3];
+        v += r * by[k];
+      }
+      const int o = (v + (1 << 21)) >> 22;
+      D[c] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+  } else if (a.mode == RS_AREA_INT) {
+    const float scale = 1.f / (a.iscale_x * a.iscale_y);
+    for (int c = 0; c < cn; ++c) {
+      int sum = 0;
+      for (int yy = 0; yy < a.iscale_y; ++yy) {
+        const uint8_t* S = src + (size_t)(dy * a.iscale_y + yy) * srow + (size_t)(dx * a.iscale_x) * cn + c;
+        for (int xx = 0; xx < a.iscale_x; ++xx) sum += S[(size_t)xx * cn];
+      }
+      D[c] = rs_sat_float(sum * scale);
+    }
+  } else if (a.mode == RS_AREA) {
+    // ResizeArea_Invoker: per source row a float row sum over the cell's columns (head, full cells,
+    // tail, in that order, starting from 0), rows accumulated as beta * rowsum in the same order
+    const AreaCell cx = rs_area_cell(dx, a.sw, a.scale_x), cy = rs_area_cell(dy, a.sh, a.scale_y);
+    for (int c = 0; c < cn; ++c) {
+      float sum = 0.f;
+      auto rowsum = [&](int sy) {
+        const uint8_t* S = src + (size_t)sy * srow + c;
+        float b = 0.f;
+        if (cx.head_si >= 0) b += S[(size_t)cx.head_si * cn] * cx.head_w;
+        for (int sx = cx.sx1; sx < cx.sx2; ++sx) b += S[(size_t)sx * cn] * cx.full_w;
+        if (cx.tail) b += S[(size_t)cx.sx2 * cn] * cx.tail_w;
+        return b;
+      };
+      bool first = true;
+      auto acc = [&](int sy, float beta) {
+        const float t = beta * rowsum(sy);
+        sum = first ? t : sum + t;
+        first = false;
+      };
+      if (cy.head_si >= 0) acc(cy.head_si, cy.head_w);
+      for (int sy = cy.sx1; sy < cy.sx2; ++sy) acc(sy, cy.full_w);
+      if (cy.tail) acc(cy.sx2, cy.tail_w);
+      D[c] = rs_sat_float(sum);
+    }
+  } else {
+    float fx, fy;
+    int sx, sy;
+    if (a.mode == RS_LINEAR_AREA) {  // INTER_AREA when an axis is enlarged: cell-aligned weights
+      sx = (int)floor(dx * a.scale_x);
+      fx = (float)((dx + 1) - (sx + 1) * a.inv_scale_x);
+      fx = fx <= 0 ? 0.f : fx - floorf(fx);
+      sy = (int)floor(dy * a.scale_y);
+      fy = (float)((dy + 1) - (sy + 1) * a.inv_scale_y);
+      fy = fy <= 0 ? 0.f : fy - floorf(fy);
+    } else {
+      fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+      sx = (int)floorf(fx);
+      fx -= sx;
+      fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+      sy = (int)floorf(fy);
+      fy -= sy;
+    }
     if (sx < 0) { fx = 0; sx = 0; }
     if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; }
     const int a0 = rs_coef((1.f - fx) * 2048), a1 = rs_coef(fx * 2048);
-    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy -= sy;
     const int b0 = rs_coef((1.f - fy) * 2048), b1 = rs_coef(fy * 2048);
     const int y0 = sy < 0 ? 0 : (sy > a.sh - 1 ? a.sh - 1 : sy);
     const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > a.sh - 1 ? a.sh - 1 : sy + 1);
@@ -207,6 +332,28 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
     } else if (a.code == ST_COLOR_GRAY2BGR) {
       const uint8_t v = src[i];
       dst[3 * i] = v; dst[3 * i + 1] = v; dst[3 * i + 2] = v;
+    } else if (a.code == ST_COLOR_BGR2YCrCb || a.code == ST_COLOR_RGB2YCrCb) {
+      // RGB2YCrCb_i<uchar>: 14-bit {R2Y, G2Y, B2Y, YCR, YCB} = {4899, 9617, 1868, 11682, 9241}
+      const int bidx = a.code == ST_COLOR_BGR2YCrCb ? 0 : 2;
+      const int p0 = src[3 * i], p1 = src[3 * i + 1], p2 = src[3 * i + 2];
+      const int C0 = bidx == 0 ? 1868 : 4899, C2 = bidx == 0 ? 4899 : 1868;
+      const int Y = (p0 * C0 + p1 * 9617 + p2 * C2 + (1 << 13)) >> 14;
+      const int rr = bidx == 0 ? p2 : p0, bb = bidx == 0 ? p0 : p2;
+      const int Cr = ((rr - Y) * 11682 + (128 << 14) + (1 << 13)) >> 14;
+      const int Cb = ((bb - Y) * 9241 + (128 << 14) + (1 << 13)) >> 14;
+      dst[3 * i] = (uint8_t)min(max(Y, 0), 255);
+      dst[3 * i + 1] = (uint8_t)min(max(Cr, 0), 255);
+      dst[3 * i + 2] = (uint8_t)min(max(Cb, 0), 255);
+    } else if (a.code == ST_COLOR_YCrCb2BGR || a.code == ST_COLOR_YCrCb2RGB) {
+      // YCrCb2RGB_i<uchar>: {CR2R, CR2G, CB2G, CB2B} = {22987, -11698, -5636, 29049}
+      const int bidx = a.code == ST_COLOR_YCrCb2BGR ? 0 : 2;
+      const int Y = src[3 * i], Cr = src[3 * i + 1] - 128, Cb = src[3 * i + 2] - 128;
+      const int b = Y + ((Cb * 29049 + (1 << 13)) >> 14);
+      const int g = Y + ((Cb * -5636 + Cr * -11698 + (1 << 13)) >> 14);
+      const int r = Y + ((Cr * 22987 + (1 << 13)) >> 14);
+      dst[3 * i + bidx] = (uint8_t)min(max(b, 0), 255);
+      dst[3 * i + 1] = (uint8_t)min(max(g, 0), 255);
+      dst[3 * i + (bidx ^ 2)] = (uint8_t)min(max(r, 0), 255);
     } else {  // BGR2HSV, hue range 180
       const int b = src[3 * i], g = src[3 * i + 1], r = src[3 * i + 2];
       const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
@@ -278,8 +425,8 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
   if (n < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0 || channels < 1 || channels > 4 ||
       (long long)h * w > 200000000LL || (long long)out_h * out_w > 200000000LL)
     return st_set_error(ctx, ST_ERR_INVALID, "resize: bad arguments (n=%d %dx%dx%d -> %dx%d)", n, h, w, channels, out_h, out_w);
-  if (interpolation != ST_INTER_NEAREST && interpolation != ST_INTER_LINEAR)
-    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: interpolation %d (INTER_NEAREST = 0 and INTER_LINEAR = 1 are implemented)", interpolation);
+  if (interpolation < ST_INTER_NEAREST || interpolation > ST_INTER_AREA)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: interpolation %d (INTER_NEAREST, INTER_LINEAR, INTER_CUBIC and INTER_AREA are implemented)", interpolation);
   if (out_h > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: output taller than 65535 rows");
   if (n == 0) return ST_OK;
   if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "resize: null argument");
@@ -295,10 +442,16 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
   a.sh = h; a.sw = w; a.dh = out_h; a.dw = out_w; a.cn = channels;
   const double inv_sx = (double)out_w / w, inv_sy = (double)out_h / h;
   a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
+  a.inv_scale_x = inv_sx; a.inv_scale_y = inv_sy;
+  a.iscale_x = (int)lrint(a.scale_x); a.iscale_y = (int)lrint(a.scale_y);
+  const bool area_fast = fabs(a.scale_x - a.iscale_x) < DBL_EPSILON && fabs(a.scale_y - a.iscale_y) < DBL_EPSILON;
   if (h == out_h && w == out_w) a.mode = RS_COPY;
   else if (interpolation == ST_INTER_NEAREST) a.mode = RS_NEAREST;
-  else if (w == 2 * out_w && h == 2 * out_h) a.mode = RS_AREA2;
-  else a.mode = RS_LINEAR;
+  else if (interpolation == ST_INTER_CUBIC) a.mode = RS_CUBIC;
+  else if ((interpolation == ST_INTER_LINEAR || interpolation == ST_INTER_AREA) && area_fast && a.iscale_x == 2 && a.iscale_y == 2) a.mode = RS_AREA2;
+  else if (interpolation == ST_INTER_LINEAR) a.mode = RS_LINEAR;
+  else if (a.scale_x >= 1 && a.scale_y >= 1) a.mode = area_fast ? RS_AREA_INT : RS_AREA;
+  else a.mode = RS_LINEAR_AREA;
   for (int f0 = 0; f0 < n; f0 += 65535) {
     const int nf = n - f0 < 65535 ? n - f0 : 65535;
     a.src = d_src + f0; a.dst = d_dst + f0;
@@ -311,7 +464,9 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
 
 ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
   switch (code) {
-    case ST_COLOR_BGR2RGB: case ST_COLOR_BGR2HSV: return in_channels == 3 ? 3 : -1;
+    case ST_COLOR_BGR2RGB: case ST_COLOR_BGR2HSV: case ST_COLOR_BGR2YCrCb: case ST_COLOR_RGB2YCrCb:
+    case ST_COLOR_YCrCb2BGR: case ST_COLOR_YCrCb2RGB:
+      return in_channels == 3 ? 3 : -1;
     case ST_COLOR_BGR2GRAY: case ST_COLOR_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ST_COLOR_GRAY2BGR: return in_channels == 1 ? 3 : -1;
     default: return -1;

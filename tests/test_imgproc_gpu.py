@@ -94,6 +94,21 @@ def test_resize_linear_matches_oracle(hip_ctx, sh, sw, dh, dw):
         np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh))
 
 
+@pytest.mark.parametrize("sh,sw,dh,dw", [(480, 640, 240, 426), (48, 60, 16, 20), (48, 60, 24, 30), (48, 60, 13, 21),
+                                         (37, 53, 80, 91), (48, 60, 20, 90), (48, 60, 100, 13), (100, 100, 1, 1),
+                                         (1080, 1920, 360, 640), (9, 7, 9, 7)])
+@pytest.mark.parametrize("interp", ["cubic", "area"])
+def test_resize_cubic_and_area_match_oracle(hip_ctx, sh, sw, dh, dw, interp):
+    """INTER_CUBIC; INTER_AREA with integer cells (3x, 2x), fractional cells, enlargement on one or
+    both axes, identity."""
+    from scannertools_amd._native import INTER_AREA, INTER_CUBIC
+    code, ocode = (INTER_CUBIC, oracle.INTER_CUBIC) if interp == "cubic" else (INTER_AREA, oracle.INTER_AREA)
+    frames = random_frames(sh + sw + dw, 2, sh, sw)
+    got = hip_ctx.resize(torch.from_numpy(frames).cuda(), dw, dh, code).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh, ocode))
+
+
 @pytest.mark.parametrize("cn", [1, 3, 4])
 def test_resize_channels_nearest_and_identities(hip_ctx, cn):
     from scannertools_amd._native import INTER_NEAREST, StError
@@ -107,7 +122,7 @@ def test_resize_channels_nearest_and_identities(hip_ctx, cn):
     const = np.full((1, 33, 71, cn), 201, np.uint8)
     assert (hip_ctx.resize(torch.from_numpy(const).cuda(), 19, 100).cpu().numpy() == 201).all()
     with pytest.raises(StError):
-        hip_ctx.resize(torch.from_numpy(f).cuda(), 10, 10, interpolation=2)      # INTER_CUBIC: not implemented
+        hip_ctx.resize(torch.from_numpy(f).cuda(), 10, 10, interpolation=4)      # INTER_LANCZOS4: not implemented
 
 
 @pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
@@ -158,7 +173,8 @@ def test_resize_op_target_size_rules():
 
 # ---- ConvertColor -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,code", [("COLOR_BGR2RGB", 4), ("COLOR_RGB2BGR", 4), ("COLOR_BGR2GRAY", 6),
-                                       ("COLOR_RGB2GRAY", 7), ("COLOR_BGR2HSV", 40)])
+                                       ("COLOR_RGB2GRAY", 7), ("COLOR_BGR2HSV", 40), ("COLOR_BGR2YCrCb", 36),
+                                       ("COLOR_RGB2YCrCb", 37), ("COLOR_YCrCb2BGR", 38), ("COLOR_YCrCb2RGB", 39)])
 @pytest.mark.parametrize("h,w", [(1, 1), (37, 53), (480, 640)])
 def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
     frames = random_frames(h + w + code, 2, h, w)

@@ -207,8 +207,22 @@ def test_resize_oracle_identities():
     assert oracle.resize_target(1920, 1080, width=0, height=240, preserve_aspect=True) == (426, 240)
     assert oracle.resize_target(1920, 1080, width=426, height=0, preserve_aspect=True) == (426, 239)
     assert oracle.resize_target(320, 200, width=426, height=240, min=True) == (320, 200)
+    # INTER_CUBIC / INTER_AREA: constants preserved, integer cells are the rounded float mean, the
+    # 2x case equals the linear reroute, fractional cells keep the image mean
+    for interp in (oracle.INTER_CUBIC, oracle.INTER_AREA):
+        for (w, h) in ((32, 24), (16, 16), (21, 13), (100, 77), (90, 20), (13, 100)):
+            assert (oracle.resize_u8(const, w, h, interp) == 137).all()
+    f2 = rng.integers(0, 256, (48, 60, 3), dtype=np.uint8)
+    blocks = f2.reshape(16, 3, 20, 3, 3).astype(np.float32).sum((1, 3)) * np.float32(1 / 9)
+    np.testing.assert_array_equal(oracle.resize_u8(f2, 20, 16, oracle.INTER_AREA), np.rint(blocks).astype(np.uint8))
+    np.testing.assert_array_equal(oracle.resize_u8(f2, 30, 24, oracle.INTER_AREA), oracle.resize_u8(f2, 30, 24))
+    assert abs(oracle.resize_u8(f2, 21, 13, oracle.INTER_AREA).mean() - f2.mean()) < 0.3
+    smooth = np.tile((np.arange(60, dtype=np.float32)[None, :, None] * 4), (48, 1, 3)).astype(np.uint8)
+    cub = oracle.resize_u8(smooth, 120, 96, oracle.INTER_CUBIC).astype(int)
+    lin = oracle.resize_u8(smooth, 120, 96).astype(int)
+    assert np.abs(cub - lin)[:, 4:-4].max() <= 1                         # cubic reproduces a ramp
     with pytest.raises(ValueError):
-        oracle.resize_u8(f, 10, 10, 2)
+        oracle.resize_u8(f, 10, 10, 4)
 
 
 def test_cvt_color_oracle_known_answers():
@@ -233,3 +247,22 @@ def test_cvt_color_oracle_known_answers():
     np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_BGR2GRAY)[..., 0], oracle.gray_u8(f))
     with pytest.raises(ValueError):
         oracle.cvt_color(f, 32)
+
+
+def test_ycrcb_oracle_known_answers():
+    """8-bit YCrCb: OpenCV's values for the primaries, the float definition within rounding, and a
+    round trip within one grey level."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)  # B, G, R
+    y = oracle.cvt_color(px, oracle.COLOR_BGR2YCrCb)[0]
+    assert y.tolist() == [[29, 107, 255], [150, 21, 43], [76, 255, 85], [255, 128, 128], [0, 128, 128], [128, 128, 128]]
+    rng = np.random.default_rng(2)
+    f = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    got = oracle.cvt_color(f, oracle.COLOR_RGB2YCrCb).astype(float)
+    r, g, b = [f[..., i].astype(float) for i in range(3)]
+    Y = 0.299 * r + 0.587 * g + 0.114 * b
+    assert np.abs(got[..., 0] - Y).max() <= 0.51
+    assert np.abs(got[..., 1] - np.clip((r - Y) * 0.713 + 128, 0, 255)).max() <= 1.01
+    assert np.abs(got[..., 2] - np.clip((b - Y) * 0.564 + 128, 0, 255)).max() <= 1.01
+    rt = oracle.cvt_color(oracle.cvt_color(f, oracle.COLOR_RGB2YCrCb), oracle.COLOR_YCrCb2RGB)
+    interior = (got[..., 1] > 0) & (got[..., 1] < 255) & (got[..., 2] > 0) & (got[..., 2] < 255)
+    assert np.abs(rt.astype(int) - f)[interior].max() <= 2
