@@ -1405,7 +1405,8 @@ struct IterArgs {
   long long* prof;          // ST_PROF builds only: per-phase s_memtime stamps of a few workgroups
 };
 
-enum { FLOW_ZERO = 0, FLOW_FIELD = 1, FLOW_COARSE = 2, FLOW_ANY = 3 };
+enum { FLOW_ZERO = 0, FLOW_FIELD = 1, FLOW_COARSE = 2, FLOW_ANY = 3,
+       FLOW_COARSE2 = 4 };  // FLOW_COARSE2: level transition with the coarse level exactly half as tall
 
 // x-dependent half of the INTER_LINEAR up-sample (fixed per thread: a thread owns one column)
 struct CoarseX {
@@ -1437,7 +1438,7 @@ struct FlowRaw {
 template <int MODE = FLOW_ANY>
 __device__ __forceinline__ void flow_issue(const IterArgs& a, const float* __restrict__ fin,
                                            const float* __restrict__ C, const CoarseX& cx, int x, int y, FlowRaw& r) {
-  if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
+  if (MODE == FLOW_COARSE || MODE == FLOW_COARSE2 || (MODE == FLOW_ANY && C)) {
     const float fy = (float)((y + 0.5) * a.scale_y - 0.5);
     const int sy = (int)floorf(fy);
     const int ya = d_clamp(sy, 0, a.ch - 1), yb = d_clamp(sy + 1, 0, a.ch - 1);
@@ -1460,7 +1461,7 @@ __device__ __forceinline__ void flow_issue(const IterArgs& a, const float* __res
 template <int MODE = FLOW_ANY>
 __device__ __forceinline__ float2 flow_finish(const IterArgs& a, const float* __restrict__ fin,
                                               const float* __restrict__ C, const CoarseX& cx, int y, const FlowRaw& r) {
-  if (MODE == FLOW_COARSE || (MODE == FLOW_ANY && C)) {
+  if (MODE == FLOW_COARSE || MODE == FLOW_COARSE2 || (MODE == FLOW_ANY && C)) {
     // cv::resize INTER_LINEAR, 2 channels: horizontal pass then vertical pass, float
     float fy = (float)((y + 0.5) * a.scale_y - 0.5);
     const int sy = (int)floorf(fy);
@@ -1478,6 +1479,47 @@ __device__ __forceinline__ float2 flow_finish(const IterArgs& a, const float* __
   }
   if (MODE == FLOW_FIELD || (MODE == FLOW_ANY && fin)) return make_float2(r.pa.x, r.pa.y);
   return make_float2(0.f, 0.f);
+}
+
+// Level transition with scale_y == 0.5 exactly: the RB = 3 fine rows of a batch (y0 <= y1 <= y2 <= y0+2)
+// read coarse rows s, s+1, s+2 only (s = floor((y0+0.5)/2 - 0.5)), so the batch's neighbourhood is
+// three 16-byte loads per thread instead of six, and 12 registers instead of 24 across phase 2.
+struct FlowRaw3 {
+  f4u8 row[3];
+};
+__device__ __forceinline__ int coarse_row0(const IterArgs& a, int y0) {
+  return (int)floorf((float)((y0 + 0.5) * a.scale_y - 0.5));
+}
+__device__ __forceinline__ void coarse3_issue(const IterArgs& a, const float* __restrict__ C, const CoarseX& cx, int y0,
+                                              FlowRaw3& r) {
+  const int s = coarse_row0(a, y0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int yy = d_clamp(s + j, 0, a.ch - 1);
+    if (cx.pair) {
+      r.row[j] = *reinterpret_cast<const f4u8*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(yy * a.cw + cx.sx));
+    } else {
+      const float2 p = ld_flow(C, yy * a.cw + cx.sx);
+      r.row[j].x = p.x; r.row[j].y = p.y; r.row[j].z = 0.f; r.row[j].w = 0.f;
+    }
+  }
+}
+__device__ __forceinline__ float2 coarse3_finish(const IterArgs& a, const CoarseX& cx, int y0, int y, const FlowRaw3& r) {
+  float fy = (float)((y + 0.5) * a.scale_y - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= sy;
+  const bool up = sy != coarse_row0(a, y0);  // sy - s is 0 or 1
+  const f4u8 pa = up ? r.row[1] : r.row[0], pb = up ? r.row[2] : r.row[1];
+  const float a1 = cx.a1, a0 = cx.a0, b0 = 1.f - fy, b1 = fy;
+  float2 ta, tb;
+  if (cx.pair) {
+    ta.x = pa.x * a0 + pa.z * a1; ta.y = pa.y * a0 + pa.w * a1;
+    tb.x = pb.x * a0 + pb.z * a1; tb.y = pb.y * a0 + pb.w * a1;
+  } else {
+    ta.x = pa.x * 1.f; ta.y = pa.y * 1.f;
+    tb.x = pb.x * 1.f; tb.y = pb.y * 1.f;
+  }
+  return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
 }
 
 template <int MODE = FLOW_ANY>
@@ -1517,7 +1559,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
-  const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
+  const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
   // ring slot s holds M of source row y0 - M + s (clamped) at entry; vs = window sum of row y0
   float ring[W][5];
@@ -1585,7 +1627,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   // is ~10 KB per batch since the flow source is a template parameter, so the five copies fit the
   // 64 KB instruction cache (the first unrolled version, 100 KB, did not).
   // (The level-transition instance keeps the rolled, shifting form: unrolled it spills.)
-  constexpr bool UNR = MODE != FLOW_COARSE;
+  constexpr bool UNR = MODE != FLOW_COARSE && MODE != FLOW_COARSE2;
   constexpr int NB = UNR ? W / RB : 1;
 #pragma unroll 1
   for (int ybase = y0; ybase < y1; ybase += NB * RB) {
@@ -1635,9 +1677,14 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
         }
         // flows of the batch after next: requested here, turned into vectors after phase 2 (the
         // up-sampling arithmetic of the level transition must not wait on loads issued just now)
-        FlowRaw raw[RB];
+        FlowRaw raw[MODE == FLOW_COARSE2 ? 1 : RB];
+        FlowRaw3 raw3;
+        if (MODE == FLOW_COARSE2) {
+          coarse3_issue(a, C, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), raw3);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+          for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+        }
         PSTAMP();
         __syncthreads();
         PSTAMP();
@@ -1673,7 +1720,12 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+        for (int r = 0; r < RB; ++r) {
+          if (MODE == FLOW_COARSE2)
+            fn[r] = coarse3_finish(a, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw3);
+          else
+            fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+        }
         PSTAMP();
         __syncthreads();
         PSTAMP();
@@ -1922,7 +1974,8 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
   a.prof = (a.h >= 1000) ? prof_buf : nullptr;
 #endif
-  if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+  if (a.coarse && a.h == 2 * a.ch) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE2>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
   else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
   else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
