@@ -1,0 +1,70 @@
+"""Seeded differential fuzzing of every op against the CPU oracle through the C ABI: random small and
+ragged shapes, random parameters.  Integer ops must agree bit for bit, flows within the stated
+tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from scannertools_amd._native import COLOR_CODES
+from util import smooth_texture
+
+pytestmark = pytest.mark.gpu
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_integer_ops(hip_ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(8):
+        h, w, n = int(rng.integers(1, 98)), int(rng.integers(1, 132)), int(rng.integers(1, 4))
+        frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        if rng.random() < 0.3:                                   # low-entropy frames: heavy bin collisions
+            frames = (frames // 64 * 64).astype(np.uint8)
+        fr = _cu(frames)
+        bins = int(rng.integers(1, 257))
+        got = hip_ctx.histogram(fr, bins).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.hist_u8c3(frames[i], bins), err_msg="hist %dx%d bins %d" % (h, w, bins))
+        k = int(rng.integers(1, 12))
+        got = hip_ctx.box_blur(fr, k).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.box_blur(frames[i], k), err_msg="blur %dx%d k %d" % (h, w, k))
+        dh, dw, interp = int(rng.integers(1, 120)), int(rng.integers(1, 150)), int(rng.integers(0, 4))
+        got = hip_ctx.resize(fr, dw, dh, interp).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh, interp),
+                                          err_msg="resize %dx%d -> %dx%d interp %d" % (h, w, dh, dw, interp))
+        name = list(COLOR_CODES)[int(rng.integers(0, len(COLOR_CODES)))]
+        src = frames[..., :1] if "GRAY2" in name else frames
+        got = hip_ctx.cvt_color(_cu(src), name).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.cvt_color(src[i], COLOR_CODES[name]), err_msg=name)
+        flows = (rng.standard_normal((n, h, w, 2)) * float(rng.choice([0.3, 3.0, 40.0]))).astype(np.float32)
+        got = hip_ctx.flow_histogram(_cu(flows)).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.flow_hist(flows[i]), err_msg="flow_hist %dx%d" % (h, w))
+        got = hip_ctx.draw_flow(fr, _cu(flows)).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.draw_flow(frames[i], flows[i]), err_msg="draw_flow %dx%d" % (h, w))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_optical_flow(hip_ctx, seed):
+    """Random frame sizes (including ones smaller than the window and ones that change the number of
+    pyramid levels) and random pair lists; every flow field against the oracle."""
+    rng = np.random.default_rng(77 + seed)
+    for _ in range(4):
+        h, w = int(rng.integers(2, 150)), int(rng.integers(2, 200))
+        nf = int(rng.integers(2, 5))
+        base = np.stack([smooth_texture(int(rng.integers(1 << 30)), h + 8, w + 8) for _ in range(3)], -1)
+        frames = np.stack([base[dy:dy + h, dx:dx + w] for dy, dx in rng.integers(0, 9, (nf, 2))]).astype(np.uint8)
+        pairs = [(int(a), int(b)) for a, b in rng.integers(0, nf, (int(rng.integers(1, 5)), 2))]
+        got = hip_ctx.optical_flow(_cu(frames), pairs=pairs).cpu().numpy()
+        for i, (a, b) in enumerate(pairs):
+            ref = oracle.optical_flow_rgb(frames[a], frames[b])
+            assert np.abs(got[i] - ref).max() <= 5e-3, (h, w, a, b, np.abs(got[i] - ref).max())
+            assert np.linalg.norm(got[i] - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-30) + 1e-6, (h, w, a, b)
