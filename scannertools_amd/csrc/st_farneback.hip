@@ -1957,14 +1957,23 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-  // One round of resident workgroups per launch (2 per CU at this register budget) when the level
-  // is big enough: the ring initialisation (15 rows of UpdateMatrices per segment) is pure
-  // overhead, so segments are as tall as parallelism allows; whole ring periods.
-  long long target = (long long)ctx->num_cus * 2;
-  long long segs = (target + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
-  int rows = (int)((a.h + segs - 1) / segs);
-  rows = (rows + 14) / 15 * 15;
-  if (rows < 15) rows = 15;
+  // Segment height = whole ring periods (15 rows).  Two workgroups are resident per CU at this
+  // register budget, so a launch runs in rounds of 2*CUs workgroups that each cost their rows plus
+  // the 15 rows of ring initialisation: pick the segment count that minimises
+  // rounds x (rows + 15) -- one round of tall segments when the batch is large (256 pairs x 8
+  // strips = exactly four rounds), more, shorter segments when that fills a partial round.
+  const long long resident = (long long)ctx->num_cus * 2;
+  const int periods = (a.h + 14) / 15;
+  int rows = periods * 15;
+  double best = 1e300;
+  for (int segs = 1; segs <= periods; ++segs) {
+    const int r = (periods + segs - 1) / segs * 15;
+    const long long nseg = (a.h + r - 1) / r;
+    const long long wgs = (long long)strips * n_pairs * nseg;
+    const long long rounds = (wgs + resident - 1) / resident;
+    const double cost = (double)rounds * (r + 15);
+    if (cost < best * 0.999) { best = cost; rows = r; }
+  }
   a.rows_per_seg = rows;
   dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
