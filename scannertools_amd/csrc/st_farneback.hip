@@ -1898,7 +1898,10 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, cons
   long long segs = ((long long)ctx->num_cus * 8 + (long long)strips * n - 1) / ((long long)strips * n);
   int rows = (int)((h + segs - 1) / segs);
   rows = (rows + 7) / 8 * 8;
-  if (rows < 64) rows = h < 64 ? h : 64;
+  // (a few frames only: down to 16-row segments -- twice the rows are read, but the launch is
+  // latency-bound and needs the workgroups)
+  const int min_rows = (long long)strips * n * ((h + 63) / 64) >= 2LL * ctx->num_cus ? 64 : 16;
+  if (rows < min_rows) rows = h < min_rows ? h : min_rows;
   a.rows_per_seg = rows;
   st_timed t(ctx, ST_K_PYR);
   hipLaunchKernelGGL(k_pyr_fused, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
