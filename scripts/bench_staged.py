@@ -6,6 +6,11 @@ import numpy as np
 from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
 n, h, w = int(os.environ.get("N", 128)), 1080, 1920
 frames = np.random.default_rng(0).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+if os.environ.get("PIN", "1") != "0":
+    # Scanner hands CPU kernels frames from its own (page-locked, when GPUs are present) allocator;
+    # PIN=0 feeds pageable numpy memory instead
+    import torch
+    frames = torch.from_numpy(frames).pin_memory().numpy()
 sc = Client()
 sc.ingest_frames("v", frames)
 frame = sc.io.Input([NamedVideoStream(sc, "v")])
