@@ -192,3 +192,66 @@ def test_engine_reports_missing_gpu_cleanly():
     hist = sc.ops.Histogram(frame=frame, device=DeviceType.CPU)
     with pytest.raises(RuntimeError, match="st_ctx_create"):
         sc.run(sc.io.Output(hist, [NamedStream(sc, "o")]), PerfParams.estimate())
+
+
+def test_op_library_under_address_and_ub_sanitizers(tmp_path):
+    """The Scanner-side host code (kernel classes, argument parsing, shim registries and the failure
+    path of kernel creation without a GPU) built with -fsanitize=address,undefined and driven through
+    the Python engine in a child process.  (GPU code cannot run under ASan on this pool.)"""
+    import shutil
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the failure path is not taken")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or shutil.which("g++") is None:
+        pytest.skip("no libasan / g++")
+    from scannertools_amd import _native
+    _native.build()
+    lib = tmp_path / "libscannertools_imgproc.so"
+    kdir = os.path.join(ROOT, "scannertools_amd", "scanner_kernels")
+    srcs = [os.path.join(kdir, f) for f in sorted(os.listdir(kdir)) if f.endswith(".cpp")]
+    flags = ["-O1", "-std=c++17", "-fPIC", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+             "-I" + os.path.join(ROOT, "scanner_shim"), "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+             "-D__HIP_PLATFORM_AMD__"]
+    srcs.append(os.path.join(ROOT, "scanner_shim", "shim.cpp"))
+    objs, procs = [], []
+    for src in srcs:  # one compiler process per translation unit
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen(["g++"] + flags + ["-c", src, "-o", obj]))
+    assert all(pr.wait() == 0 for pr in procs)
+    subprocess.check_call(["g++", "-shared", "-fsanitize=address,undefined", "-o", str(lib)] + objs +
+                          ["-L" + os.path.dirname(_native.LIB_PATH), "-lscannertools_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.dirname(_native.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    script = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from scannertools_amd import engine
+engine.IMGPROC_LIB = %r
+from scannertools_amd.engine import Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+assert len(engine.registered_kernels()) >= 12
+assert engine.op_info("Resize")["frame_output"] and engine.op_info("NoSuchOp") is None
+sc = Client()
+sc.ingest_frames("v", np.zeros((2, 8, 8, 3), np.uint8))
+frame = sc.io.Input([NamedVideoStream(sc, "v")])
+errors = []
+for mk in (lambda: sc.ops.Histogram(frame=frame), lambda: sc.ops.Blur(frame=frame, kernel_size=3, sigma=0.1),
+           lambda: sc.ops.Resize(frame=frame, width=4, height=4, interpolation="INTER_AREA"),
+           lambda: sc.ops.ConvertColor(frame=frame, conversion="COLOR_RGB2GRAY"),
+           lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.GPU), lambda: sc.ops.FlowHistogram(flow=frame),
+           lambda: sc.ops.Blur(frame=frame, kernel_size=0)):
+    try:
+        sc.run(sc.io.Output(mk(), [NamedStream(sc, "o")]), PerfParams.estimate())
+    except RuntimeError as e:
+        errors.append(str(e))
+assert len(errors) == 7, errors
+assert any("Could not parse BlurArgs" in e for e in errors)
+print("sanitized run ok")
+''' % (ROOT, str(lib))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "sanitized run ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-4000:]
