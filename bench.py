@@ -274,6 +274,7 @@ def main():
             threads = min(cores, 64)
             sample = batches[0][:min(B + 1, 9)].cpu().numpy()
             v, n_pairs, secs = cpu_baseline(sample, threads, args.cpu_pairs_per_thread)
+            v1, n1, secs1 = cpu_baseline(sample, 1, 2)  # one Scanner kernel instance (1 thread and all cores)
             result["cpu_baseline"] = {
                 "value": v,
                 "unit": "frames/s",
@@ -282,6 +283,9 @@ def main():
                 "sample": "%d pairs of the same %dx%d stream (histogram + Farneback per frame), %d oracle "
                           "instances on %d threads, %.1f s wall" % (n_pairs, w, h, threads, threads, secs),
                 "host_cores": cores,
+                "single_thread": {"value": v1, "unit": "frames/s", "cores": 1,
+                                  "sample": "%d pairs, %.1f s wall" % (n1, secs1)},
+                "gpu_over_cpu": {"all_cores": fps / v if v > 0 else None, "single_thread": fps / v1 if v1 > 0 else None},
             }
         print(json.dumps(result), flush=True)
     if world > 1:
