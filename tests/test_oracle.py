@@ -266,3 +266,50 @@ def test_ycrcb_oracle_known_answers():
     rt = oracle.cvt_color(oracle.cvt_color(f, oracle.COLOR_RGB2YCrCb), oracle.COLOR_YCrCb2RGB)
     interior = (got[..., 1] > 0) & (got[..., 1] < 255) & (got[..., 2] > 0) & (got[..., 2] < 255)
     assert np.abs(rt.astype(int) - f)[interior].max() <= 2
+
+
+def test_resize_oracle_against_torch_conventions():
+    """Independent cross-check of the sampling conventions (not a bit pin): torch's float
+    interpolate uses the same half-pixel centres (bilinear / bicubic with A = -0.75), the same
+    floor(x*scale) nearest rule and the same cell averaging ('area') as the OpenCV algorithms
+    restated in the oracle, so the 8-bit results must agree within the fixed-point rounding."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (12, 16, 3)).astype(np.float32)
+    img = np.clip(np.kron(base, np.ones((8, 8, 1), np.float32)) + rng.normal(0, 3, (96, 128, 3)), 0, 255).astype(np.uint8)
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+
+    def tor(mode, size, **kw):
+        return F.interpolate(t, size=size, mode=mode, **kw)[0].permute(1, 2, 0).numpy()
+
+    for (dh, dw) in ((48, 64), (37, 51), (150, 170), (96, 200)):
+        lin = oracle.resize_u8(img, dw, dh).astype(np.float32)
+        if not (dh * 2 == 96 and dw * 2 == 128):
+            assert np.abs(lin - tor("bilinear", (dh, dw), align_corners=False)).max() <= 1.0
+        near = oracle.resize_u8(img, dw, dh, oracle.INTER_NEAREST)
+        np.testing.assert_array_equal(near, tor("nearest", (dh, dw)).astype(np.uint8))
+        cub = oracle.resize_u8(img, dw, dh, oracle.INTER_CUBIC).astype(np.float32)
+        ref = np.clip(tor("bicubic", (dh, dw), align_corners=False), 0, 255)
+        assert np.abs(cub - ref)[2:-2, 2:-2].max() <= 1.5            # borders: replicate vs torch's clamp of the index
+    def box_average(a, dh, dw):
+        """Definition of area resampling: mean of the source over each destination cell, cells of
+        fractional extent weighted by their overlap (float64)."""
+        def weights(src, dst):
+            s = src / dst
+            wm = np.zeros((dst, src))
+            for d in range(dst):
+                lo, hi = d * s, min((d + 1) * s, src)
+                for i in range(int(np.floor(lo)), int(np.ceil(hi))):
+                    wm[d, i] = max(0.0, min(hi, i + 1) - max(lo, i))
+                wm[d] /= wm[d].sum()
+            return wm
+        wy, wx = weights(a.shape[0], dh), weights(a.shape[1], dw)
+        return np.einsum("yi,ijc,xj->yxc", wy, a.astype(np.float64), wx)
+
+    for (dh, dw) in ((48, 64), (32, 32), (24, 16), (37, 51), (95, 127), (13, 100 // 3)):
+        area = oracle.resize_u8(img, dw, dh, oracle.INTER_AREA).astype(np.float64)
+        assert np.abs(area - box_average(img, dh, dw)).max() <= 0.51
+    for (dh, dw) in ((48, 64), (32, 32), (24, 16)):                   # integer cells: torch's 'area' is the same mean
+        area = oracle.resize_u8(img, dw, dh, oracle.INTER_AREA).astype(np.float32)
+        assert np.abs(area - tor("area", (dh, dw))).max() <= 0.51
