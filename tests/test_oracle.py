@@ -313,3 +313,35 @@ def test_resize_oracle_against_torch_conventions():
     for (dh, dw) in ((48, 64), (32, 32), (24, 16)):                   # integer cells: torch's 'area' is the same mean
         area = oracle.resize_u8(img, dw, dh, oracle.INTER_AREA).astype(np.float32)
         assert np.abs(area - tor("area", (dh, dw))).max() <= 0.51
+
+
+def test_farneback_oracle_against_independent_float64_derivation():
+    """The C restatement of cv::FarnebackOpticalFlow vs an independent float64 implementation of
+    the published algorithm built from scipy/torch primitives (tests/ref_farneback_np.py): every
+    stage and the end-to-end flow agree to float32 rounding.  Not a pin against OpenCV output, but
+    it rules out indexing / border / ordering errors in the restatement."""
+    import ref_farneback_np as ref
+    h, w = 264, 328                                              # 3 pyramid levels + full resolution
+    f0, f1 = translated_rgb_pair(21, h, w, 3, -2)
+    g0, g1 = oracle.gray_u8(f0), oracle.gray_u8(f1)
+    assert ref.levels_for(h, w) == oracle.fb_levels(h, w) == 3
+    for k in range(4):
+        a, b = oracle.fb_pyr_image(g0, k), ref.pyramid_image(g0, k)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-4, k
+    I = oracle.fb_pyr_image(g0, 1)
+    R_o, R_r = oracle.polyexp(I), ref.poly_expansion(I.astype(np.float64))
+    assert np.abs(R_o - R_r).max() <= 2e-4 * max(1.0, np.abs(R_r).max())
+    I1 = oracle.fb_pyr_image(g1, 1)
+    R1_o = oracle.polyexp(I1)
+    fl = (np.random.default_rng(3).standard_normal(I.shape + (2,)) * 2).astype(np.float32)
+    M_o = oracle.update_matrices(R_o, R1_o, fl)
+    M_r = ref.update_matrices(R_o.astype(np.float64), R1_o.astype(np.float64), fl.astype(np.float64))
+    assert np.abs(M_o - M_r).max() <= 1e-4 * max(1.0, np.abs(M_r).max())
+    flow_o, _ = oracle.update_flow_blur(R_o, R1_o, M_o, 15, False)
+    flow_r = ref.box_solve(M_o.astype(np.float64), 15)
+    assert np.abs(flow_o - flow_r).max() <= 1e-4
+    got, want = oracle.farneback(g0, g1), ref.farneback(g0, g1)
+    assert np.linalg.norm(got - want) <= 2e-4 * np.linalg.norm(want)
+    assert np.abs(got - want).max() <= 2e-3
+    inner = got[40:-40, 40:-40]
+    assert abs(np.median(inner[..., 0]) - 3) < 0.05 and abs(np.median(inner[..., 1]) + 2) < 0.05
