@@ -27,7 +27,10 @@
  *               only assert dtype/shape (scannertools/tests/test_all.py:162-177) and no
  *               OpenCV build exists here to emit golden vectors.  The oracle is pinned
  *               only by analytic known-answer tests (polynomial expansion of exact
- *               quadratics, recovered integer translations, zero-flow identities).
+ *               quadratics, recovered integer translations, zero-flow identities) and
+ *               by an independent float64 derivation of the published algorithm
+ *               (tests/ref_farneback_np.py; stages and end-to-end flow agree to float32
+ *               rounding).
  * The later sections restate the ops either side of the path (each with its own header):
  *   DrawFlow    : pinned by golden vectors produced by importing the reference's vis.py.
  *   Blur        : pinned by the reference source itself (blur_kernel_cpu.cpp spells out the
