@@ -42,6 +42,9 @@ struct BlurArgsK {
 };
 
 // LDS: the staged source rows of the tile, as bytes
+// KS > 0: kernel size known at compile time (the window bytes are then read as whole dwords and
+// unpacked with static shifts); KS == 0: any size, byte reads.
+template <int KS>
 __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   extern __shared__ unsigned smem[];
   const int t = threadIdx.x;
@@ -80,10 +83,26 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   // horizontal sums of staged row r for this thread's 4 bytes: window byte j is staged byte
   // 4t + j, output byte c sums j = c + 3i, i = 0..k-1
   auto hsum = [&](int r, unsigned s[4]) {
-    const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + 4 * t;
     s[0] = s[1] = s[2] = s[3] = 0;
-    for (int i = 0; i < a.k; ++i) {
-      s[0] += row[3 * i]; s[1] += row[3 * i + 1]; s[2] += row[3 * i + 2]; s[3] += row[3 * i + 3];
+    if (KS > 0) {
+      // the window (3*KS + 1 bytes) starts dword aligned at staged dword t of the row
+      constexpr int NW = (3 * KS + 1 + 3) / 4;
+      const unsigned* rw = stage + (size_t)r * a.row_dwords + t;
+      unsigned wd[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) wd[q] = rw[q];
+#pragma unroll
+      for (int i = 0; i < KS; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = 3 * i + c;
+          s[c] += (wd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        }
+    } else {
+      const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + 4 * t;
+      for (int i = 0; i < a.k; ++i) {
+        s[0] += row[3 * i]; s[1] += row[3 * i + 1]; s[2] += row[3 * i + 2]; s[3] += row[3 * i + 3];
+      }
     }
   };
   // ---- vertical running sums, divide, store.  The row that leaves the window is summed again
@@ -405,7 +424,9 @@ ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_d
   const int nrows = BL_ROWS + kernel_size - 1;
   const size_t lds = (size_t)nrows * a.row_dwords * 4;
   if (lds > 160 * 1024) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: kernel_size %d needs %zu B of LDS", kernel_size, lds);
-  ST_HIP(ctx, hipFuncSetAttribute((const void*)k_box_blur_u8c3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void (*kern)(BlurArgsK) = kernel_size == 3 ? k_box_blur_u8c3<3> : kernel_size == 5 ? k_box_blur_u8c3<5>
+                          : kernel_size == 7 ? k_box_blur_u8c3<7> : k_box_blur_u8c3<0>;
+  ST_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nb = 3 * w;
   for (int f0 = 0; f0 < n; f0 += 65535) {
     const int nf = n - f0 < 65535 ? n - f0 : 65535;
@@ -413,7 +434,7 @@ ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_d
     dim3 grid((nb + BL_TILEB - 1) / BL_TILEB, (h + BL_ROWS - 1) / BL_ROWS, nf);
     if (grid.y > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "blur: frame too tall");
     st_timed t(ctx, ST_K_BLUR_OP);
-    hipLaunchKernelGGL(k_box_blur_u8c3, grid, dim3(BL_T), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(BL_T), lds, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;
