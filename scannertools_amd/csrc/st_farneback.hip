@@ -2,13 +2,17 @@
 //
 // Replaces the arithmetic of OpticalFlowKernelCPU::execute
 // (/root/reference/scannertools/scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:36-41):
-//   cv::cvtColor(BGR2GRAY) x2  ->  k_gray
+//   cv::cvtColor(BGR2GRAY) x2  ->  k_gray4 / k_gray
 //   cv::FarnebackOpticalFlow::calc:
-//     convertTo(F32) + GaussianBlur + resize        ->  k_pyr            (one launch per level)
+//     convertTo(F32) + GaussianBlur + resize        ->  k_pyr_fused      (all four levels in one pass over
+//                                                       the gray frame; k_pyr0 / k_pyr_dec / k_pyr per
+//                                                       level for other geometries)
 //     FarnebackPolyExp                              ->  k_polyexp        (row-marching, LDS exchange)
-//     resize(prevFlow)*2 + FarnebackUpdateMatrices  ->  k_update_matrices
-//     FarnebackUpdateFlow_Blur (x numIters)         ->  k_blur_update    (box blur + 2x2 solve with the
-//                                                                          next UpdateMatrices fused in)
+//     resize(prevFlow)*2 + FarnebackUpdateMatrices
+//       + FarnebackUpdateFlow_Blur                  ->  k_flow_iter      (one launch per iteration: M is
+//                                                       recomputed on the fly, never stored)
+//     the same stages unfused                       ->  k_update_matrices, k_blur_update(_v2)
+//                                                       (window sizes other than 15, stage tests)
 // All kernels are batched over frames / pairs through blockIdx.z.  The operand order and the
 // accumulator types (float vs double) of every expression follow the OpenCV scalar code so
 // that, built with -ffp-contract=off, every stage except the running-sum box filter is
@@ -19,7 +23,7 @@
 //   R_k   f32, per frame lh*lw float4 [d/dy, d/dx, yy, xx] then lh*lw float [xy]: one 16-B and one
 //         4-B load per pixel, coalesced across a wave (also for the bilinear gather of R1 when
 //         the flow is smooth); see the note above update_matrices_px
-//   M     f32 planar (5,lh,lw): [G11, G12, G22, h1, h2] (two buffers, ping-pong per iteration)
+//   M     f32 planar (5,lh,lw): [G11, G12, G22, h1, h2] -- unfused path only (ping-pong per iteration)
 //   flow  f32 (lh,lw,2) interleaved (u,v): the op's output format
 #include <cmath>
 #include <cstdlib>
