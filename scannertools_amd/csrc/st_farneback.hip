@@ -2099,9 +2099,35 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   for (int i = 0; i < nf; ++i) aligned4 = aligned4 && ((uintptr_t)frames[i] & 3) == 0;
   ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
   if (pyr1) ST_TRY(launch_pyr_fused(ctx, gray, nf, h, w, p, imgs));
-  for (int k = levels; k >= 0; --k) {
-    if (!pyr1) ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
-    ST_TRY(launch_polyexp(ctx, pyr1 ? imgs[k] : img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
+  // Small batches: the flow iterations of the coarse levels are latency-bound launches of a few
+  // dozen workgroups, so the polynomial expansions of the finer levels (independent of them) run
+  // on a second stream meanwhile; each level's first iteration waits for its expansion.
+  // (ST_NO_OVERLAP=1 keeps everything on one stream.)
+  static const bool no_overlap = getenv("ST_NO_OVERLAP") != nullptr;
+  const bool overlap = pyr1 && fused && levels >= 1 && levels < 7 && npairs <= 16 && !no_overlap;
+  if (overlap) {
+    if (!ctx->aux_stream) {
+      ST_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+      for (auto& e : ctx->aux_events) ST_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipEvent_t pyr_done = ctx->aux_events[7];
+    ST_HIP(ctx, hipEventRecord(pyr_done, ctx->stream));
+    ST_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, pyr_done, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->aux_stream;  // launch helpers (and their timing brackets) use ctx->stream
+    int st = ST_OK;
+    for (int k = levels - 1; k >= 0 && st == ST_OK; --k) {
+      st = launch_polyexp(ctx, imgs[k], nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]);
+      if (st == ST_OK && hipEventRecord(ctx->aux_events[k], ctx->aux_stream) != hipSuccess) st = ST_ERR_HIP;
+    }
+    ctx->stream = main_stream;
+    if (st != ST_OK) return st == ST_ERR_HIP ? st_set_error(ctx, ST_ERR_HIP, "farneback: second-stream launch failed") : st;
+    ST_TRY(launch_polyexp(ctx, imgs[levels], nf, geom[levels].lh, geom[levels].lw, p.poly_n, p.poly_sigma, R[levels]));
+  } else {
+    for (int k = levels; k >= 0; --k) {
+      if (!pyr1) ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
+      ST_TRY(launch_polyexp(ctx, pyr1 ? imgs[k] : img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
+    }
   }
   // per-pair stages, coarse to fine
   if (fused) {
@@ -2111,6 +2137,7 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
     for (int k = levels; k >= 0; --k) {
       const int lh = geom[k].lh, lw = geom[k].lw;
+      if (overlap && k < levels) ST_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_events[k], 0));
       for (int it = 0; it < p.num_iters; ++it) {
         const bool last = it == p.num_iters - 1;
         IterArgs q;

@@ -24,6 +24,9 @@ struct st_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // second stream + events for overlapping independent stages of small batches (created lazily)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_events[8] = {};
   // bump-allocated scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
