@@ -1,4 +1,6 @@
 // Context, error reporting, scratch arena and per-kernel event timing for libscannertools_hip.so.
+#include <cstdlib>
+
 #include "st_internal.h"
 
 int st_set_error(st_ctx* ctx, int status, const char* fmt, ...) {
@@ -53,6 +55,8 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
     return ST_ERR_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* e = getenv("ST_ITER_TILE")) c->tile_mode = atoi(e);
+  if (const char* e = getenv("ST_ITER_TILE_PX")) c->tile_px = atoll(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   *out_ctx = c;

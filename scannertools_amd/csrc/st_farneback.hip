@@ -1748,6 +1748,98 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_flow_iter_tile: the same iteration for launches too small to fill the chip by marching
+// (few pairs, coarse pyramid levels).  A workgroup produces one 32 x 32 tile: UpdateMatrices on
+// the tile plus its 7-pixel apron (replicated at the frame border, as the box filter's
+// BORDER_REPLICATE requires) into LDS, a horizontal and a vertical 15-tap pass (fresh sums in
+// double, row sums handed over as float like the marching kernel's column sums), the 2x2 solve.
+// 2.1x redundant UpdateMatrices work, but thousands of short independent workgroups instead of a
+// few dozen long ones: a level-3 launch drops from ~25 us to ~10 us.
+// ---------------------------------------------------------------------------------------------
+constexpr int FT_T = 32, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
+  __shared__ float Mt[5][FT_S][FT_S + 1];
+  __shared__ float Hs[5][FT_S][FT_T + 1];
+  const int tid = threadIdx.x;
+  const int h = a.h, w = a.w;
+  const int np = h * w;
+  const int pr = blockIdx.z;
+  const int X0 = blockIdx.x * FT_T, Y0 = blockIdx.y * FT_T;
+  const float* __restrict__ R0;
+  const float* __restrict__ R1;
+  if (a.pairs) {
+    R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
+    R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
+  } else {
+    R0 = a.R;
+    R1 = a.R1_direct;
+  }
+  const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
+  const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
+  float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
+
+  // ---- phase 1: M on the tile + apron
+  for (int i = tid; i < FT_S * FT_S; i += 256) {
+    const int ty = i / FT_S, tx = i - ty * FT_S;
+    const int x = d_clamp(X0 - FT_M + tx, 0, w - 1), y = d_clamp(Y0 - FT_M + ty, 0, h - 1);
+    const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, x) : CoarseX{0, 1.f, 0.f, false};
+    const float2 f = iter_flow_at<MODE>(a, fin, C, cx, x, y);
+    float m[5];
+    update_matrices_px(R0, R1, np, h, w, x, y, f.x, f.y, m);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
+  }
+  __syncthreads();
+  // ---- phase 2: horizontal 15-tap sums of every row of the apron-extended tile
+  for (int i = tid; i < FT_S * (FT_T / 8); i += 256) {
+    const int row = i / (FT_T / 8), x0 = (i - row * (FT_T / 8)) * 8;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float* src = &Mt[c][row][x0];
+      double acc = src[0];
+#pragma unroll
+      for (int k = 1; k < 2 * FT_M + 1; ++k) acc += (double)src[k];
+      Hs[c][row][x0] = (float)acc;
+#pragma unroll
+      for (int j = 1; j < 8; ++j) {
+        acc += (double)src[j + 2 * FT_M] - (double)src[j - 1];
+        Hs[c][row][x0 + j] = (float)acc;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: vertical 15-tap sums + solve; thread = (column, 4-row segment)
+  {
+    const int tx = tid & (FT_T - 1), y0 = (tid / FT_T) * 4;
+    const int x = X0 + tx;
+    double t[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      double acc = Hs[c][y0][tx];
+#pragma unroll
+      for (int k = 1; k < 2 * FT_M + 1; ++k) acc += (double)Hs[c][y0 + k][tx];
+      t[c] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j > 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) t[c] += (double)Hs[c][y0 + j + 2 * FT_M][tx] - (double)Hs[c][y0 + j - 1][tx];
+      }
+      const int y = Y0 + y0 + j;
+      const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
+      const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
+      const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
+      if (x < w && y < h)
+        *reinterpret_cast<float2*>(fout + 2 * ((size_t)y * w + x)) =
+            make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
 int check_params(st_ctx* ctx, const st_fb_params& p, int h, int w) {
@@ -1963,6 +2055,22 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 }
 
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
+  // Launches whose marching form would be a handful of short segments take the tile kernel: by
+  // default when the launch covers <= 600 k pixels in total (one 1080p pair: levels 1-3).  The two
+  // kernels associate the window sums differently, so with this rule a pair's flow can differ in
+  // its last float bits (up to a few 1e-3 px where the 2x2 system is ill-conditioned) depending on
+  // how many pairs share the call; ST_ITER_TILE=0 (read at st_ctx_create) keeps the marching
+  // kernel everywhere and with it batch-size-independent results, ST_ITER_TILE=1 forces tiles.
+  const bool tile = ctx->tile_mode == 1 || (ctx->tile_mode != 0 && (long long)n_pairs * a.h * a.w <= ctx->tile_px);
+  if (tile && (a.h + FT_T - 1) / FT_T <= 65535) {
+    dim3 grid((a.w + FT_T - 1) / FT_T, (a.h + FT_T - 1) / FT_T, n_pairs);
+    st_timed t(ctx, ST_K_BLUR_UPDATE);
+    if (a.coarse) hipLaunchKernelGGL(k_flow_iter_tile<FLOW_COARSE>, grid, dim3(256), 0, ctx->stream, a);
+    else if (a.flow_in) hipLaunchKernelGGL(k_flow_iter_tile<FLOW_FIELD>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_flow_iter_tile<FLOW_ZERO>, grid, dim3(256), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+    return ST_OK;
+  }
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
   // Segment height = whole ring periods (15 rows).  Two workgroups are resident per CU at this
   // register budget, so a launch runs in rounds of 2*CUs workgroups that each cost their rows plus

@@ -25,6 +25,11 @@ struct st_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   // second stream + events for overlapping independent stages of small batches (created lazily)
+  // flow-iteration kernel choice for small launches (ST_ITER_TILE, read when the context is created):
+  // -1 by total size (default), 0 never the tile kernel (results independent of the batch size to the
+  // last bit), 1 always
+  int tile_mode = -1;
+  long long tile_px = 600000;
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_events[8] = {};
   // bump-allocated scratch
