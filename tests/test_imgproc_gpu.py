@@ -224,3 +224,27 @@ def test_hsv_histogram_pipeline(device):
         np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(oracle.cvt_color(frames[i], oracle.COLOR_BGR2HSV), 16))
         assert gg.shape == (60, 80, 1)
         np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))
+
+
+def test_empty_batches_and_bad_handles(hip_ctx):
+    """n = 0 is a no-op for every entry point; a null context is an error code, not a crash."""
+    import ctypes
+    from scannertools_amd import _native
+    assert hip_ctx.box_blur([], 3).shape[0] == 0
+    assert hip_ctx.resize([], 4, 4).shape[0] == 0
+    assert hip_ctx.cvt_color([], "COLOR_BGR2GRAY").shape[0] == 0
+    assert hip_ctx.draw_flow([], []).shape[0] == 0
+    assert hip_ctx.flow_histogram([]).shape == (0, 2, 64)
+    L = _native.lib()
+    null = ctypes.c_void_p()
+    tab = (ctypes.c_void_p * 1)()
+    assert L.st_box_blur_u8c3_batch(null, tab, 1, 4, 4, 3, tab) != 0
+    assert L.st_resize_u8_batch(null, tab, 1, 4, 4, 3, 2, 2, 1, tab) != 0
+    assert L.st_cvt_color_u8_batch(null, tab, 1, 4, 4, 3, 6, 15, tab) != 0
+    assert L.st_flow_hist_batch(null, tab, 1, 4, 4, None) != 0
+    assert L.st_draw_flow_batch(null, tab, tab, 1, 4, 4, tab) != 0
+    # null row pointers inside a valid call are rejected before any launch
+    with pytest.raises(_native.StError):
+        hip_ctx._check(L.st_box_blur_u8c3_batch(hip_ctx._h, tab, 1, 4, 4, 3, tab))
+    assert L.st_cvt_color_out_channels(6, 3) == 1 and L.st_cvt_color_out_channels(6, 1) == -1
+    assert L.st_cvt_color_out_channels(12345, 3) == -1
