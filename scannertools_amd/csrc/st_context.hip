@@ -57,6 +57,7 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   c->stream = c->own_stream;
   if (const char* e = getenv("ST_ITER_TILE")) c->tile_mode = atoi(e);
   if (const char* e = getenv("ST_ITER_TILE_PX")) c->tile_px = atoll(e);
+  if (const char* e = getenv("ST_PAIRS_PER_WG")) c->pairs_per_wg = atoi(e) == 2 ? 2 : 1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   *out_ctx = c;
@@ -203,7 +204,10 @@ int st_time_begin(st_ctx* ctx, int id) {
     } else {
       hipEvent_t a, b;
       ST_HIP(ctx, hipEventCreate(&a));
-      ST_HIP(ctx, hipEventCreate(&b));
+      if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return st_set_error(ctx, ST_ERR_HIP, "timing: hipEventCreate failed");
+      }
       t.starts.push_back(a);
       t.stops.push_back(b);
     }
@@ -215,6 +219,7 @@ int st_time_begin(st_ctx* ctx, int id) {
 int st_time_end(st_ctx* ctx, int id) {
   if (!(ctx->timing_mask & (1u << id))) return ST_OK;
   st_timing_slot& t = ctx->timing[id];
+  if (t.used >= t.stops.size()) return st_set_error(ctx, ST_ERR_INVALID, "timing: bracket closed without an open one");
   ST_HIP(ctx, hipEventRecord(t.stops[t.used], ctx->stream));
   t.used++;
   t.launches++;

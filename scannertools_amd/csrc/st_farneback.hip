@@ -1403,6 +1403,7 @@ struct IterArgs {
   float* flow_out;          // per pair (h,w,2), or
   float* const* flow_ptrs;  // device table of per-pair output frames (used when non-null)
   int h, w, ch, cw, rows_per_seg;
+  int n_pairs;              // pairs in this launch (the last workgroup of a two-pair launch may hold one)
   double scale_x, scale_y;  // coarse/fine size ratios as cv::resize computes them
   float mul;                // 1/pyr_scale
   double scale;             // 1/(block_size^2)
@@ -1534,22 +1535,31 @@ __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* _
   return flow_finish<MODE>(a, fin, C, cx, y, r);
 }
 
-template <int M, int RB, typename VT, int MODE>
-__global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
+// NP = pairs per workgroup.  NP == 2: a 512-thread workgroup marches pairs 2z and 2z+1 of a strip in
+// lock-step (they share both barriers of every batch).  In a stream of consecutive pairs the
+// expansion of the middle frame is R1 of the first pair and R0 of the second, so the two halves ask
+// for the same lines of it within one batch and it leaves HBM once instead of twice.
+template <int M, int RB, typename VT, int MODE, int NP>
+__global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterArgs a) {
   constexpr int W = 2 * M + 1;
   constexpr int NSEG = B2_OUT / RB;  // phase-2 segments per row (RB pixels each)
   static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % RB == 0 && RB * NSEG <= B2_T, "bad batch geometry");
-  __shared__ VT V[RB][5][B2_T];
-  __shared__ float2 F[RB][B2_T];
-  const int tid = threadIdx.x;
+  __shared__ VT Vs[NP][RB][5][B2_T];
+  __shared__ float2 Fs[NP][RB][B2_T];
+  const int half = NP == 2 ? (int)(threadIdx.x >> 8) : 0;  // wave-uniform
+  const int tid = NP == 2 ? (int)(threadIdx.x & (B2_T - 1)) : (int)threadIdx.x;
+  VT(*V)[5][B2_T] = Vs[half];
+  float2(*F)[B2_T] = Fs[half];
   const int h = a.h, w = a.w;
   const int np = h * w;
-  const int pr = blockIdx.z;
+  // the idle half of an odd launch repeats the last pair without storing (it must meet the barriers)
+  const int pr_raw = (int)blockIdx.z * NP + half;
+  const int pr = NP == 2 ? min(pr_raw, a.n_pairs - 1) : pr_raw;
   const int x = (int)blockIdx.x * B2_OUT - B2_HALO + tid;
   const int xc = d_clamp(x, 0, w - 1);
   const int y0 = blockIdx.y * a.rows_per_seg;
   const int y1 = min(h, y0 + a.rows_per_seg);
-  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
+  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w && (NP == 1 || pr_raw < a.n_pairs);
 
   const float* __restrict__ R0;
   const float* __restrict__ R1;
@@ -1633,8 +1643,28 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
   // (The level-transition instance keeps the rolled, shifting form: unrolled it spills.)
   constexpr bool UNR = MODE != FLOW_COARSE && MODE != FLOW_COARSE2;
   constexpr int NB = UNR ? W / RB : 1;
+  int since_anchor = 0;  // batches since the last anchor row (rolled form)
 #pragma unroll 1
   for (int ybase = y0; ybase < y1; ybase += NB * RB) {
+    // Anchor rows: at every row y = 15 j > 0 the column sums restart from the fresh sum of the 15
+    // ring rows y-7 .. y+7, added in row order (the slots are in row order at a period boundary).
+    // The sums of a row therefore depend on the frame pair alone, not on where the launch cut the
+    // frame into segments (segments start at multiples of 15) nor on how many pairs share the launch;
+    // k_flow_iter_tile forms the same sums in the same order.  The reference carries one running sum
+    // down the whole frame; re-anchoring bounds the drift of the float-rounded row differences to 14
+    // rows, so this is also the closer of the two to the exact window sum.
+    if (UNR ? ybase > y0 : since_anchor == W / RB) {
+      since_anchor = 0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+      for (int s = 0; s < W; ++s) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
+        __builtin_amdgcn_sched_barrier(0);  // one row's conversions live at a time
+      }
+    }
+    ++since_anchor;
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
       const int ybb = ybase + bb * RB;
@@ -1749,19 +1779,26 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter(IterArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // k_flow_iter_tile: the same iteration for launches too small to fill the chip by marching
-// (few pairs, coarse pyramid levels).  A workgroup produces one 32 x 32 tile: UpdateMatrices on
+// (few pairs, coarse pyramid levels).  A workgroup produces one 30 x 30 tile: UpdateMatrices on
 // the tile plus its 7-pixel apron (replicated at the frame border, as the box filter's
-// BORDER_REPLICATE requires) into LDS, a horizontal and a vertical 15-tap pass (fresh sums in
-// double, row sums handed over as float like the marching kernel's column sums), the 2x2 solve.
-// 2.1x redundant UpdateMatrices work, but thousands of short independent workgroups instead of a
+// BORDER_REPLICATE requires) into LDS, then the window sums in EXACTLY the association of
+// k_flow_iter -- vertically: anchored at rows 15 j (fresh sum of the 15 rows in row order; the
+// reference's initialisation order at row 0), float-rounded row differences added in double in
+// between, handed over as float; horizontally: fresh 15-term sum in double at columns 3 i, two
+// slides after it -- and the same solve.  Tiles start at multiples of 30 in both directions, so
+// the anchors fall on tile rows 0 and 15 and on every third tile column, and the two kernels agree
+// bit for bit: which of them a launch takes is a scheduling matter only.
+// 2.15x redundant UpdateMatrices work, but thousands of short independent workgroups instead of a
 // few dozen long ones: a level-3 launch drops from ~25 us to ~10 us.
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_T = 32, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
+constexpr int FT_T = 30, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
+static_assert(FT_T % (2 * FT_M + 1) == 0 && FT_T % 3 == 0 && B2_OUT % 3 == 0, "tile anchors must coincide with k_flow_iter's");
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
-  __shared__ float Mt[5][FT_S][FT_S + 1];
-  __shared__ float Hs[5][FT_S][FT_T + 1];
+  constexpr int W = 2 * FT_M + 1;
+  __shared__ float Mt[5][FT_S][FT_S];  // 38.7 + 26.4 KB: just inside the 64 KB of static LDS; the access
+  __shared__ float Vt[5][FT_T][FT_S];  // patterns below are conflict-free without padding (lane strides 1 and 3)
   const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
   const int np = h * w;
@@ -1780,7 +1817,7 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
 
-  // ---- phase 1: M on the tile + apron
+  // ---- phase 1: M on the tile + apron (Mt row j = source row Y0 - 7 + j, clamped)
   for (int i = tid; i < FT_S * FT_S; i += 256) {
     const int ty = i / FT_S, tx = i - ty * FT_S;
     const int x = d_clamp(X0 - FT_M + tx, 0, w - 1), y = d_clamp(Y0 - FT_M + ty, 0, h - 1);
@@ -1792,47 +1829,62 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
     for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
   }
   __syncthreads();
-  // ---- phase 2: horizontal 15-tap sums of every row of the apron-extended tile
-  for (int i = tid; i < FT_S * (FT_T / 8); i += 256) {
-    const int row = i / (FT_T / 8), x0 = (i - row * (FT_T / 8)) * 8;
+  // ---- phase 2: column sums of the two 15-row periods of the tile; item = (channel, period, column)
+  for (int i = tid; i < 5 * 2 * FT_S; i += 256) {
+    const int c = i / (2 * FT_S), rem = i - c * (2 * FT_S);
+    const int p = rem / FT_S, col = rem - p * FT_S;
+    const int ya = Y0 + W * p;  // anchor row
+    if (ya >= h) continue;
+    const int la = W * p;       // Mt row of source row ya - 7
+    double vs;
+    if (ya == 0) {
+      // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
+      vs = (double)(Mt[c][FT_M][col] * (float)(FT_M + 2));
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const float* src = &Mt[c][row][x0];
-      double acc = src[0];
+      for (int yy = 1; yy < FT_M; ++yy) vs += (double)Mt[c][FT_M + yy][col];
+      const float d = Mt[c][2 * FT_M][col] - Mt[c][FT_M][col];
+      vs += d;
+    } else {
+      vs = 0;
 #pragma unroll
-      for (int k = 1; k < 2 * FT_M + 1; ++k) acc += (double)src[k];
-      Hs[c][row][x0] = (float)acc;
+      for (int s2 = 0; s2 < W; ++s2) vs += (double)Mt[c][la + s2][col];
+    }
 #pragma unroll
-      for (int j = 1; j < 8; ++j) {
-        acc += (double)src[j + 2 * FT_M] - (double)src[j - 1];
-        Hs[c][row][x0 + j] = (float)acc;
+    for (int j = 0; j < W; ++j) {
+      Vt[c][la + j][col] = (float)vs;
+      if (j + 1 < W) {
+        const float d = Mt[c][la + j + W][col] - Mt[c][la + j][col];
+        vs += d;
       }
     }
   }
   __syncthreads();
-  // ---- phase 3: vertical 15-tap sums + solve; thread = (column, 4-row segment)
-  {
-    const int tx = tid & (FT_T - 1), y0 = (tid / FT_T) * 4;
-    const int x = X0 + tx;
+  // ---- phase 3: row sums + solve; item = (row, 3-pixel group), groups start at x = 3 i
+  for (int i = tid; i < FT_T * (FT_T / 3); i += 256) {
+    const int r = i / (FT_T / 3), g = i - r * (FT_T / 3);
+    const int y = Y0 + r;
+    if (y >= h) continue;
+    const int j0 = FT_M + 3 * g;  // Vt column of the group's first pixel
     double t[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      double acc = Hs[c][y0][tx];
+      const float* vp = &Vt[c][r][j0 - FT_M];
+      double acc = vp[0];
 #pragma unroll
-      for (int k = 1; k < 2 * FT_M + 1; ++k) acc += (double)Hs[c][y0 + k][tx];
+      for (int k = 1; k < W; ++k) acc += (double)vp[k];
       t[c] = acc;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j > 0) {
+    for (int k = 0; k < 3; ++k) {
+      if (k > 0) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) t[c] += (double)Hs[c][y0 + j + 2 * FT_M][tx] - (double)Hs[c][y0 + j - 1][tx];
+        for (int c = 0; c < 5; ++c) t[c] += (double)Vt[c][r][j0 + k + FT_M] - (double)Vt[c][r][j0 + k - FT_M - 1];
       }
-      const int y = Y0 + y0 + j;
       const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
       const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
       const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
-      if (x < w && y < h)
+      const int x = X0 + 3 * g + k;
+      if (x < w)
         *reinterpret_cast<float2*>(fout + 2 * ((size_t)y * w + x)) =
             make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
     }
@@ -2032,8 +2084,11 @@ int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
 int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
   if (a.m == 7) {
     const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-    // whole ring periods (15 rows) per segment; >= 4 workgroups per CU when the level allows
-    long long segs = ((long long)ctx->num_cus * 4 + (long long)strips * n_pairs - 1) / ((long long)strips * n_pairs);
+    // whole ring periods (15 rows) per segment; >= 4 workgroups per CU when the level allows.  The
+    // running sums of this (unfused) path restart per segment, so the segment height must not depend
+    // on how many pairs share the launch: it is derived from the level's size alone (a pair's
+    // result is then the same in any batch).
+    long long segs = ((long long)ctx->num_cus * 4 + (long long)strips - 1) / ((long long)strips);
     int rows = (int)((a.h + segs - 1) / segs);
     rows = (rows + 14) / 15 * 15;
     if (rows < 15) rows = 15;
@@ -2046,7 +2101,7 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
     return ST_OK;
   }
   const int strips = (a.w + (BLUR_T - 2 * a.m) - 1) / (BLUR_T - 2 * a.m);
-  a.rows_per_seg = rows_per_segment(ctx, a.h, strips, n_pairs, 2 * a.m + 1);
+  a.rows_per_seg = rows_per_segment(ctx, a.h, strips, 1, 2 * a.m + 1);  // independent of n_pairs, as above
   dim3 grid(strips, (a.h + a.rows_per_seg - 1) / a.rows_per_seg, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
   hipLaunchKernelGGL(k_blur_update, grid, dim3(BLUR_T), 0, ctx->stream, a);
@@ -2056,11 +2111,12 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   // Launches whose marching form would be a handful of short segments take the tile kernel: by
-  // default when the launch covers <= 600 k pixels in total (one 1080p pair: levels 1-3).  The two
-  // kernels associate the window sums differently, so with this rule a pair's flow can differ in
-  // its last float bits (up to a few 1e-3 px where the 2x2 system is ill-conditioned) depending on
-  // how many pairs share the call; ST_ITER_TILE=0 (read at st_ctx_create) keeps the marching
-  // kernel everywhere and with it batch-size-independent results, ST_ITER_TILE=1 forces tiles.
+  // default when the launch covers <= 600 k pixels in total (one 1080p pair: levels 1-3).  Both
+  // kernels form the window sums in the same association (anchored every 15 rows / 3 columns), so
+  // the choice, like the segment height below, changes the schedule and not one bit of the result:
+  // a pair's flow does not depend on how many pairs share the call.  ST_ITER_TILE=0 / 1 (read at
+  // st_ctx_create) force the marching / the tile kernel (A/B runs, parity tests of each kernel).
+  a.n_pairs = n_pairs;
   const bool tile = ctx->tile_mode == 1 || (ctx->tile_mode != 0 && (long long)n_pairs * a.h * a.w <= ctx->tile_px);
   if (tile && (a.h + FT_T - 1) / FT_T <= 65535) {
     dim3 grid((a.w + FT_T - 1) / FT_T, (a.h + FT_T - 1) / FT_T, n_pairs);
@@ -2072,25 +2128,30 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     return ST_OK;
   }
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-  // Segment height = whole ring periods (15 rows).  Two workgroups are resident per CU at this
-  // register budget, so a launch runs in rounds of 2*CUs workgroups that each cost their rows plus
-  // the 15 rows of ring initialisation: pick the segment count that minimises
-  // rounds x (rows + 15) -- one round of tall segments when the batch is large (256 pairs x 8
-  // strips = exactly four rounds), more, shorter segments when that fills a partial round.
-  const long long resident = (long long)ctx->num_cus * 2;
+  // ST_PAIRS_PER_WG=2: two pairs per workgroup (512 threads, one workgroup per CU); default one pair
+  // per 256-thread workgroup (faster as measured -- see st_internal.h).
+  const int npw = (ctx->pairs_per_wg == 2 && n_pairs >= 2) ? 2 : 1;
+  const int groups = (n_pairs + npw - 1) / npw;
+  // Segment height = whole ring periods (15 rows).  Eight waves are resident per CU at this
+  // register budget (two 256-thread or one 512-thread workgroup), so a launch runs in rounds of
+  // resident workgroups that each cost their rows plus the 15 rows of ring initialisation: pick
+  // the segment count that minimises rounds x (rows + 15) -- one round of tall segments when the
+  // batch is large (256 pairs x 8 strips = exactly four rounds), more, shorter segments when that
+  // fills a partial round.
+  const long long resident = (long long)ctx->num_cus * (2 / npw);
   const int periods = (a.h + 14) / 15;
   int rows = periods * 15;
   double best = 1e300;
   for (int segs = 1; segs <= periods; ++segs) {
     const int r = (periods + segs - 1) / segs * 15;
     const long long nseg = (a.h + r - 1) / r;
-    const long long wgs = (long long)strips * n_pairs * nseg;
+    const long long wgs = (long long)strips * groups * nseg;
     const long long rounds = (wgs + resident - 1) / resident;
     const double cost = (double)rounds * (r + 15);
     if (cost < best * 0.999) { best = cost; rows = r; }
   }
   a.rows_per_seg = rows;
-  dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
+  dim3 grid(strips, (a.h + rows - 1) / rows, groups);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
 #ifdef ST_PROF
   static long long* prof_buf = nullptr;
@@ -2098,10 +2159,21 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
   a.prof = (a.h >= 1000) ? prof_buf : nullptr;
 #endif
-  if (a.coarse && a.h == 2 * a.ch) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE2>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (a.coarse) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter<7, 3, float, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
+  const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
+#define ST_LAUNCH_ITER(MODE_, NP_) \
+  hipLaunchKernelGGL((k_flow_iter<7, 3, float, MODE_, NP_>), grid, dim3(B2_T * NP_), 0, ctx->stream, a)
+  if (npw == 2) {
+    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, 2);
+    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, 2);
+    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, 2);
+    else ST_LAUNCH_ITER(FLOW_ZERO, 2);
+  } else {
+    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, 1);
+    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, 1);
+    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, 1);
+    else ST_LAUNCH_ITER(FLOW_ZERO, 1);
+  }
+#undef ST_LAUNCH_ITER
   ST_HIP(ctx, hipGetLastError());
 #ifdef ST_PROF
   if (a.prof && getenv("ST_PROF_DUMP")) {

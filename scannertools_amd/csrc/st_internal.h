@@ -26,10 +26,14 @@ struct st_ctx {
   hipStream_t stream = nullptr;
   // second stream + events for overlapping independent stages of small batches (created lazily)
   // flow-iteration kernel choice for small launches (ST_ITER_TILE, read when the context is created):
-  // -1 by total size (default), 0 never the tile kernel (results independent of the batch size to the
-  // last bit), 1 always
+  // -1 by total size (default), 0 never the tile kernel, 1 always.  The two kernels agree bit for
+  // bit, so this is a scheduling switch only.
   int tile_mode = -1;
   long long tile_px = 600000;
+  // pairs marched per workgroup by k_flow_iter (ST_PAIRS_PER_WG: 1 or 2).  Two pairs in lock-step
+  // share the middle frame's expansion on chip, but the 8-wave barriers cost more than the saved
+  // traffic returns (measured: 2.24 vs 2.01 ms per launch at 256 pairs of 1080p), so 1 is the default.
+  int pairs_per_wg = 1;
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_events[8] = {};
   // bump-allocated scratch
@@ -74,11 +78,14 @@ inline size_t st_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a
 int st_time_begin(st_ctx* ctx, int id);
 int st_time_end(st_ctx* ctx, int id);
 
+// A bracket is closed only if it was opened: when st_time_begin fails (event creation / record) the
+// launch simply goes untimed; the failure stays in last_error and the slot's counters are untouched.
 struct st_timed {
   st_ctx* ctx;
   int id;
-  st_timed(st_ctx* c, int k) : ctx(c), id(k) { st_time_begin(ctx, id); }
-  ~st_timed() { st_time_end(ctx, id); }
+  bool open;
+  st_timed(st_ctx* c, int k) : ctx(c), id(k), open(st_time_begin(c, k) == ST_OK) {}
+  ~st_timed() { if (open) (void)st_time_end(ctx, id); }
 };
 
 #endif  // ST_INTERNAL_H_

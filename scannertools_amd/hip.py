@@ -13,13 +13,24 @@ from . import _native
 from ._native import FbParams, StError, default_params  # noqa: F401
 
 
-def _require_cuda(t, dtype, name):
+def _require_cuda(t, dtype, name, device=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError("%s must be a CUDA tensor (no CPU fallback exists)" % name)
     if t.dtype != dtype:
         raise TypeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise ValueError("%s must be contiguous" % name)
+    if device is not None and t.device != device:
+        raise ValueError("%s lives on %s but the context runs on %s" % (name, t.device, device))
+
+
+def _check_out(out, shape, dtype, device):
+    """A caller-supplied output buffer is written through its raw pointer: it must be exactly the
+    dense device array the kernel will produce."""
+    _require_cuda(out, dtype, "out", device)
+    if tuple(out.shape) != tuple(shape):
+        raise ValueError("out must have shape %s, got %s" % (tuple(shape), tuple(out.shape)))
+    return out
 
 
 class HipContext:
@@ -104,21 +115,21 @@ class HipContext:
             if n == 0:
                 return torch.zeros((0, 3, bins), dtype=torch.int32, device=self.device)
             for f in frames:
-                _require_cuda(f, torch.uint8, "frame")
+                _require_cuda(f, torch.uint8, "frame", self.device)
             h, w, c = frames[0].shape
             if any(tuple(f.shape) != (h, w, 3) for f in frames):
                 raise ValueError("all frames must be (h,w,3) with equal shape")
-            if out is None:
-                out = torch.empty((n, 3, bins), dtype=torch.int32, device=self.device)
+            out = (torch.empty((n, 3, bins), dtype=torch.int32, device=self.device) if out is None
+                   else _check_out(out, (n, 3, bins), torch.int32, self.device))
             table = (ctypes.c_void_p * n)(*[f.data_ptr() for f in frames])
             self._check(self._L.st_hist_u8c3_batch(self._h, table, n, h, w, bins, ctypes.c_void_p(out.data_ptr())))
             return out
-        _require_cuda(frames, torch.uint8, "frames")
+        _require_cuda(frames, torch.uint8, "frames", self.device)
         if frames.dim() != 4 or frames.shape[3] != 3:
             raise ValueError("frames must be (n,h,w,3)")
         n, h, w, _ = frames.shape
-        if out is None:
-            out = torch.empty((n, 3, bins), dtype=torch.int32, device=self.device)
+        out = (torch.empty((n, 3, bins), dtype=torch.int32, device=self.device) if out is None
+               else _check_out(out, (n, 3, bins), torch.int32, self.device))
         if n == 0:
             return out
         self._check(self._L.st_hist_u8c3_strided(self._h, ctypes.c_void_p(frames.data_ptr()), 3 * h * w, n, h, w,
@@ -138,21 +149,21 @@ class HipContext:
             if n == 0:
                 return torch.zeros((0, 2, 64), dtype=torch.int32, device=self.device)
             for f in flows:
-                _require_cuda(f, torch.float32, "flow")
+                _require_cuda(f, torch.float32, "flow", self.device)
             h, w, _ = flows[0].shape
             if any(tuple(f.shape) != (h, w, 2) for f in flows):
                 raise ValueError("all flows must be (h,w,2) with equal shape")
-            if out is None:
-                out = torch.empty((n, 2, 64), dtype=torch.int32, device=self.device)
+            out = (torch.empty((n, 2, 64), dtype=torch.int32, device=self.device) if out is None
+                   else _check_out(out, (n, 2, 64), torch.int32, self.device))
             table = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flows])
             self._check(self._L.st_flow_hist_batch(self._h, table, n, h, w, ctypes.c_void_p(out.data_ptr())))
             return out
-        _require_cuda(flows, torch.float32, "flows")
+        _require_cuda(flows, torch.float32, "flows", self.device)
         if flows.dim() != 4 or flows.shape[3] != 2:
             raise ValueError("flows must be (n,h,w,2)")
         n, h, w, _ = flows.shape
-        if out is None:
-            out = torch.empty((n, 2, 64), dtype=torch.int32, device=self.device)
+        out = (torch.empty((n, 2, 64), dtype=torch.int32, device=self.device) if out is None
+               else _check_out(out, (n, 2, 64), torch.int32, self.device))
         if n == 0:
             return out
         self._check(self._L.st_flow_hist_strided(self._h, ctypes.c_void_p(flows.data_ptr()), 8 * h * w, n, h, w,
@@ -172,12 +183,12 @@ class HipContext:
             return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
         h, w, _ = fr[0].shape
         for f, g in zip(fr, fl):
-            _require_cuda(f, torch.uint8, "frame")
-            _require_cuda(g, torch.float32, "flow")
+            _require_cuda(f, torch.uint8, "frame", self.device)
+            _require_cuda(g, torch.float32, "flow", self.device)
             if tuple(f.shape) != (h, w, 3) or tuple(g.shape) != (h, w, 2):
                 raise ValueError("frames must be (h,w,3) and flows (h,w,2) with equal h,w")
-        if out is None:
-            out = torch.empty((n, h, 2 * w, 3), dtype=torch.uint8, device=self.device)
+        out = (torch.empty((n, h, 2 * w, 3), dtype=torch.uint8, device=self.device) if out is None
+               else _check_out(out, (n, h, 2 * w, 3), torch.uint8, self.device))
         tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
         tg = (ctypes.c_void_p * n)(*[g.data_ptr() for g in fl])
         to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
@@ -195,11 +206,11 @@ class HipContext:
             return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
         h, w, _ = fr[0].shape
         for f in fr:
-            _require_cuda(f, torch.uint8, "frame")
+            _require_cuda(f, torch.uint8, "frame", self.device)
             if tuple(f.shape) != (h, w, 3):
                 raise ValueError("all frames must be (h,w,3) with equal shape")
-        if out is None:
-            out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device)
+        out = (torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device) if out is None
+               else _check_out(out, (n, h, w, 3), torch.uint8, self.device))
         tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
         to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
         self._check(self._L.st_box_blur_u8c3_batch(self._h, tf, n, h, w, int(kernel_size), to))
@@ -215,11 +226,11 @@ class HipContext:
             return torch.zeros((0, height, width, 3), dtype=torch.uint8, device=self.device)
         h, w, c = fr[0].shape
         for f in fr:
-            _require_cuda(f, torch.uint8, "frame")
+            _require_cuda(f, torch.uint8, "frame", self.device)
             if tuple(f.shape) != (h, w, c):
                 raise ValueError("all frames must have the same (h,w,c) shape")
-        if out is None:
-            out = torch.empty((n, height, width, c), dtype=torch.uint8, device=self.device)
+        out = (torch.empty((n, height, width, c), dtype=torch.uint8, device=self.device) if out is None
+               else _check_out(out, (n, height, width, c), torch.uint8, self.device))
         tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
         to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
         self._check(self._L.st_resize_u8_batch(self._h, tf, n, h, w, c, int(height), int(width), int(interpolation), to))
@@ -239,14 +250,14 @@ class HipContext:
             return torch.zeros((0, 0, 0, 3), dtype=torch.uint8, device=self.device)
         h, w, c = fr[0].shape
         for f in fr:
-            _require_cuda(f, torch.uint8, "frame")
+            _require_cuda(f, torch.uint8, "frame", self.device)
             if tuple(f.shape) != (h, w, c):
                 raise ValueError("all frames must have the same (h,w,c) shape")
         oc = self._L.st_cvt_color_out_channels(int(code), c)
         if oc < 0:
             raise ValueError("conversion code %d on %d-channel frames is not implemented" % (code, c))
-        if out is None:
-            out = torch.empty((n, h, w, oc), dtype=torch.uint8, device=self.device)
+        out = (torch.empty((n, h, w, oc), dtype=torch.uint8, device=self.device) if out is None
+               else _check_out(out, (n, h, w, oc), torch.uint8, self.device))
         tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
         to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
         self._check(self._L.st_cvt_color_u8_batch(self._h, tf, n, h, w, c, int(code), int(gray_bits), to))
@@ -264,13 +275,13 @@ class HipContext:
         if isinstance(frames, (list, tuple)):
             fl = list(frames)
         else:
-            _require_cuda(frames, torch.uint8, "frames")
+            _require_cuda(frames, torch.uint8, "frames", self.device)
             if frames.dim() != 4 or frames.shape[3] != 3:
                 raise ValueError("frames must be (n,h,w,3)")
             fl = [frames[i] for i in range(frames.shape[0])]
         n = len(fl)
         for f in fl:
-            _require_cuda(f, torch.uint8, "frame")
+            _require_cuda(f, torch.uint8, "frame", self.device)
         if n:
             h, w, _ = fl[0].shape
             if any(tuple(f.shape) != (h, w, 3) for f in fl):
@@ -283,12 +294,8 @@ class HipContext:
             if p:
                 raise ValueError("pairs given but no frames")
             return torch.zeros((0, 0, 0, 2), dtype=torch.float32, device=self.device)
-        if out is None:
-            out = torch.empty((p, h, w, 2), dtype=torch.float32, device=self.device)
-        else:
-            _require_cuda(out, torch.float32, "out")
-            if tuple(out.shape) != (p, h, w, 2):
-                raise ValueError("out must be (%d,%d,%d,2)" % (p, h, w))
+        out = (torch.empty((p, h, w, 2), dtype=torch.float32, device=self.device) if out is None
+               else _check_out(out, (p, h, w, 2), torch.float32, self.device))
         if p == 0:
             return out
         prm = params if params is not None else default_params()
@@ -301,7 +308,7 @@ class HipContext:
     # -- stage-level entry points (used by the parity tests) ----------------------------------
     def gray(self, rgb, bits=15):
         self._bind()
-        _require_cuda(rgb, torch.uint8, "rgb")
+        _require_cuda(rgb, torch.uint8, "rgb", self.device)
         h, w, _ = rgb.shape
         out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
         self._check(self._L.st_gray_u8(self._h, ctypes.c_void_p(rgb.data_ptr()), h, w, bits,
@@ -310,7 +317,7 @@ class HipContext:
 
     def pyr_image(self, gray, level, params=None):
         self._bind()
-        _require_cuda(gray, torch.uint8, "gray")
+        _require_cuda(gray, torch.uint8, "gray", self.device)
         prm = params if params is not None else default_params()
         h, w = gray.shape
         lh, lw = ctypes.c_int(), ctypes.c_int()
@@ -324,7 +331,7 @@ class HipContext:
     def polyexp(self, img, poly_n=5, poly_sigma=1.2):
         """(h,w) f32 -> R (h,w,5) f32, OpenCV's interleaved layout (unpacked from the device layout)."""
         self._bind()
-        _require_cuda(img, torch.float32, "img")
+        _require_cuda(img, torch.float32, "img", self.device)
         h, w = img.shape
         out = torch.empty(5 * h * w, dtype=torch.float32, device=self.device)
         self._check(self._L.st_fb_polyexp(self._h, ctypes.c_void_p(img.data_ptr()), h, w, poly_n, poly_sigma,
@@ -334,19 +341,19 @@ class HipContext:
     def update_matrices(self, r0, r1, flow=None, coarse_flow=None, pyr_scale=0.5):
         """R0,R1 (h,w,5) (+ flow (h,w,2) or coarse flow (ch,cw,2)) -> planar M (5,h,w)."""
         self._bind()
-        _require_cuda(r0, torch.float32, "r0")
-        _require_cuda(r1, torch.float32, "r1")
+        _require_cuda(r0, torch.float32, "r0", self.device)
+        _require_cuda(r1, torch.float32, "r1", self.device)
         h, w, _ = r0.shape
         r0, r1 = pack_r(r0), pack_r(r1)
         out = torch.empty((5, h, w), dtype=torch.float32, device=self.device)
         fp = cp = None
         ch = cw = 0
         if coarse_flow is not None:
-            _require_cuda(coarse_flow, torch.float32, "coarse_flow")
+            _require_cuda(coarse_flow, torch.float32, "coarse_flow", self.device)
             ch, cw, _ = coarse_flow.shape
             cp = ctypes.c_void_p(coarse_flow.data_ptr())
         elif flow is not None:
-            _require_cuda(flow, torch.float32, "flow")
+            _require_cuda(flow, torch.float32, "flow", self.device)
             fp = ctypes.c_void_p(flow.data_ptr())
         self._check(self._L.st_fb_update_matrices(self._h, ctypes.c_void_p(r0.data_ptr()), ctypes.c_void_p(r1.data_ptr()),
                                                   fp, cp, ch, cw, pyr_scale, h, w, ctypes.c_void_p(out.data_ptr())))
@@ -356,7 +363,7 @@ class HipContext:
         """One FarnebackUpdateFlow_Blur pass over planar M (5,h,w) (R0, R1: (h,w,5), needed when
         update=True).  Returns (flow (h,w,2), M' (5,h,w) or None)."""
         self._bind()
-        _require_cuda(m, torch.float32, "m")
+        _require_cuda(m, torch.float32, "m", self.device)
         _, h, w = m.shape
         r0 = pack_r(r0) if r0 is not None else None
         r1 = pack_r(r1) if r1 is not None else None
@@ -373,19 +380,19 @@ class HipContext:
     def flow_iteration(self, r0, r1, flow_in=None, coarse_flow=None, pyr_scale=0.5, block_size=15):
         """One fused iteration (UpdateMatrices + box blur + solve) as the production path runs it."""
         self._bind()
-        _require_cuda(r0, torch.float32, "r0")
-        _require_cuda(r1, torch.float32, "r1")
+        _require_cuda(r0, torch.float32, "r0", self.device)
+        _require_cuda(r1, torch.float32, "r1", self.device)
         h, w, _ = r0.shape
         r0, r1 = pack_r(r0), pack_r(r1)
         out = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
         fp = cp = None
         ch = cw = 0
         if coarse_flow is not None:
-            _require_cuda(coarse_flow, torch.float32, "coarse_flow")
+            _require_cuda(coarse_flow, torch.float32, "coarse_flow", self.device)
             ch, cw, _ = coarse_flow.shape
             cp = ctypes.c_void_p(coarse_flow.data_ptr())
         elif flow_in is not None:
-            _require_cuda(flow_in, torch.float32, "flow_in")
+            _require_cuda(flow_in, torch.float32, "flow_in", self.device)
             fp = ctypes.c_void_p(flow_in.data_ptr())
         self._check(self._L.st_fb_flow_iteration(self._h, ctypes.c_void_p(r0.data_ptr()), ctypes.c_void_p(r1.data_ptr()),
                                                  fp, cp, ch, cw, pyr_scale, h, w, block_size,

@@ -73,13 +73,3 @@ def outlier_boundaries(diffs: np.ndarray) -> list:
         flag[i] = diffs[i] - np.mean(window) > 2.5 * np.std(window)
     return [int(i) for i in np.nonzero(flag)[0]]
 
-
-def _outlier_boundaries_loop(diffs: np.ndarray) -> list:
-    """The reference's loop, verbatim in structure (shot_detection.py:21-26); test cross-check."""
-    n = len(diffs)
-    boundaries = []
-    for i in range(1, n):
-        window = diffs[max(i - WINDOW_SIZE, 0):min(i + WINDOW_SIZE, n)]
-        if diffs[i] - np.mean(window) > 2.5 * np.std(window):
-            boundaries.append(i)
-    return boundaries

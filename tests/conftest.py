@@ -34,3 +34,45 @@ def hip_ctx():
     ctx = HipContext(0)
     yield ctx
     ctx.close()
+
+
+# k_flow_iter scheduling modes (ST_ITER_TILE / ST_PAIRS_PER_WG are read when a context is created):
+#   default  kernel by launch size, one pair per workgroup      march    marching kernel everywhere, one pair
+#   tile     tile kernel everywhere                             march2   marching kernel, two pairs per workgroup
+FLOW_MODES = {"default": {}, "march": {"ST_ITER_TILE": "0"}, "tile": {"ST_ITER_TILE": "1"},
+              "march2": {"ST_ITER_TILE": "0", "ST_PAIRS_PER_WG": "2"}}
+
+
+def make_mode_ctx(mode, **kw):
+    """A HipContext created under the environment of one scheduling mode."""
+    from scannertools_amd.hip import HipContext
+    env = FLOW_MODES[mode]
+    keys = ("ST_ITER_TILE", "ST_PAIRS_PER_WG")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        return HipContext(0, **kw)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="session")
+def mode_ctxs():
+    """One context per scheduling mode of the flow iteration (every kernel instance reachable)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    ctxs = {m: make_mode_ctx(m) for m in FLOW_MODES}
+    yield ctxs
+    for c in ctxs.values():
+        c.close()
+
+
+@pytest.fixture(params=list(FLOW_MODES))
+def flow_ctx(request, mode_ctxs):
+    return mode_ctxs[request.param]

@@ -3,12 +3,18 @@
 Stage tests compare each kernel with the oracle's restatement of the same OpenCV routine on
 identical inputs.  The library is built with -ffp-contract=off and follows the scalar operand
 order, so every stage whose arithmetic is per-pixel (gray, pyramid, polynomial expansion,
-UpdateMatrices) must be BIT-EXACT.  The box filter uses running double sums restarted per
-vertical segment (the reference accumulates float-rounded differences from the top of the
+UpdateMatrices) must be BIT-EXACT.  The box filter re-anchors its running double sums every 15
+rows / 3 columns (the reference accumulates float-rounded differences from the top / left of the
 image), so blur-dependent outputs are compared within a tolerance:
   stage   UpdateFlow_Blur : |d flow| <= 1e-4 px, |d M'| <= 1e-4 * max|M'|
   end-to-end flow         : relative L2 <= 1e-4 and max-abs <= 5e-3 px on textured pairs
 (north-star bound: relative L2 <= 1e-3, max-abs <= 1e-2 px).
+
+The flow iteration has two kernels (marching k_flow_iter with one or two pairs per workgroup, and
+k_flow_iter_tile) and a launch-size rule that picks between them; the ``flow_ctx`` fixture runs a
+test under every scheduling mode (conftest.FLOW_MODES), so each kernel instance -- zero / field /
+coarse / half-height coarse flow source x one / two pairs per workgroup x tile -- is compared with
+the oracle, and ``test_schedules_agree_bitwise`` checks that the modes agree to the last bit.
 """
 import numpy as np
 import pytest
@@ -184,29 +190,42 @@ def test_update_flow_blur_other_window(hip_ctx):
 
 
 # ---------------------------------------------------------------- fused iteration (production kernel)
-@pytest.mark.parametrize("h,w", SIZES + [(20, 500), (600, 24), (135, 240)])
-def test_flow_iteration_parity(hip_ctx, h, w):
-    """k_flow_iter == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources."""
+ITER_SIZES = SIZES + [(20, 500), (600, 24), (135, 240), (270, 480), (540, 960)]
+
+
+def _iteration_cases(h, w):
+    """Inputs of the three flow sources of one iteration at (h, w) + the oracle's results."""
     R0, R1 = _expansions(h + 3, h, w)
-    r0, r1 = cu(R0), cu(R1)
     rng = np.random.default_rng(h)
-    # (a) zero flow
+    cases = {}
     M = oracle.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
-    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
-    assert np.abs(hip_ctx.flow_iteration(r0, r1).cpu().numpy() - ref).max() <= 1e-4
-    # (b) a given flow field
+    cases["zero"] = (dict(), oracle.update_flow_blur(R0, R1, M, 15, False)[0])
     fin = (rng.standard_normal((h, w, 2)) * 2).astype(np.float32)
     M = oracle.update_matrices(R0, R1, fin)
-    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
-    assert np.abs(hip_ctx.flow_iteration(r0, r1, flow_in=cu(fin)).cpu().numpy() - ref).max() <= 1e-4
-    # (c) up-sampled coarse flow
+    cases["field"] = (dict(flow_in=fin), oracle.update_flow_blur(R0, R1, M, 15, False)[0])
+    # exactly half as tall when h is even (FLOW_COARSE2 instance), the generic instance otherwise
     ch, cw = (h + 1) // 2, (w + 1) // 2
     coarse = (rng.standard_normal((ch, cw, 2)) * 2).astype(np.float32)
     up = oracle.resize_linear(coarse, h, w) * np.float32(2.0)
     M = oracle.update_matrices(R0, R1, up)
-    ref, _ = oracle.update_flow_blur(R0, R1, M, 15, False)
-    got = hip_ctx.flow_iteration(r0, r1, coarse_flow=cu(coarse), pyr_scale=0.5).cpu().numpy()
-    assert np.abs(got - ref).max() <= 1e-4
+    cases["coarse"] = (dict(coarse_flow=coarse, pyr_scale=0.5), oracle.update_flow_blur(R0, R1, M, 15, False)[0])
+    return R0, R1, cases
+
+
+@pytest.mark.parametrize("h,w", ITER_SIZES)
+def test_flow_iteration_parity(mode_ctxs, h, w):
+    """One fused iteration == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources,
+    under the marching kernel (k_flow_iter) and the tile kernel (k_flow_iter_tile) alike; and the two
+    kernels agree bit for bit."""
+    R0, R1, cases = _iteration_cases(h, w)
+    r0, r1 = cu(R0), cu(R1)
+    for name, (kw, ref) in cases.items():
+        outs = {}
+        for mode in ("march", "tile"):
+            got = mode_ctxs[mode].flow_iteration(r0, r1, **{k: (cu(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+            outs[mode] = got.cpu().numpy()
+            assert np.abs(outs[mode] - ref).max() <= 1e-4, (name, mode, np.abs(outs[mode] - ref).max())
+        np.testing.assert_array_equal(outs["march"], outs["tile"], err_msg=name)
 
 
 # ---------------------------------------------------------------- A3 end to end
@@ -217,7 +236,8 @@ def _check_flow(got, ref):
 
 
 @pytest.mark.parametrize("h,w", [(240, 320), (203, 317), (480, 640), (48, 64)])
-def test_flow_matches_oracle(hip_ctx, h, w):
+def test_flow_matches_oracle(flow_ctx, h, w):
+    hip_ctx = flow_ctx
     f0, f1 = translated_rgb_pair(h, h, w, 3, -2)
     got = hip_ctx.optical_flow(cu(np.stack([f0, f1]))).cpu().numpy()
     assert got.shape == (1, h, w, 2)
@@ -240,8 +260,9 @@ def test_flow_identical_frames(hip_ctx):
     _check_flow(fl, oracle.optical_flow_rgb(f0, f0))
 
 
-def test_flow_stream_batch_pairs_and_direction(hip_ctx):
+def test_flow_stream_batch_pairs_and_direction(flow_ctx):
     """Batched stencil {0,1} over a stream, arbitrary pairs, CPU-kernel direction."""
+    hip_ctx = flow_ctx
     h, w = 120, 160
     frames, _ = texture_stream(2, 6, h, w)
     d = cu(frames)
@@ -257,14 +278,34 @@ def test_flow_stream_batch_pairs_and_direction(hip_ctx):
     assert np.abs(got2[0] - got2[1]).max() > 0.1  # direction matters
 
 
-def test_flow_batch_equals_single(hip_ctx):
-    """Scheduling (segment heights, batching) must not change results bit-for-bit within the HIP path."""
-    h, w = 135, 240
-    frames, _ = texture_stream(3, 4, h, w)
-    d = cu(frames)
-    batch = hip_ctx.optical_flow(d)
-    single = torch.stack([hip_ctx.optical_flow(d[i:i + 2])[0] for i in range(3)])
-    assert rel_l2(batch.cpu().numpy(), single.cpu().numpy()) < 1e-6
+@pytest.mark.parametrize("h,w,n", [(135, 240, 4), (256, 320, 6), (1080, 1920, 4)])
+def test_flow_batch_equals_single(hip_ctx, h, w, n):
+    """A pair's flow must not depend on how a stream is cut into calls (Scanner's work packets are
+    ragged and the reference is deterministic per pair): whole batch == one pair per call == an
+    uneven split, bit for bit, in the default configuration -- although the three use different
+    kernels and segment heights."""
+    if h == 1080:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        low = torch.rand((1, 3, h // 8 + 8, w // 8 + 8), device="cuda", generator=g)
+        tex = torch.nn.functional.interpolate(low, size=(h + 32, w + 32), mode="bicubic", align_corners=False)[0]
+        tex = ((tex - tex.amin()) / (tex.amax() - tex.amin()) * 255).permute(1, 2, 0)
+        d = torch.stack([tex[16 + i:16 + i + h, 16 - 2 * i:16 - 2 * i + w].to(torch.uint8) for i in range(n)]).contiguous()
+    else:
+        d = cu(texture_stream(3, n, h, w)[0])
+    batch = hip_ctx.optical_flow(d).cpu().numpy()
+    single = torch.stack([hip_ctx.optical_flow(d[i:i + 2])[0] for i in range(n - 1)]).cpu().numpy()
+    np.testing.assert_array_equal(batch, single)
+    split = torch.cat([hip_ctx.optical_flow(d[:3]), hip_ctx.optical_flow(d[2:])]).cpu().numpy()
+    np.testing.assert_array_equal(batch, split)
+
+
+def test_schedules_agree_bitwise(mode_ctxs):
+    """Every scheduling mode (kernel choice, pairs per workgroup) gives the same bits end to end."""
+    for (h, w, n) in ((135, 240, 3), (203, 317, 4), (544, 960, 5)):
+        d = cu(texture_stream(h, n, h, w)[0])
+        ref = mode_ctxs["march"].optical_flow(d).cpu().numpy()
+        for mode in ("default", "march2", "tile"):
+            np.testing.assert_array_equal(mode_ctxs[mode].optical_flow(d).cpu().numpy(), ref, err_msg="%s %dx%d" % (mode, h, w))
 
 
 def test_flow_other_params(hip_ctx):
@@ -277,13 +318,44 @@ def test_flow_other_params(hip_ctx):
         _check_flow(got, ref)
 
 
-def test_flow_1080p_pair(hip_ctx):
+def test_flow_1080p_pair(flow_ctx):
+    hip_ctx = flow_ctx
     h, w = 1080, 1920
     f0, f1 = translated_rgb_pair(21, h, w, 4, 3)
     got = hip_ctx.optical_flow(cu(np.stack([f0, f1]))).cpu().numpy()[0]
     _check_flow(got, oracle.optical_flow_rgb(f0, f1))
     inner = got[100:-100, 100:-100]
     assert abs(np.median(inner[..., 0]) - 4) < 0.05 and abs(np.median(inner[..., 1]) - 3) < 0.05
+
+
+def _torch_stream(n, h, w, seed, step=2):
+    """n frames of a smooth texture under a steady translation, generated on the GPU (big sizes)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    m = step * n + 8
+    low = torch.rand((1, 3, (h + 2 * m) // 8 + 2, (w + 2 * m) // 8 + 2), device="cuda", generator=g)
+    tex = torch.nn.functional.interpolate(low, size=(h + 2 * m, w + 2 * m), mode="bicubic", align_corners=False)[0]
+    tex = ((tex - tex.amin()) / (tex.amax() - tex.amin()) * 235 + 10).permute(1, 2, 0)
+    fr = [tex[m + i:m + i + h, m - step * i:m - step * i + w] + torch.randint(-2, 3, (h, w, 3), device="cuda", generator=g)
+          for i in range(n)]
+    return torch.stack([f.clamp(0, 255).to(torch.uint8) for f in fr]).contiguous()
+
+
+def test_flow_1080p_batch_launch_geometry(mode_ctxs):
+    """24 pairs of 1080p in one call: every pyramid level takes the marching kernel (all four flow
+    sources of k_flow_iter, multi-round segment geometry as in the 256-pair benchmark call); a
+    sample of the pairs against the oracle, all of them against the two-pairs-per-workgroup
+    schedule."""
+    h, w, n = 1080, 1920, 25
+    d = _torch_stream(n, h, w, 9)
+    got = mode_ctxs["default"].optical_flow(d)
+    np_frames = d.cpu().numpy()
+    for i in (0, 7, 16, 23):
+        _check_flow(got[i].cpu().numpy(), oracle.optical_flow_rgb(np_frames[i], np_frames[i + 1]))
+    ref2 = mode_ctxs["march2"].optical_flow(d)
+    assert torch.equal(got, ref2)
+    # an odd pair count leaves half a workgroup idle in the last group of the two-pair schedule
+    odd = mode_ctxs["march2"].optical_flow(d[:4])
+    assert torch.equal(odd, got[:3])
 
 
 @pytest.mark.parametrize("h,w", [(1, 1), (1, 40), (40, 1), (2, 2), (3, 5), (31, 33)])
@@ -327,37 +399,37 @@ def test_flow_4k_properties(hip_ctx):
     assert abs(float(inner[..., 0].median()) + 5) < 0.05 and abs(float(inner[..., 1].median()) + 2) < 0.05
     assert float(fl[2, :1500, :3000].abs().max()) < 0.05                              # identical frames
     single = hip_ctx.optical_flow(fr[:2])
-    assert rel_l2(fl[0].cpu().numpy(), single[0].cpu().numpy()) < 1e-6
+    assert torch.equal(fl[0], single[0])
 
 
-def test_flow_in_passes_under_a_scratch_cap(monkeypatch):
+def test_flow_4k_pair_matches_oracle(hip_ctx):
+    """Config 4 resolution against the oracle (one pair; the oracle needs a few seconds at 4K)."""
+    h, w = 2160, 3840
+    d = _torch_stream(2, h, w, 17, step=3)
+    got = hip_ctx.optical_flow(d).cpu().numpy()[0]
+    fr = d.cpu().numpy()
+    _check_flow(got, oracle.optical_flow_rgb(fr[0], fr[1]))
+
+
+def test_flow_in_passes_under_a_scratch_cap():
     """A small workspace limit makes st_farneback_pairs split the batch into passes (frames shared
     by consecutive pairs are then expanded once per pass), for the one-pass pyramid geometry
-    (256x320) and for a generic one (203x317).  With ST_ITER_TILE=0 (marching kernel everywhere) the
-    passes reproduce the single call bit for bit; with the default kernel choice, which depends on
-    the number of pairs in a call, they agree within the flow tolerance.  A cap below what one pair
-    needs is an error, not a fallback."""
-    from scannertools_amd.hip import HipContext
+    (256x320) and for a generic one (203x317).  The passes reproduce the single call bit for bit
+    (the launches differ in size, hence in kernel and segment choice; the results must not).  A cap
+    below what one pair needs is an error, not a fallback."""
+    from conftest import make_mode_ctx
     from scannertools_amd._native import StError
     for (h, w) in ((256, 320), (203, 317)):
         frames, _ = texture_stream(h, 10, h, w)
         fr = torch.from_numpy(frames).cuda()
         pairs = [(i, i + 1) for i in range(9)] + [(4, 2), (7, 7)]
         per_pair = 4 * h * w * (5 * 2 * 1.4 + 2 * 2 + 2)      # rough: two expansions + flow buffers
-        for mode in ("0", None):
-            if mode is None:
-                monkeypatch.delenv("ST_ITER_TILE", raising=False)
-            else:
-                monkeypatch.setenv("ST_ITER_TILE", mode)      # read by st_ctx_create
-            with HipContext(0) as big:
+        for mode in ("default", "march"):
+            with make_mode_ctx(mode) as big:
                 ref = big.optical_flow(fr, pairs=pairs).cpu().numpy()
-            with HipContext(0, workspace_limit=int(3.5 * per_pair)) as small:
+            with make_mode_ctx(mode, workspace_limit=int(3.5 * per_pair)) as small:
                 got = small.optical_flow(fr, pairs=pairs).cpu().numpy()
-            if mode == "0":
-                np.testing.assert_array_equal(got, ref)
-            else:
-                assert np.abs(got - ref).max() <= 5e-3
-                assert np.linalg.norm(got - ref) <= 1e-4 * np.linalg.norm(ref)
-        with HipContext(0, workspace_limit=int(0.2 * per_pair)) as tiny:
+            np.testing.assert_array_equal(got, ref)
+        with make_mode_ctx("default", workspace_limit=int(0.2 * per_pair)) as tiny:
             with pytest.raises(StError):
                 tiny.optical_flow(fr, pairs=pairs)

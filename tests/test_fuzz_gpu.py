@@ -53,9 +53,11 @@ def test_fuzz_integer_ops(hip_ctx, seed):
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_fuzz_optical_flow(hip_ctx, seed):
+def test_fuzz_optical_flow(flow_ctx, seed):
     """Random frame sizes (including ones smaller than the window and ones that change the number of
-    pyramid levels) and random pair lists; every flow field against the oracle."""
+    pyramid levels) and random pair lists; every flow field against the oracle, under every
+    scheduling mode of the flow iteration."""
+    hip_ctx = flow_ctx
     rng = np.random.default_rng(77 + seed)
     for _ in range(4):
         h, w = int(rng.integers(2, 150)), int(rng.integers(2, 200))

@@ -34,8 +34,20 @@ def test_shot_boundaries_contract_and_constants():
         sa.shot_boundaries(None, [np.zeros((2, 16), np.int32)] * 4)
 
 
+def _outlier_boundaries_loop(diffs):
+    """Per-window evaluation of the outlier rule (what shot_detection.py:21-26 does row by row):
+    the cross-check of the product's strided, vectorised evaluation."""
+    W, n = 500, len(diffs)
+    out = []
+    for i in range(1, n):
+        window = diffs[max(i - W, 0):min(i + W, n)]
+        if diffs[i] - np.mean(window) > 2.5 * np.std(window):
+            out.append(i)
+    return out
+
+
 def test_vectorised_window_statistics_equal_the_reference_loop():
-    from scannertools_amd.shot_detection import _outlier_boundaries_loop, outlier_boundaries
+    from scannertools_amd.shot_detection import outlier_boundaries
     rng = np.random.default_rng(0)
     for trial in range(25):
         n = int(rng.integers(1, 3500)) if trial < 22 else (999, 1000, 1001)[trial - 22]
