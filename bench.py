@@ -5,21 +5,32 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 
 OpticalFlow op over a device-resident 1080p frame stream (stencil {0,1}: one flow field per
 consecutive frame pair) together with the per-channel Histogram op on the same frames.  One
 "step" = one batch of B = 256 frames per GPU (257 resident frames, 256
-pairs): Histogram on B frames (256 bins) + OpticalFlow on the B pairs formed with one halo frame.  value = frames/s through both ops,
-whole job (all ranks), inputs already in HBM when the timed region starts.
+pairs): Histogram on B frames (256 bins) + OpticalFlow on the B pairs formed with one halo frame.
+value = frames/s through both ops, whole job (all ranks), inputs already in HBM when the timed
+region starts.
 
 Multi-GPU: frames are independent (pairs need one halo frame), so every rank processes its own
 contiguous shard with no data-path collective ("weak" scaling: per-GPU batch fixed);
 torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the time.
+`python bench.py --gpus N` starts its own N ranks (one child process per GPU, spawned before the
+parent touches the GPU; the parent relays rank 0's line and fails if any rank fails); under an
+external launcher (torch.distributed.run) WORLD_SIZE must equal --gpus.
 
 The JSON line also carries
   roofline     : for the dominant kernel (k_flow_iter: UpdateMatrices + 15x15 box blur + 2x2
-                 solve, one launch per Farneback iteration), algorithmic bytes / HIP-event time
-                 measured live over the timed region on the stream the kernels run on;
-                 peak = 8 TB/s HBM3E spec.
+                 solve, one launch per Farneback iteration): `achieved` = ALGORITHMIC bytes of the
+                 stages it covers (SURVEY.md 8d model) / HIP-event time measured live over the
+                 timed region on the stream the kernels run on; `traffic` = HBM bytes per launch
+                 from the PMC counters of the committed profile; `frac_traffic` = those bytes /
+                 the live launch time / peak (what the memory system really moved).
+  parity       : the bench configuration's own output against the oracle (a 256-pair step taken
+                 outside the timed region; first pairs' flows, first frames' histograms).
   histogram    : frames/s and roofline of the Histogram kernel alone (same run, own timed loop).
   cpu_baseline : the CPU oracle (oracle/oracle.c, a port of the OpenCV algorithms the reference
-                 calls) timed on this host's cores on a bounded sample of the same stream.
+                 calls) on all host cores, median of >= 3 repetitions on a bounded sample.
+  extra        : own timed loops after the headline: config 4 (4K, batch 32), the host-fed
+                 (PCIe-inclusive) rates through the DeviceType::CPU kernel classes, Histogram at
+                 small batches.  None of these is `value`.
 """
 import argparse
 import json
@@ -37,6 +48,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4 copy ceiling of the same guide (report both fractions)
 
 
+# ------------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------------
 def make_stream(torch, device, n, h, w, seed):
     """n RGB frames on the device: a smooth random texture under an integer random-walk
     translation plus +-2 grey levels of per-frame noise (non-trivial flow, well-spread
@@ -64,56 +78,214 @@ def fb_geometry(h, w):
     return [fb_level_geom(h, w, k)[:2] for k in range(levels + 1)]
 
 
-def cpu_baseline(frames_np, threads, pairs_per_thread):
+def iter_model_bytes(h, w, pairs):
+    """Algorithmic bytes of the stages k_flow_iter covers, per step of `pairs` pairs: UpdateMatrices
+    (60 B/px + 8 B/px of coarse flow on the finer levels), the two fused blur+UpdateMatrices passes
+    (80 B/px each) and the final blur (28 B/px) of the stream-amortised model of SURVEY.md 8d:
+    248*sum(P_k) + 8*(sum(P_k) - P_0) per pair.  (The kernel itself moves less: M is never
+    materialised -- DESIGN.md 4.5.)"""
+    geom = fb_geometry(h, w)
+    sum_p = sum(lh * lw for lh, lw in geom)
+    p0 = geom[0][0] * geom[0][1]
+    return (248 * sum_p + 8 * (sum_p - p0)) * pairs, 284 * sum_p
+
+
+def host_threads():
+    """Threads the CPU baseline may use: the cores this process may run on, bounded so that the
+    oracle instances (about 0.2 GB each at 1080p) stay inside half of the available memory."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    avail = None
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(path).read().strip()
+            if v.isdigit():
+                avail = min(avail, int(v)) if avail else int(v)
+        except OSError:
+            pass
+    return cores, avail
+
+
+def cpu_baseline(frames_np, threads, pairs_per_thread, reps, bins, keep=0):
     """T independent oracle instances over disjoint contiguous shards (Scanner's
-    pipeline_instances_per_node model), histogram + flow per frame."""
+    pipeline_instances_per_node model), histogram + flow per frame; `reps` repetitions, median
+    rate.  Returns (median frames/s, per-rep seconds, pairs per rep, {pair index: (hist, flow)} for
+    the first `keep` pairs -- the parity block compares them with the GPU's output)."""
     import oracle
     oracle.lib()
     n_pairs = threads * pairs_per_thread
     assert len(frames_np) >= 2
+    kept = {}
 
     def work(t):
         for j in range(pairs_per_thread):
             i = (t * pairs_per_thread + j) % (len(frames_np) - 1)
-            oracle.hist_u8c3(frames_np[i], 256)
-            oracle.optical_flow_rgb(frames_np[i], frames_np[i + 1])
+            hst = oracle.hist_u8c3(frames_np[i], bins)
+            fl = oracle.optical_flow_rgb(frames_np[i], frames_np[i + 1])
+            if i < keep and i not in kept:
+                kept[i] = (hst, fl)
 
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    secs = []
+    for _ in range(reps):
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        secs.append(time.perf_counter() - t0)
+    return n_pairs / float(np.median(secs)), secs, n_pairs, kept
+
+
+def timed_flow_hist(torch, ctx, _native, batches, B, bins, steps, warmup, barrier, flow_out, hist_out):
+    """W untimed + K timed steps of (Histogram on B frames, OpticalFlow on B pairs); returns the wall
+    time and the HIP-event time / launch count of the flow-iteration kernel inside the timed region."""
+    nb = len(batches)
+
+    def step(i):
+        fr = batches[i % nb]
+        ctx.histogram(fr[:B], bins, out=hist_out)
+        ctx.optical_flow(fr, out=flow_out)
+
+    for i in range(warmup):
+        step(i)
+    barrier()
+    ctx.timing_enable([_native.K_BLUR_UPDATE])
+    ctx.timing_reset()
+    barrier()
     t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+    for i in range(steps):
+        step(i)
+    barrier()
     dt = time.perf_counter() - t0
-    return n_pairs / dt, n_pairs, dt
+    launches, ms = ctx.timing_read(_native.K_BLUR_UPDATE)
+    ctx.timing_enable([])
+    return dt, launches, ms
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256,
-                    help="frames (= flow pairs) per step per GPU; 256 pairs over 257 resident frames = SURVEY.md 8d config 2")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--bins", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs-per-thread", type=int, default=3)
-    args = ap.parse_args()
+def extras(torch, ctx, _native, device, args, batches, hist_out):
+    """Records that are not `value`: each has its own timed loop, run after the headline."""
+    out = {}
+    sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+    # (iii) Histogram at the small batches the reference pipelines pass (old/histograms.py:10-15)
+    h, w, bins = args.height, args.width, args.bins
+    small = {}
+    for nb in (32, 64):
+        if nb > args.batch:
+            continue
+        fr = batches[0][:nb]
+        for _ in range(3):
+            ctx.histogram(fr, bins, out=hist_out[:nb])
+        ctx.timing_enable([_native.K_HIST])
+        ctx.timing_reset()
+        reps = 40
+        for _ in range(reps):
+            ctx.histogram(fr, bins, out=hist_out[:nb])
+        n, ms = ctx.timing_read(_native.K_HIST)
+        ctx.timing_enable([])
+        gbs = (3 * h * w + 3 * bins * 4) * nb * reps / (ms * 1e-3) / 1e9
+        small["batch_%d" % nb] = {"frames_per_s": nb * reps / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / max(n, 1)}
+    out["histogram_small_batches"] = small
 
+    # (i) config 4: OpticalFlow at 4K, batch 32 (BASELINE.json configs[3])
+    if not args.no_4k:
+        H4, W4, B4 = 2160, 3840, 32
+        fr4 = [make_stream(torch, device, B4 + 1, H4, W4, seed=4000 + b) for b in range(2)]
+        fo4 = torch.empty((B4, H4, W4, 2), dtype=torch.float32, device=device)
+        ho4 = torch.empty((B4, 3, bins), dtype=torch.int32, device=device)
+        dt, launches, ms = timed_flow_hist(torch, ctx, _native, fr4, B4, bins, 4, 1, sync, fo4, ho4)
+        it_bytes, frame_bytes = iter_model_bytes(H4, W4, B4)
+        gbs = it_bytes * 4 / (ms * 1e-3) / 1e9
+        out["config4_4k_batch32"] = {
+            "workload": "OpticalFlow + %d-bin Histogram, 3840x2160, 32 pairs per call (33 resident frames)" % bins,
+            "frames_per_s": B4 * 4 / dt, "ms_per_step": dt / 4 * 1e3, "steps": 4,
+            "roofline": {"kernel": "k_flow_iter", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": ms / max(launches, 1)},
+            "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
+        del fr4, fo4, ho4
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+
+    # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the
+    # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
+    try:
+        from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+        n = 128
+        host = batches[0][:n].cpu().pin_memory()
+        # measured H2D rate of this host for the same bytes (pinned -> device)
+        dst = torch.empty_like(batches[0][:n])
+        dst.copy_(host, non_blocking=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(host, non_blocking=True)
+        sync()
+        h2d = 3 * host.numel() / (time.perf_counter() - t0) / 1e9
+        sc = Client(device_id=device.index)
+        sc.ingest_frames("v", host.numpy())
+        frame = sc.io.Input([NamedVideoStream(sc, "v")])
+        fed = {"h2d_GBs_pinned_copy": h2d, "frames": n}
+        for name, mk, nrep in (("Histogram", lambda: sc.ops.Histogram(frame=frame, device=DeviceType.CPU, batch=64, bins=bins), 3),
+                               ("OpticalFlow", lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.CPU, batch=32), 2)):
+            best = None
+            for _ in range(nrep):
+                o = NamedStream(sc, "hf_" + name)
+                sc.execute_seconds = 0.0
+                sc.run(sc.io.Output(mk(), [o]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+                best = sc.execute_seconds if best is None else min(best, sc.execute_seconds)
+            fed[name] = {"frames_per_s": n / best, "input_GBs": n * 3 * h * w / best / 1e9,
+                         "frac_of_h2d": n * 3 * h * w / best / 1e9 / h2d}
+        out["host_fed"] = fed
+    except Exception as e:  # the headline must not die on an auxiliary record
+        out["host_fed"] = {"error": repr(e)}
+    return out
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if args.dry_run:
+        # launcher self-test (CPU, gloo): rendezvous, barriers and the max-over-ranks reduction of the
+        # real path around a dummy step; no kernels run and the line is marked as such
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001 * (rank + 1))
+        dt = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (launcher self-test, no kernels)", "dry_run": True, "value": 0.0,
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / max(args.steps, 1) * 1e3}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -128,50 +300,23 @@ def main():
     flow_out = torch.empty((B, h, w, 2), dtype=torch.float32, device=device)
     hist_out = torch.empty((B, 3, args.bins), dtype=torch.int32, device=device)
 
-    def step(i):
-        fr = batches[i % n_batches]
-        ctx.histogram(fr[:B], args.bins, out=hist_out)
-        ctx.optical_flow(fr, out=flow_out)
-
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    ctx.timing_enable([_native.K_BLUR_UPDATE])
-    ctx.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, blur_launches, blur_ms = timed_flow_hist(torch, ctx, _native, batches, B, args.bins, args.steps, args.warmup,
+                                                 barrier, flow_out, hist_out)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    blur_launches, blur_ms = ctx.timing_read(_native.K_BLUR_UPDATE)
-    ctx.timing_enable([])
 
     frames_total = B * args.steps * world
     fps = frames_total / dt
 
-    # dominant-kernel roofline.  k_flow_iter runs numIters times per level and covers the stages
-    # UpdateMatrices (60 B/px + 8 B/px of coarse flow on the finer levels), the two fused
-    # blur+UpdateMatrices passes (80 B/px each) and the final blur (28 B/px) of the
-    # stream-amortised model of SURVEY.md 8d: 248*sum(P_k) + 8*(sum(P_k) - P_0) bytes per pair.
-    # (The kernel itself moves less: M is never materialised -- see DESIGN.md.)
-    geom = fb_geometry(h, w)
-    sum_p = sum(lh * lw for lh, lw in geom)
-    p0 = geom[0][0] * geom[0][1]
-    blur_bytes_per_step = (248 * sum_p + 8 * (sum_p - p0)) * B
+    blur_bytes_per_step, flow_model_bytes = iter_model_bytes(h, w, B)
     blur_gbs = blur_bytes_per_step * args.steps / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
-    flow_model_bytes = 284 * sum_p  # stream-amortised algorithmic bytes per flow frame
 
     # Histogram kernel alone (same data), its own timed loop
     hist_steps = max(args.steps, 10)
@@ -204,13 +349,17 @@ def main():
     # command (scripts/profile_round.sh -> scripts/pmc_traffic.py -> profiles/traffic.json):
     # 128-B read requests + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes.  None when the
     # profile is missing or was taken at another batch size / resolution.
-    traffic = None
+    traffic = l2_hit = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (B, h, w) == (256, 1080, 1920):
         try:
-            traffic = float(json.load(open(tpath))["k_flow_iter"]["hbm_bytes_per_launch"])
+            tj = json.load(open(tpath))["k_flow_iter"]
+            traffic = float(tj["hbm_bytes_per_launch"])
+            l2_hit = tj.get("L2_hit_rate")
         except Exception:
             traffic = None
+    avg_launch_s = blur_ms / max(blur_launches, 1) * 1e-3
+    traffic_gbs = (traffic / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None
 
     result = None
     if rank == 0:
@@ -238,13 +387,17 @@ def main():
                 "kernel": "k_flow_iter",
                 "bound": "hbm",
                 "achieved": blur_gbs,
+                "achieved_is": "algorithmic bytes of the covered stages (SURVEY 8d model: M priced as if materialised) / measured launch time",
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": blur_gbs / HBM_PEAK_GBS,
-                "frac_of_copy_ceiling": blur_gbs / HBM_COPY_CEILING_GBS,
                 "traffic": traffic,
-                "traffic_GBs": (traffic / (blur_ms / max(blur_launches, 1) * 1e-3) / 1e9) if traffic else None,
-                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/traffic.json)",
+                "traffic_GBs": traffic_gbs,
+                "frac_traffic": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
+                "frac_traffic_of_copy_ceiling": (traffic_gbs / HBM_COPY_CEILING_GBS) if traffic_gbs else None,
+                "l2_hit_rate": l2_hit,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/traffic.json); "
+                                "frac_traffic is what the memory system really moved per second / peak",
                 "algorithmic_bytes_per_launch": blur_bytes_per_step * args.steps / max(blur_launches, 1),
                 "launches": blur_launches,
                 "avg_launch_ms": blur_ms / max(blur_launches, 1),
@@ -270,29 +423,93 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            threads = min(cores, 64)
+            # one more 256-pair step of the bench configuration outside the timed region: its output
+            # is what the oracle results computed by the baseline leg are compared with
+            ctx.histogram(batches[0][:B], args.bins, out=hist_out)
+            ctx.optical_flow(batches[0], out=flow_out)
+            torch.cuda.synchronize(device)
+            keep = min(B, 8)
+            gpu_flow = flow_out[:keep].cpu().numpy()
+            gpu_hist = hist_out[:keep].cpu().numpy()
+            cores, avail = host_threads()
+            threads = cores
+            note = ""
+            if avail:
+                cap = max(1, int(avail * 0.5 / 0.25e9))
+                if cap < threads:
+                    threads, note = cap, " (capped by host memory: %.0f GB available)" % (avail / 1e9)
             sample = batches[0][:min(B + 1, 9)].cpu().numpy()
-            v, n_pairs, secs = cpu_baseline(sample, threads, args.cpu_pairs_per_thread)
-            v1, n1, secs1 = cpu_baseline(sample, 1, 2)  # one Scanner kernel instance (1 thread and all cores)
+            v, secs, n_pairs, kept = cpu_baseline(sample, threads, args.cpu_pairs_per_thread, args.cpu_reps, args.bins, keep)
+            v1, secs1, n1, _ = cpu_baseline(sample, 1, 1, max(args.cpu_reps, 3), args.bins)
             result["cpu_baseline"] = {
                 "value": v,
                 "unit": "frames/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%d pairs of the same %dx%d stream (histogram + Farneback per frame), %d oracle "
-                          "instances on %d threads, %.1f s wall" % (n_pairs, w, h, threads, threads, secs),
+                "sample": "%d pairs per repetition of the same %dx%d stream (histogram + Farneback per frame), %d oracle "
+                          "instances on %d threads%s, median of %d repetitions (%s s)" % (
+                              n_pairs, w, h, threads, threads, note, len(secs), ", ".join("%.1f" % s for s in secs)),
                 "host_cores": cores,
                 "single_thread": {"value": v1, "unit": "frames/s", "cores": 1,
-                                  "sample": "%d pairs, %.1f s wall" % (n1, secs1)},
+                                  "sample": "%d pair per repetition, median of %d (%s s)" % (
+                                      n1, len(secs1), ", ".join("%.2f" % s for s in secs1))},
                 "gpu_over_cpu": {"all_cores": fps / v if v > 0 else None, "single_thread": fps / v1 if v1 > 0 else None},
             }
+            if kept:
+                idx = sorted(kept)
+                ref = np.stack([kept[i][1] for i in idx])
+                got = gpu_flow[idx]
+                result["parity"] = {
+                    "what": "GPU output of one %d-pair step of this configuration vs the oracle, pairs %s" % (B, idx),
+                    "flow_rel_l2": float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)),
+                    "flow_max_abs": float(np.abs(got - ref).max()),
+                    "flow_tolerance": {"rel_l2": 1e-4, "max_abs_px": 5e-3},
+                    "hist_bit_exact": bool(all((gpu_hist[i] == kept[i][0]).all() for i in idx)),
+                }
+        if world == 1 and not args.no_extras:
+            del flow_out
+            ctx.release_workspace()
+            torch.cuda.empty_cache()
+            result["extra"] = extras(torch, ctx, _native, device, args, batches, hist_out)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256,
+                    help="frames (= flow pairs) per step per GPU; 256 pairs over 257 resident frames = SURVEY.md 8d config 2")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra records (4K, host-fed, small histogram batches)")
+    ap.add_argument("--no-4k", action="store_true")
+    ap.add_argument("--cpu-pairs-per-thread", type=int, default=1)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test on CPU (gloo): rendezvous + barriers + reduction around a dummy step")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # one child per GPU, started before this process touches the GPU (it never does)
+        from scannertools_amd.sharding import spawn_ranks
+        return spawn_ranks(__file__, sys.argv[1:], args.gpus, args.master_port)
+    if int(env_world or "1") != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; start it as `python bench.py --gpus N` or under a "
+                         "launcher whose world size equals --gpus\n" % (args.gpus, env_world))
+        return 2
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -7,7 +7,42 @@ collective touches the data path.  The only exchange is the optional gather of t
 histograms (<= 3 KB per frame) onto rank 0 for the stream-global ShotBoundaries op; it runs over
 torch.distributed ("nccl" = RCCL on GPU tensors, "gloo" on CPU tensors).
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def spawn_ranks(script, argv, n, port=0):
+    """One process per GPU without an external launcher: start `n` children of `script argv` with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's stdout, return 0
+    only if every rank exited 0.  The caller must not have touched the GPU (on this pool a process
+    that has initialised HIP must not be replaced, and the children own the devices); this function
+    imports neither torch nor the HIP library."""
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write("%s: rank exit codes %s\n" % (os.path.basename(script), codes))
+        sys.stderr.write(out0 or "")
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
 
 
 def shard_range(n, rank, world):

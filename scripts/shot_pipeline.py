@@ -3,7 +3,8 @@
 across the GPUs of a node.
 
     python scripts/shot_pipeline.py [--frames 10000] [--height 1080 --width 1920]            # 1 GPU
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/shot_pipeline.py
+    python scripts/shot_pipeline.py --gpus 8                 # starts its own 8 ranks (one per GPU)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/shot_pipeline.py --gpus 8
 
 Each rank owns a contiguous shard of the stream (scannertools_amd.sharding.shard_range), generates
 it on its own GPU (a per-shot random texture with small per-frame noise; cuts planted at known
@@ -31,7 +32,23 @@ def main():
     ap.add_argument("--chunk", type=int, default=250)
     ap.add_argument("--bins", type=int, default=16)
     ap.add_argument("--cuts", type=int, default=8)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU self-test of the multi-rank plumbing (gloo): every rank fabricates its shard's "
+                         "per-frame histogram rows instead of running the kernel; shard -> gather -> ShotBoundaries")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # one child per GPU, started before this process touches the GPU (it never does)
+        from scannertools_amd.sharding import spawn_ranks
+        return spawn_ranks(__file__, sys.argv[1:], args.gpus, args.master_port)
+    if int(env_world or "1") != args.gpus:
+        sys.stderr.write("shot_pipeline.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, env_world))
+        return 2
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -101,7 +118,39 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def dry_run(args):
+    """No GPU, no kernel: each rank makes up the histogram rows of its shard (a per-shot base
+    histogram plus small noise), then the real sharding / gather / ShotBoundaries code runs."""
+    import torch
+    import torch.distributed as dist
+    from scannertools_amd.sharding import gather_rows, shard_range
+    from scannertools_amd.shot_detection import shot_boundaries
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = args.frames
+    cuts = sorted({int(n * (i + 1) / (args.cuts + 1)) for i in range(args.cuts)})
+    a, b = shard_range(n, rank, world)
+    px = args.height * args.width
+    rows = np.empty((b - a, 3, args.bins), np.int32)
+    for i in range(a, b):
+        shot = int(np.searchsorted(cuts, i, side="right"))
+        base = np.random.default_rng(shot).multinomial(px, np.random.default_rng(100 + shot).dirichlet(np.ones(args.bins)), 3)
+        rows[i - a] = base + np.random.default_rng(10000 + i).integers(-2, 3, (3, args.bins))
+    full = gather_rows(torch.from_numpy(rows), n, dst=0)
+    if rank == 0:
+        res = shot_boundaries(None, list(full.numpy()))
+        print(json.dumps({"dry_run": True, "frames": n, "n_gpus": world, "bins": args.bins, "boundaries": res[0],
+                          "planted": cuts, "planted_found": all(c in res[0] for c in cuts)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

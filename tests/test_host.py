@@ -107,6 +107,38 @@ def test_two_rank_gloo_shot_pipeline(tmp_path):
     assert np.load(out).tolist() == GOLD["s0_n1000_b16__bounds"].tolist()
 
 
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` must start two ranks itself (the parent never touches the GPU) and
+    relay rank 0's line; exercised on CPU with --dry-run (gloo rendezvous, barriers and the
+    max-over-ranks reduction around a dummy step).  A WORLD_SIZE that contradicts --gpus is an error."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 3
+    assert line["ms_per_step"] >= 2.0                 # the slower rank (2 ms per dummy step) sets the time
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
+
+
+def test_shot_pipeline_starts_its_own_ranks():
+    """scripts/shot_pipeline.py --gpus 2 --dry-run: two gloo ranks, CPU histograms of a tiny stream
+    (numpy bincount standing in for the kernel in the dry run only), gather on rank 0, ShotBoundaries."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shot_pipeline.py"), "--gpus", "2", "--dry-run",
+                        "--frames", "1200", "--height", "24", "--width", "32", "--cuts", "3"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["frames"] == 1200 and line["planted_found"] is True
+
+
 # ---- C ABI --------------------------------------------------------------------------------------
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "scannertools_hip.h")).read()
