@@ -1382,6 +1382,13 @@ __global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
   }
 }
 
+// ST_ABLATE (build-time bit mask, experiments only -- results are then meaningless): 1 no window
+// sums / solve, 2 no UpdateMatrices arithmetic, 4 no expansion loads, 8 no running column sums,
+// 16 no flow stores.  Timing a build with one part removed shows what that part costs in place.
+#ifndef ST_ABLATE
+#define ST_ABLATE 0
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // One full Farneback iteration without materialising M:
 //     flow_out = solve(box_15x15(UpdateMatrices(R0, R1, flow_in)))
@@ -1539,11 +1546,11 @@ __device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* _
 // lock-step (they share both barriers of every batch).  In a stream of consecutive pairs the
 // expansion of the middle frame is R1 of the first pair and R0 of the second, so the two halves ask
 // for the same lines of it within one batch and it leaves HBM once instead of twice.
-template <int M, int RB, typename VT, int MODE, int NP>
+template <int M, int RB, typename VT, int MODE, int NP, int SW>
 __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterArgs a) {
   constexpr int W = 2 * M + 1;
-  constexpr int NSEG = B2_OUT / RB;  // phase-2 segments per row (RB pixels each)
-  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % RB == 0 && RB * NSEG <= B2_T, "bad batch geometry");
+  constexpr int NSEG = B2_OUT / SW;  // phase-2 segments per row (SW pixels each)
+  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % SW == 0 && RB * NSEG <= B2_T, "bad batch geometry");
   __shared__ VT Vs[NP][RB][5][B2_T];
   __shared__ float2 Fs[NP][RB][B2_T];
   const int half = NP == 2 ? (int)(threadIdx.x >> 8) : 0;  // wave-uniform
@@ -1673,7 +1680,7 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
         PSTAMP();
         // ---- phase 3 of the PREVIOUS batch first: its flow rows go out ahead of this batch's
         // loads, so that the stores do not queue behind them in the memory pipeline ----
-        if (writer && ybb > y0) {
+        if (writer && ybb > y0 && !(ST_ABLATE & 16)) {
 #pragma unroll
           for (int r = 0; r < RB; ++r)
             *reinterpret_cast<float2*>(fout + 2 * (size_t)((ybb - RB + r) * w + x)) = F[r][tid];
@@ -1683,16 +1690,30 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           float m[5];
-          um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
+          if (ST_ABLATE & 2) {  // ablation: loads consumed, no UpdateMatrices arithmetic
+            m[0] = L[r].q.x + L[r].t0.x; m[1] = L[r].q.y + L[r].t1.y; m[2] = L[r].b0.z + L[r].qs;
+            m[3] = L[r].b1.w + L[r].ts.x; m[4] = L[r].bs.y + fl[r].x;
+          } else {
+            um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
+          }
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
-            V[r][c][tid] = (VT)vs[c];
-            const float d = m[c] - ring[bb * RB + r][c];
-            vs[c] += d;
+            if (ST_ABLATE & 8) {  // ablation: no running column sums
+              V[r][c][tid] = (VT)(m[c] + ring[bb * RB + r][c]);
+            } else {
+              V[r][c][tid] = (VT)vs[c];
+              const float d = m[c] - ring[bb * RB + r][c];
+              vs[c] += d;
+            }
             ring[bb * RB + r][c] = m[c];  // rolled form: parked in the slot it frees, rotated below
           }
           fl[r] = fn[r];
-          um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
+          if (ST_ABLATE & 4) {  // ablation: no expansion loads
+            L[r].q = make_float4(fl[r].x, fl[r].y, m[0], m[1]); L[r].qs = m[2];
+            L[r].t0 = L[r].t1 = L[r].b0 = L[r].b1 = L[r].q; L[r].ts.x = L[r].ts.y = L[r].bs.x = L[r].bs.y = m[3];
+          } else {
+            um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
+          }
         }
         if (!UNR) {
           float tmp[RB][5];
@@ -1725,8 +1746,11 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
         // ---- phase 2: horizontal window + solve ----
         if (tid < RB * NSEG) {
           const int r = tid / NSEG, sg = tid - r * NSEG;
-          const int j0 = B2_HALO + sg * RB;
-          {
+          const int j0 = B2_HALO + sg * SW;
+          if (ST_ABLATE & 1) {  // ablation: no window sums, no solve
+#pragma unroll
+            for (int i = 0; i < SW; ++i) F[r][j0 + i] = make_float2((float)V[r][3][j0 + i], (float)V[r][4][j0 + i]);
+          } else {
           double t[5];
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
@@ -1738,7 +1762,7 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
             __builtin_amdgcn_sched_barrier(0);
           }
 #pragma unroll
-          for (int i = 0; i < RB; ++i) {
+          for (int i = 0; i < SW; ++i) {
             if (i > 0) {
 #pragma unroll
               for (int c = 0; c < 5; ++c) {
@@ -2150,6 +2174,8 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     const double cost = (double)rounds * (r + 15);
     if (cost < best * 0.999) { best = cost; rows = r; }
   }
+  static const int force_rows = getenv("ST_ITER_ROWS") ? atoi(getenv("ST_ITER_ROWS")) : 0;  // experiments
+  if (force_rows >= 15 && force_rows % 15 == 0 && force_rows < rows) rows = force_rows;
   a.rows_per_seg = rows;
   dim3 grid(strips, (a.h + rows - 1) / rows, groups);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
@@ -2160,19 +2186,18 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   a.prof = (a.h >= 1000) ? prof_buf : nullptr;
 #endif
   const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-#define ST_LAUNCH_ITER(MODE_, NP_) \
-  hipLaunchKernelGGL((k_flow_iter<7, 3, float, MODE_, NP_>), grid, dim3(B2_T * NP_), 0, ctx->stream, a)
-  if (npw == 2) {
-    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, 2);
-    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, 2);
-    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, 2);
-    else ST_LAUNCH_ITER(FLOW_ZERO, 2);
-  } else {
-    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, 1);
-    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, 1);
-    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, 1);
-    else ST_LAUNCH_ITER(FLOW_ZERO, 1);
-  }
+#define ST_LAUNCH_ITER(MODE_, NP_, VT_, SW_) \
+  hipLaunchKernelGGL((k_flow_iter<7, 3, VT_, MODE_, NP_, SW_>), grid, dim3(B2_T * NP_), 0, ctx->stream, a)
+#define ST_LAUNCH_MODES(NP_, VT_, SW_)                                      \
+  do {                                                                      \
+    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, NP_, VT_, SW_);   \
+    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, NP_, VT_, SW_); \
+    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, NP_, VT_, SW_);  \
+    else ST_LAUNCH_ITER(FLOW_ZERO, NP_, VT_, SW_);                           \
+  } while (0)
+  if (npw == 2) ST_LAUNCH_MODES(2, float, 3);
+  else ST_LAUNCH_MODES(1, float, 3);
+#undef ST_LAUNCH_MODES
 #undef ST_LAUNCH_ITER
   ST_HIP(ctx, hipGetLastError());
 #ifdef ST_PROF
