@@ -243,6 +243,18 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                 best = sc.execute_seconds if best is None else min(best, sc.execute_seconds)
             fed[name] = {"frames_per_s": n / best, "input_GBs": n * 3 * h * w / best / 1e9,
                          "frac_of_h2d": n * 3 * h * w / best / 1e9 / h2d}
+        # the same Histogram graph fed from PAGEABLE host memory (the kernel bounces it through its
+        # page-locked ring)
+        sc.ingest_frames("vp", np.array(host.numpy(), copy=True))
+        framep = sc.io.Input([NamedVideoStream(sc, "vp")])
+        best = None
+        for _ in range(2):
+            o = NamedStream(sc, "hf_pageable")
+            sc.execute_seconds = 0.0
+            sc.run(sc.io.Output(sc.ops.Histogram(frame=framep, device=DeviceType.CPU, batch=64, bins=bins), [o]),
+                   PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+            best = sc.execute_seconds if best is None else min(best, sc.execute_seconds)
+        fed["Histogram_pageable_source"] = {"frames_per_s": n / best, "input_GBs": n * 3 * h * w / best / 1e9}
         out["host_fed"] = fed
     except Exception as e:  # the headline must not die on an auxiliary record
         out["host_fed"] = {"error": repr(e)}

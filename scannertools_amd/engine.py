@@ -376,8 +376,8 @@ class _Ops:
     def Histogram(self, frame, device=None, batch=None, bins=None):
         """sc.ops.Histogram(frame=..., device=..., batch=...) (tests/test_all.py:154,
         old/histograms.py:13-14).  ``bins`` is this build's optional extension (default 16)."""
-        import struct
-        args = struct.pack("<i", bins) if bins is not None else b""
+        from . import _proto
+        args = _proto.encode([(1, "int32", int(bins))]) if bins is not None else b""   # HistogramArgs
         node = _CppOpNode(self.sc, "Histogram", frame, device, batch, None, args)
         node.reader = _types.histograms
         return node
