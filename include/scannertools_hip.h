@@ -207,11 +207,12 @@ int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n,
 /* Resize: replaces the cv::resize(img, out, Size(out_w, out_h), 0, 0, interpolation) call of
  * ResizeKernel::execute (scannertools_cpp/imgproc/resize_kernel.cpp:68-73) for U8 frames of 1..4
  * channels.  interpolation takes cv::InterpolationFlags values; ST_INTER_LINEAR (the op's default,
- * resize_kernel.cpp:31), ST_INTER_NEAREST, ST_INTER_CUBIC and ST_INTER_AREA are implemented, the
- * others (INTER_LANCZOS4, ...) return ST_ERR_UNSUPPORTED.
+ * resize_kernel.cpp:31), ST_INTER_NEAREST, ST_INTER_CUBIC, ST_INTER_AREA and ST_INTER_LANCZOS4 are
+ * implemented -- every entry of the reference's table (resize_kernel.cpp:10-17) except the
+ * INTER_MAX mask value, which returns ST_ERR_UNSUPPORTED.
  * The target size is the caller's business (ResizeArgs width/height/min/preserve_aspect,
  * resize_kernel.cpp:44-62, is evaluated by the kernel class). */
-enum st_interpolation { ST_INTER_NEAREST = 0, ST_INTER_LINEAR = 1, ST_INTER_CUBIC = 2, ST_INTER_AREA = 3 };
+enum st_interpolation { ST_INTER_NEAREST = 0, ST_INTER_LINEAR = 1, ST_INTER_CUBIC = 2, ST_INTER_AREA = 3, ST_INTER_LANCZOS4 = 4 };
 int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                        int out_h, int out_w, int interpolation, uint8_t* const* out_dev);
 
@@ -226,7 +227,9 @@ enum st_color_code {
   ST_COLOR_BGR2GRAY = 6, ST_COLOR_RGB2GRAY = 7,
   ST_COLOR_GRAY2BGR = 8, ST_COLOR_GRAY2RGB = 8,
   ST_COLOR_BGR2YCrCb = 36, ST_COLOR_RGB2YCrCb = 37, ST_COLOR_YCrCb2BGR = 38, ST_COLOR_YCrCb2RGB = 39,
-  ST_COLOR_BGR2HSV = 40
+  ST_COLOR_BGR2HSV = 40, ST_COLOR_RGB2HSV = 41, ST_COLOR_HSV2BGR = 54, ST_COLOR_HSV2RGB = 55,
+  ST_COLOR_BGR2HSV_FULL = 66, ST_COLOR_RGB2HSV_FULL = 67, ST_COLOR_HSV2BGR_FULL = 70, ST_COLOR_HSV2RGB_FULL = 71,
+  ST_COLOR_BGR2YUV = 82, ST_COLOR_RGB2YUV = 83, ST_COLOR_YUV2BGR = 84, ST_COLOR_YUV2RGB = 85
 };
 int st_cvt_color_out_channels(int code, int in_channels);
 int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,

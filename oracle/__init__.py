@@ -231,7 +231,7 @@ def box_blur(frame, kernel_size):
     return out
 
 
-INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA = 0, 1, 2, 3
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 
 
 def resize_target(frame_w, frame_h, width=0, height=0, min=False, preserve_aspect=False):
@@ -253,6 +253,9 @@ def resize_u8(frame, width, height, interpolation=INTER_LINEAR):
 
 COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR, COLOR_GRAY2RGB, COLOR_BGR2HSV = 4, 4, 6, 7, 8, 8, 40
 COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB = 36, 37, 38, 39
+COLOR_RGB2HSV, COLOR_HSV2BGR, COLOR_HSV2RGB = 41, 54, 55
+COLOR_BGR2HSV_FULL, COLOR_RGB2HSV_FULL, COLOR_HSV2BGR_FULL, COLOR_HSV2RGB_FULL = 66, 67, 70, 71
+COLOR_BGR2YUV, COLOR_RGB2YUV, COLOR_YUV2BGR, COLOR_YUV2RGB = 82, 83, 84, 85
 
 
 def cvt_color(frame, code, gray_bits=15):

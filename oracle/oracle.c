@@ -789,6 +789,79 @@ static void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uint
   free(xofs); free(ialpha);
 }
 
+/* cv::interpolateLanczos4 (imgproc/src/resize.cpp) */
+static void orc_lanczos4_coeffs(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) coeffs[i] = 0;
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; i++) {
+    const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+/* One axis of the 8-tap table: offset (first tap = offset - 3) and the 11-bit fixed-point weights
+ * saturate_cast<short>(c * 2048).  Also what the HIP launcher builds on the host (same libm). */
+ORC_API void orc_lanczos4_axis(int dsize, double scale, int* ofs, short* coef) {
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = cv_floor_f(f);
+    f -= s;
+    float c[8];
+    orc_lanczos4_coeffs(f, c);
+    ofs[d] = s;
+    for (int k = 0; k < 8; ++k) coef[8 * d + k] = orc_sat_short_round(c[k] * 2048);
+  }
+}
+
+/* INTER_LANCZOS4, 8-bit: 8 x 8 taps from sx - 3 / sy - 3, columns and rows outside the image
+ * replicate the edge (HResizeLanczos4 / clipped row indices), (v + 2^21) >> 22 saturated
+ * (VResizeLanczos4 with FixedPtCast<int, uchar, 22>). */
+static void orc_resize_lanczos4_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw,
+                                   double scale_x, double scale_y) {
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 8 * dw);
+  int* yofs = (int*)malloc(sizeof(int) * dh);
+  short* ibeta = (short*)malloc(sizeof(short) * 8 * dh);
+  orc_lanczos4_axis(dw, scale_x, xofs, ialpha);
+  orc_lanczos4_axis(dh, scale_y, yofs, ibeta);
+  int* rows[8];
+  for (int k = 0; k < 8; ++k) rows[k] = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    for (int k = 0; k < 8; ++k) {
+      const int yy = imin(imax(yofs[dy] - 3 + k, 0), sh - 1);
+      const uint8_t* S = src + (size_t)yy * sw * cn;
+      for (int dx = 0; dx < dw; ++dx)
+        for (int c = 0; c < cn; ++c) {
+          int v = 0;
+          for (int j = 0; j < 8; ++j) {
+            const int sxj = imin(imax(xofs[dx] - 3 + j, 0), sw - 1);
+            v += S[sxj * cn + c] * ialpha[8 * dx + j];
+          }
+          rows[k][dx * cn + c] = v;
+        }
+    }
+    uint8_t* D = dst + (size_t)dy * dw * cn;
+    const short* beta = ibeta + 8 * dy;
+    for (int i = 0; i < dw * cn; ++i) {
+      int v = 0;
+      for (int k = 0; k < 8; ++k) v += rows[k][i] * beta[k];
+      D[i] = orc_sat_u8_int((v + (1 << 21)) >> 22);
+    }
+  }
+  for (int k = 0; k < 8; ++k) free(rows[k]);
+  free(xofs); free(ialpha); free(yofs); free(ibeta);
+}
+
 /* computeResizeAreaTab: the source cells (index, weight) that one axis of an INTER_AREA
  * down-scale accumulates into each destination cell. */
 typedef struct { int di, si; float alpha; } orc_area_tab;
@@ -905,13 +978,14 @@ static void orc_resize_area_u8(const uint8_t* src, int sh, int sw, int cn, uint8
 }
 
 /* interpolation: cv::InterpolationFlags values 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC,
- * 3 = INTER_AREA */
+ * 3 = INTER_AREA, 4 = INTER_LANCZOS4 */
 ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int interpolation) {
-  if (interpolation < 0 || interpolation > 3) return 1;
+  if (interpolation < 0 || interpolation > 4) return 1;
   if (sh == dh && sw == dw) { memcpy(dst, src, (size_t)sh * sw * cn); return 0; }
   const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
   const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
   if (interpolation == 2) { orc_resize_cubic_u8(src, sh, sw, cn, dst, dh, dw, scale_x, scale_y); return 0; }
+  if (interpolation == 4) { orc_resize_lanczos4_u8(src, sh, sw, cn, dst, dh, dw, scale_x, scale_y); return 0; }
   if (interpolation == 3) { orc_resize_area_u8(src, sh, sw, cn, dst, dh, dw, scale_x, scale_y, inv_sx, inv_sy); return 0; }
   if (interpolation == 0) {
     for (int y = 0; y < dh; ++y) {
@@ -987,7 +1061,22 @@ ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* d
  * hue-sector identities in tests/).
  * ------------------------------------------------------------------------------------------ */
 enum { ORC_BGR2RGB = 4, ORC_BGR2GRAY = 6, ORC_RGB2GRAY = 7, ORC_GRAY2BGR = 8, ORC_BGR2YCrCb = 36, ORC_RGB2YCrCb = 37,
-       ORC_YCrCb2BGR = 38, ORC_YCrCb2RGB = 39, ORC_BGR2HSV = 40 };
+       ORC_YCrCb2BGR = 38, ORC_YCrCb2RGB = 39, ORC_BGR2HSV = 40, ORC_RGB2HSV = 41, ORC_HSV2BGR = 54, ORC_HSV2RGB = 55,
+       ORC_BGR2HSV_FULL = 66, ORC_RGB2HSV_FULL = 67, ORC_HSV2BGR_FULL = 70, ORC_HSV2RGB_FULL = 71,
+       ORC_BGR2YUV = 82, ORC_RGB2YUV = 83, ORC_YUV2BGR = 84, ORC_YUV2RGB = 85 };
+
+/* Further codes of the reference's table (convert_color_kernel.cpp:60-93), restated from
+ * imgproc/src/color_hsv.simd.hpp and color_yuv.simd.hpp:
+ *   RGB2HSV (41), BGR/RGB2HSV_FULL (66, 67): RGB2HSV_b with blue index 2 / hue range 256
+ *     (hdiv256[i] = cvRound((256 << 12)/(6.*i)));
+ *   HSV2BGR/RGB (54, 55), _FULL (70, 71): HSV2RGB_b = bytes -> float (h, s/255, v/255) ->
+ *     HSV2RGB_native (h *= 6/hrange; wrapped into [0, 6); sector = floor(h); tab = {v, v(1-s),
+ *     v(1-s h), v(1-s(1-h))}; sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} giving
+ *     (b, g, r)) -> saturate_cast<uchar>(x * 255), float arithmetic throughout;
+ *   BGR/RGB2YUV (82, 83): RGB2YCrCb_i with {R2YI, G2YI, B2YI, R2VI, B2UI} = {4899, 9617, 1868, 14369,
+ *     8061} and the chroma pair stored as (U, V) = (Cb-like, Cr-like);
+ *   YUV2BGR/RGB (84, 85): YCrCb2RGB_i with {V2RI, V2GI, U2GI, U2BI} = {18678, -9519, -6472, 33292}.
+ * PARITY UNPINNED against real OpenCV output like the codes above. */
 
 ORC_API int orc_cvt_out_channels(int code, int in_channels) {
   switch (code) {
@@ -995,9 +1084,30 @@ ORC_API int orc_cvt_out_channels(int code, int in_channels) {
     case ORC_BGR2GRAY: case ORC_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ORC_GRAY2BGR: return in_channels == 1 ? 3 : -1;
     case ORC_BGR2HSV: case ORC_BGR2YCrCb: case ORC_RGB2YCrCb: case ORC_YCrCb2BGR: case ORC_YCrCb2RGB:
+    case ORC_RGB2HSV: case ORC_HSV2BGR: case ORC_HSV2RGB: case ORC_BGR2HSV_FULL: case ORC_RGB2HSV_FULL:
+    case ORC_HSV2BGR_FULL: case ORC_HSV2RGB_FULL: case ORC_BGR2YUV: case ORC_RGB2YUV: case ORC_YUV2BGR: case ORC_YUV2RGB:
       return in_channels == 3 ? 3 : -1;
     default: return -1;
   }
+}
+
+/* HSV2RGB_native (color_hsv.simd.hpp); hscale = 6.f / hrange */
+static void orc_hsv2rgb_native(float h, float s, float v, float hscale, float* b, float* g, float* r) {
+  if (s == 0) { *b = *g = *r = v; return; }
+  static const int sector_data[][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+  float tab[4];
+  h *= hscale;
+  h = fmodf(h, 6.f);
+  int sector = (int)floorf(h);
+  h -= sector;
+  if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+  tab[0] = v;
+  tab[1] = v * (1.f - s);
+  tab[2] = v * (1.f - s * h);
+  tab[3] = v * (1.f - s * (1.f - h));
+  *b = tab[sector_data[sector][0]];
+  *g = tab[sector_data[sector][1]];
+  *r = tab[sector_data[sector][2]];
 }
 
 ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code, int gray_bits, uint8_t* dst) {
@@ -1039,16 +1149,53 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
       dst[3 * i + 1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
       dst[3 * i + (bidx ^ 2)] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
     }
-  } else {  /* BGR2HSV, hrange 180 */
+  } else if (code == ORC_BGR2YUV || code == ORC_RGB2YUV) {
+    const int bidx = code == ORC_BGR2YUV ? 0 : 2, sh = 14, delta = 128 * (1 << 14);
+    const int C0 = bidx == 0 ? 1868 : 4899, C1 = 9617, C2 = bidx == 0 ? 4899 : 1868, C3 = 14369, C4 = 8061;
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* p = src + 3 * i;
+      const int Y = (p[0] * C0 + p[1] * C1 + p[2] * C2 + (1 << (sh - 1))) >> sh;
+      const int V = ((p[bidx ^ 2] - Y) * C3 + delta + (1 << (sh - 1))) >> sh;
+      const int U = ((p[bidx] - Y) * C4 + delta + (1 << (sh - 1))) >> sh;
+      dst[3 * i] = orc_sat_u8_int(Y);
+      dst[3 * i + 1] = orc_sat_u8_int(U);   /* yuvOrder: dst[i + 2 - 1] = Cb */
+      dst[3 * i + 2] = orc_sat_u8_int(V);   /*           dst[i + 1 + 1] = Cr */
+    }
+  } else if (code == ORC_YUV2BGR || code == ORC_YUV2RGB) {
+    const int bidx = code == ORC_YUV2BGR ? 0 : 2, sh = 14, rnd = 1 << (sh - 1);
+    for (size_t i = 0; i < n; ++i) {
+      const int Y = src[3 * i], U = src[3 * i + 1] - 128, V = src[3 * i + 2] - 128;
+      const int b = Y + ((U * 33292 + rnd) >> sh);
+      const int g = Y + ((U * -6472 + V * -9519 + rnd) >> sh);
+      const int r = Y + ((V * 18678 + rnd) >> sh);
+      dst[3 * i + bidx] = orc_sat_u8_int(b);
+      dst[3 * i + 1] = orc_sat_u8_int(g);
+      dst[3 * i + (bidx ^ 2)] = orc_sat_u8_int(r);
+    }
+  } else if (code == ORC_HSV2BGR || code == ORC_HSV2RGB || code == ORC_HSV2BGR_FULL || code == ORC_HSV2RGB_FULL) {
+    const int bidx = (code == ORC_HSV2BGR || code == ORC_HSV2BGR_FULL) ? 0 : 2;
+    const int hrange = (code == ORC_HSV2BGR || code == ORC_HSV2RGB) ? 180 : 255;  /* cvtColor passes 255 for _FULL on 8U */
+    const float hscale = 6.f / hrange;
+    for (size_t i = 0; i < n; ++i) {
+      const float hh = src[3 * i], ss = src[3 * i + 1] * (1.f / 255.f), vv = src[3 * i + 2] * (1.f / 255.f);
+      float b, g, r;
+      orc_hsv2rgb_native(hh, ss, vv, hscale, &b, &g, &r);
+      dst[3 * i + bidx] = orc_sat_u8_float(b * 255.f);
+      dst[3 * i + 1] = orc_sat_u8_float(g * 255.f);
+      dst[3 * i + (bidx ^ 2)] = orc_sat_u8_float(r * 255.f);
+    }
+  } else {  /* BGR2HSV / RGB2HSV, hrange 180 (256 for _FULL) */
     const int hsv_shift = 12;
+    const int bidx = (code == ORC_BGR2HSV || code == ORC_BGR2HSV_FULL) ? 0 : 2;
+    const int hr = (code == ORC_BGR2HSV || code == ORC_RGB2HSV) ? 180 : 256;
     int sdiv[256], hdiv[256];
     sdiv[0] = hdiv[0] = 0;
     for (int i = 1; i < 256; ++i) {
       sdiv[i] = (int)lrint((255 << hsv_shift) / (1. * i));
-      hdiv[i] = (int)lrint((180 << hsv_shift) / (6. * i));
+      hdiv[i] = (int)lrint((hr << hsv_shift) / (6. * i));
     }
     for (size_t i = 0; i < n; ++i) {
-      const int b = src[3 * i], g = src[3 * i + 1], r = src[3 * i + 2];
+      const int b = src[3 * i + bidx], g = src[3 * i + 1], r = src[3 * i + (bidx ^ 2)];
       int v = b, vmin = b;
       if (g > v) v = g;
       if (r > v) v = r;
@@ -1059,7 +1206,7 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
       const int s = (diff * sdiv[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
       int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
       hh = (hh * hdiv[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
-      hh += hh < 0 ? 180 : 0;
+      hh += hh < 0 ? hr : 0;
       dst[3 * i] = (uint8_t)(hh < 0 ? 0 : (hh > 255 ? 255 : hh));
       dst[3 * i + 1] = (uint8_t)s;
       dst[3 * i + 2] = (uint8_t)v;

@@ -13,11 +13,14 @@ LIB_PATH = os.environ.get("ST_HIP_LIB") or os.path.join(_HERE, "lib", "libscanne
 CSRC = os.path.join(_HERE, "csrc")
 
 ST_OK, ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_OOM, ST_ERR_UNSUPPORTED = range(5)
-INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA = 0, 1, 2, 3  # cv::InterpolationFlags values the Resize op implements
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4  # cv::InterpolationFlags values the Resize op implements
 # cv::ColorConversionCodes values the ConvertColor op implements
 COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COLOR_RGB2GRAY": 7,
                "COLOR_GRAY2BGR": 8, "COLOR_GRAY2RGB": 8, "COLOR_BGR2YCrCb": 36, "COLOR_RGB2YCrCb": 37,
-               "COLOR_YCrCb2BGR": 38, "COLOR_YCrCb2RGB": 39, "COLOR_BGR2HSV": 40}
+               "COLOR_YCrCb2BGR": 38, "COLOR_YCrCb2RGB": 39, "COLOR_BGR2HSV": 40, "COLOR_RGB2HSV": 41,
+               "COLOR_HSV2BGR": 54, "COLOR_HSV2RGB": 55, "COLOR_BGR2HSV_FULL": 66, "COLOR_RGB2HSV_FULL": 67,
+               "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
+               "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85}
 K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_COUNT = range(12)
 KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color"]
 

@@ -21,6 +21,8 @@
 // (OpenCV's integer tables, oracle/oracle.c orc_cvt_color_u8).
 #include <cfloat>
 #include <cmath>
+#include <cstring>
+#include <vector>
 
 #include "st_internal.h"
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
 }
 
 // ---- Resize -------------------------------------------------------------------------------------
-enum { RS_NEAREST = 0, RS_LINEAR = 1, RS_AREA2 = 2, RS_COPY = 3, RS_CUBIC = 4, RS_AREA_INT = 5, RS_AREA = 6, RS_LINEAR_AREA = 7 };
+enum { RS_NEAREST = 0, RS_LINEAR = 1, RS_AREA2 = 2, RS_COPY = 3, RS_CUBIC = 4, RS_AREA_INT = 5, RS_AREA = 6, RS_LINEAR_AREA = 7, RS_LANCZOS4 = 8 };
 
 struct ResizeArgsK {
   const uint8_t* const* src;
@@ -150,6 +152,11 @@ struct ResizeArgsK {
   double scale_x, scale_y;  // source / destination size ratios as cv::resize computes them
   double inv_scale_x, inv_scale_y;
   int iscale_x, iscale_y;   // RS_AREA_INT: integer cell size
+  // RS_LANCZOS4: per-axis tables built on the host (cv::interpolateLanczos4 evaluates sin / cos in
+  // double; the host's libm is the one OpenCV and the oracle use): first-tap offsets + 3 and 8
+  // fixed-point weights per destination column / row
+  const int* xofs; const short* ialpha;
+  const int* yofs; const short* ibeta;
 };
 
 // saturate_cast<short>(float): cvRound = round half to even, then saturation
@@ -251,6 +258,32 @@ __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
       const int o = (v + (1 << 21)) >> 22;
       D[c] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
     }
+  } else if (a.mode == RS_LANCZOS4) {
+    // HResizeLanczos4 + VResizeLanczos4 for 8-bit data: 8 x 8 taps from (sx - 3, sy - 3), the edge
+    // pixel replicated outside the image, (v + 2^21) >> 22 saturated
+    const int sx = a.xofs[dx], sy = a.yofs[dy];
+    int ax[8], by[8], xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ax[k] = a.ialpha[8 * dx + k];
+      by[k] = a.ibeta[8 * dy + k];
+      const int xx = sx - 3 + k;
+      xs[k] = (xx < 0 ? 0 : (xx > a.sw - 1 ? a.sw - 1 : xx)) * cn;
+    }
+    for (int c = 0; c < cn; ++c) {
+      int v = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int yy = sy - 3 + k;
+        const uint8_t* S = src + (size_t)(yy < 0 ? 0 : (yy > a.sh - 1 ? a.sh - 1 : yy)) * srow + c;
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r += S[xs[j]] * ax[j];
+        v += r * by[k];
+      }
+      const int o = (v + (1 << 21)) >> 22;
+      D[c] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
   } else if (a.mode == RS_AREA_INT) {
     const float scale = 1.f / (a.iscale_x * a.iscale_y);
     for (int c = 0; c < cn; ++c) {
@@ -330,13 +363,18 @@ struct CvtArgsK {
   int cb, cg, cr, rnd, shift, bi;  // gray weights (bi = byte holding blue)
 };
 
+__device__ __forceinline__ bool cvt_is_to_hsv(int code) {
+  return code == ST_COLOR_BGR2HSV || code == ST_COLOR_RGB2HSV || code == ST_COLOR_BGR2HSV_FULL || code == ST_COLOR_RGB2HSV_FULL;
+}
+
 __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
   __shared__ int sdiv[256], hdiv[256];
   const int t = threadIdx.x;
-  if (a.code == ST_COLOR_BGR2HSV) {
-    // RGB2HSV_b tables: saturate_cast<int>((255 << 12)/(1.*i)), saturate_cast<int>((180 << 12)/(6.*i))
+  if (cvt_is_to_hsv(a.code)) {
+    // RGB2HSV_b tables: saturate_cast<int>((255 << 12)/(1.*i)), saturate_cast<int>((hrange << 12)/(6.*i))
+    const int hr = (a.code == ST_COLOR_BGR2HSV || a.code == ST_COLOR_RGB2HSV) ? 180 : 256;
     sdiv[t] = t ? (int)rint((255 << 12) / (1. * t)) : 0;
-    hdiv[t] = t ? (int)rint((180 << 12) / (6. * t)) : 0;
+    hdiv[t] = t ? (int)rint((hr << 12) / (6. * t)) : 0;
     __syncthreads();
   }
   const uint8_t* __restrict__ src = a.src[blockIdx.y];
@@ -373,15 +411,64 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
       dst[3 * i + bidx] = (uint8_t)min(max(b, 0), 255);
       dst[3 * i + 1] = (uint8_t)min(max(g, 0), 255);
       dst[3 * i + (bidx ^ 2)] = (uint8_t)min(max(r, 0), 255);
-    } else {  // BGR2HSV, hue range 180
-      const int b = src[3 * i], g = src[3 * i + 1], r = src[3 * i + 2];
+    } else if (a.code == ST_COLOR_BGR2YUV || a.code == ST_COLOR_RGB2YUV) {
+      // RGB2YCrCb_i<uchar> with {R2YI, G2YI, B2YI, R2VI, B2UI} = {4899, 9617, 1868, 14369, 8061}; stored (Y, U, V)
+      const int bidx = a.code == ST_COLOR_BGR2YUV ? 0 : 2;
+      const int p0 = src[3 * i], p1 = src[3 * i + 1], p2 = src[3 * i + 2];
+      const int C0 = bidx == 0 ? 1868 : 4899, C2 = bidx == 0 ? 4899 : 1868;
+      const int Y = (p0 * C0 + p1 * 9617 + p2 * C2 + (1 << 13)) >> 14;
+      const int rr = bidx == 0 ? p2 : p0, bb = bidx == 0 ? p0 : p2;
+      const int V = ((rr - Y) * 14369 + (128 << 14) + (1 << 13)) >> 14;
+      const int U = ((bb - Y) * 8061 + (128 << 14) + (1 << 13)) >> 14;
+      dst[3 * i] = (uint8_t)min(max(Y, 0), 255);
+      dst[3 * i + 1] = (uint8_t)min(max(U, 0), 255);
+      dst[3 * i + 2] = (uint8_t)min(max(V, 0), 255);
+    } else if (a.code == ST_COLOR_YUV2BGR || a.code == ST_COLOR_YUV2RGB) {
+      // YCrCb2RGB_i<uchar> with {V2RI, V2GI, U2GI, U2BI} = {18678, -9519, -6472, 33292}
+      const int bidx = a.code == ST_COLOR_YUV2BGR ? 0 : 2;
+      const int Y = src[3 * i], U = src[3 * i + 1] - 128, V = src[3 * i + 2] - 128;
+      const int b = Y + ((U * 33292 + (1 << 13)) >> 14);
+      const int g = Y + ((U * -6472 + V * -9519 + (1 << 13)) >> 14);
+      const int r = Y + ((V * 18678 + (1 << 13)) >> 14);
+      dst[3 * i + bidx] = (uint8_t)min(max(b, 0), 255);
+      dst[3 * i + 1] = (uint8_t)min(max(g, 0), 255);
+      dst[3 * i + (bidx ^ 2)] = (uint8_t)min(max(r, 0), 255);
+    } else if (a.code == ST_COLOR_HSV2BGR || a.code == ST_COLOR_HSV2RGB || a.code == ST_COLOR_HSV2BGR_FULL ||
+               a.code == ST_COLOR_HSV2RGB_FULL) {
+      // HSV2RGB_b: bytes -> (h, s/255, v/255) -> HSV2RGB_native in float -> saturate_cast<uchar>(x * 255)
+      const int bidx = (a.code == ST_COLOR_HSV2BGR || a.code == ST_COLOR_HSV2BGR_FULL) ? 0 : 2;
+      const float hscale = (a.code == ST_COLOR_HSV2BGR || a.code == ST_COLOR_HSV2RGB) ? 6.f / 180 : 6.f / 255;
+      float hh = src[3 * i];
+      const float ss = src[3 * i + 1] * (1.f / 255.f), vv = src[3 * i + 2] * (1.f / 255.f);
+      float b, g, r;
+      if (ss == 0) {
+        b = g = r = vv;
+      } else {
+        hh *= hscale;
+        hh = fmodf(hh, 6.f);
+        int sector = (int)floorf(hh);
+        hh -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+        const float t0 = vv, t1 = vv * (1.f - ss), t2 = vv * (1.f - ss * hh), t3 = vv * (1.f - ss * (1.f - hh));
+        // sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> (b, g, r)
+        b = sector == 0 || sector == 1 ? t1 : (sector == 2 ? t3 : (sector == 5 ? t2 : t0));
+        g = sector == 0 ? t3 : (sector == 1 || sector == 2 ? t0 : (sector == 3 ? t2 : t1));
+        r = sector == 0 || sector == 5 ? t0 : (sector == 1 ? t2 : (sector == 4 ? t3 : t1));
+      }
+      dst[3 * i + bidx] = rs_sat_float(b * 255.f);
+      dst[3 * i + 1] = rs_sat_float(g * 255.f);
+      dst[3 * i + (bidx ^ 2)] = rs_sat_float(r * 255.f);
+    } else {  // BGR2HSV / RGB2HSV, hue range 180 (256 for _FULL)
+      const int bi = (a.code == ST_COLOR_BGR2HSV || a.code == ST_COLOR_BGR2HSV_FULL) ? 0 : 2;
+      const int hr = (a.code == ST_COLOR_BGR2HSV || a.code == ST_COLOR_RGB2HSV) ? 180 : 256;
+      const int b = src[3 * i + bi], g = src[3 * i + 1], r = src[3 * i + (bi ^ 2)];
       const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
       const int diff = v - vmin;
       const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
       const int sv = (diff * sdiv[v] + (1 << 11)) >> 12;
       int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
       hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
-      hh += hh < 0 ? 180 : 0;
+      hh += hh < 0 ? hr : 0;
       dst[3 * i] = (uint8_t)(hh < 0 ? 0 : (hh > 255 ? 255 : hh));
       dst[3 * i + 1] = (uint8_t)sv;
       dst[3 * i + 2] = (uint8_t)v;
@@ -440,26 +527,66 @@ ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_d
   return ST_OK;
 }
 
+namespace {
+// cv::interpolateLanczos4 (imgproc/src/resize.cpp)
+void lanczos4_coeffs(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) coeffs[i] = 0;
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+  for (int i = 0; i < 8; i++) {
+    const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+void lanczos4_axis(int dsize, double scale, int* ofs, short* coef) {
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    const int sidx = (int)floorf(f);
+    f -= sidx;
+    float c[8];
+    lanczos4_coeffs(f, c);
+    ofs[d] = sidx;
+    for (int k = 0; k < 8; ++k) {
+      const long r = lrintf(c[k] * 2048);  // saturate_cast<short>: round half to even
+      coef[8 * d + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+    }
+  }
+}
+}  // namespace
+
 ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                                  int out_h, int out_w, int interpolation, uint8_t* const* out_dev) {
   ST_TRY(st_enter(ctx));
   if (n < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0 || channels < 1 || channels > 4 ||
       (long long)h * w > 200000000LL || (long long)out_h * out_w > 200000000LL)
     return st_set_error(ctx, ST_ERR_INVALID, "resize: bad arguments (n=%d %dx%dx%d -> %dx%d)", n, h, w, channels, out_h, out_w);
-  if (interpolation < ST_INTER_NEAREST || interpolation > ST_INTER_AREA)
-    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: interpolation %d (INTER_NEAREST, INTER_LINEAR, INTER_CUBIC and INTER_AREA are implemented)", interpolation);
+  if (interpolation < ST_INTER_NEAREST || interpolation > ST_INTER_LANCZOS4)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: interpolation %d (INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA and INTER_LANCZOS4 are implemented)", interpolation);
   if (out_h > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "resize: output taller than 65535 rows");
   if (n == 0) return ST_OK;
   if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "resize: null argument");
   for (int i = 0; i < n; ++i)
     if (!frames_dev[i] || !out_dev[i] || frames_dev[i] == out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "resize: row %d is null or aliased", i);
   const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
-  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const bool lanczos = interpolation == ST_INTER_LANCZOS4 && !(h == out_h && w == out_w);
+  const size_t lz = lanczos ? st_align_up(sizeof(int) * (size_t)out_w) + st_align_up(sizeof(short) * 8 * (size_t)out_w) +
+                              st_align_up(sizeof(int) * (size_t)out_h) + st_align_up(sizeof(short) * 8 * (size_t)out_h) : 0;
+  ST_TRY(st_ws_reserve(ctx, 2 * tb + lz));
   const uint8_t** d_src = (const uint8_t**)st_ws_alloc(ctx, tb);
   uint8_t** d_dst = (uint8_t**)st_ws_alloc(ctx, tb);
   ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   ResizeArgsK a;
+  memset(&a, 0, sizeof(a));
   a.sh = h; a.sw = w; a.dh = out_h; a.dw = out_w; a.cn = channels;
   const double inv_sx = (double)out_w / w, inv_sy = (double)out_h / h;
   a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
@@ -469,10 +596,29 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
   if (h == out_h && w == out_w) a.mode = RS_COPY;
   else if (interpolation == ST_INTER_NEAREST) a.mode = RS_NEAREST;
   else if (interpolation == ST_INTER_CUBIC) a.mode = RS_CUBIC;
+  else if (interpolation == ST_INTER_LANCZOS4) a.mode = RS_LANCZOS4;
   else if ((interpolation == ST_INTER_LINEAR || interpolation == ST_INTER_AREA) && area_fast && a.iscale_x == 2 && a.iscale_y == 2) a.mode = RS_AREA2;
   else if (interpolation == ST_INTER_LINEAR) a.mode = RS_LINEAR;
   else if (a.scale_x >= 1 && a.scale_y >= 1) a.mode = area_fast ? RS_AREA_INT : RS_AREA;
   else a.mode = RS_LINEAR_AREA;
+  std::vector<int> hx, hy;
+  std::vector<short> ha, hb;
+  if (a.mode == RS_LANCZOS4) {
+    hx.resize(out_w); ha.resize(8 * (size_t)out_w); hy.resize(out_h); hb.resize(8 * (size_t)out_h);
+    lanczos4_axis(out_w, a.scale_x, hx.data(), ha.data());
+    lanczos4_axis(out_h, a.scale_y, hy.data(), hb.data());
+    int* dx_ = (int*)st_ws_alloc(ctx, sizeof(int) * (size_t)out_w);
+    short* da_ = (short*)st_ws_alloc(ctx, sizeof(short) * 8 * (size_t)out_w);
+    int* dy_ = (int*)st_ws_alloc(ctx, sizeof(int) * (size_t)out_h);
+    short* db_ = (short*)st_ws_alloc(ctx, sizeof(short) * 8 * (size_t)out_h);
+    if (!dx_ || !da_ || !dy_ || !db_) return st_set_error(ctx, ST_ERR_OOM, "resize: scratch plan exhausted");
+    // pageable sources: hipMemcpyAsync returns once the runtime has staged them, so the vectors may go
+    ST_HIP(ctx, hipMemcpyAsync(dx_, hx.data(), sizeof(int) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
+    ST_HIP(ctx, hipMemcpyAsync(da_, ha.data(), sizeof(short) * ha.size(), hipMemcpyHostToDevice, ctx->stream));
+    ST_HIP(ctx, hipMemcpyAsync(dy_, hy.data(), sizeof(int) * hy.size(), hipMemcpyHostToDevice, ctx->stream));
+    ST_HIP(ctx, hipMemcpyAsync(db_, hb.data(), sizeof(short) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
+    a.xofs = dx_; a.ialpha = da_; a.yofs = dy_; a.ibeta = db_;
+  }
   for (int f0 = 0; f0 < n; f0 += 65535) {
     const int nf = n - f0 < 65535 ? n - f0 : 65535;
     a.src = d_src + f0; a.dst = d_dst + f0;
@@ -486,7 +632,9 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
 ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
   switch (code) {
     case ST_COLOR_BGR2RGB: case ST_COLOR_BGR2HSV: case ST_COLOR_BGR2YCrCb: case ST_COLOR_RGB2YCrCb:
-    case ST_COLOR_YCrCb2BGR: case ST_COLOR_YCrCb2RGB:
+    case ST_COLOR_YCrCb2BGR: case ST_COLOR_YCrCb2RGB: case ST_COLOR_RGB2HSV: case ST_COLOR_HSV2BGR: case ST_COLOR_HSV2RGB:
+    case ST_COLOR_BGR2HSV_FULL: case ST_COLOR_RGB2HSV_FULL: case ST_COLOR_HSV2BGR_FULL: case ST_COLOR_HSV2RGB_FULL:
+    case ST_COLOR_BGR2YUV: case ST_COLOR_RGB2YUV: case ST_COLOR_YUV2BGR: case ST_COLOR_YUV2RGB:
       return in_channels == 3 ? 3 : -1;
     case ST_COLOR_BGR2GRAY: case ST_COLOR_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ST_COLOR_GRAY2BGR: return in_channels == 1 ? 3 : -1;

@@ -23,11 +23,10 @@ def compute_histograms(sc, videos, device=DeviceType.GPU, batch=64):
 
 def compute_hsv_histograms(sc, videos, device=DeviceType.GPU, batch=64):
     """old/histograms.py:32-37: RGB -> HSV conversion, then Histogram.  The reference's
-    ConvertToHSVCPP op is cv::cvtColor(COLOR_RGB2HSV) (old/cpp_ops/imgproc.cpp:41); with the
-    ConvertColor op of this library that is COLOR_RGB2BGR followed by COLOR_BGR2HSV."""
+    ConvertToHSVCPP op is cv::cvtColor(COLOR_RGB2HSV) (old/cpp_ops/imgproc.cpp:41): one pass of the
+    ConvertColor op of this library with the same code."""
     def build(f):
-        bgr = sc.ops.ConvertColor(frame=f, conversion='COLOR_RGB2BGR', device=device, batch=batch)
-        hsv = sc.ops.ConvertColor(frame=bgr, conversion='COLOR_BGR2HSV', device=device, batch=batch)
+        hsv = sc.ops.ConvertColor(frame=f, conversion='COLOR_RGB2HSV', device=device, batch=batch)
         return sc.ops.Histogram(frame=hsv, device=device, batch=batch)
     return [_run(sc, v, 'hsv_hist', build) for v in videos]
 

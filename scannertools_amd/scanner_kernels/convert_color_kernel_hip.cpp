@@ -7,7 +7,8 @@
 // scannertools_imgproc.proto:29-31: the name of a cv::ColorConversionCodes constant).  The per-frame
 // cv::cvtColor / cvc::cvtColor calls are replaced by ONE st_cvt_color_u8_batch() call per execute().
 // Implemented names: COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR,
-// COLOR_GRAY2RGB, COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB, COLOR_BGR2HSV; an unknown name invalidates the stream as in the reference
+// COLOR_GRAY2RGB, COLOR_BGR/RGB2YCrCb, COLOR_YCrCb2BGR/RGB, COLOR_BGR/RGB2YUV, COLOR_YUV2BGR/RGB,
+// COLOR_BGR/RGB2HSV, COLOR_HSV2BGR/RGB and the four _FULL hue-range variants; an unknown name invalidates the stream as in the reference
 // (:231-236), a name of the reference's table that is not implemented here is reported the same way
 // instead of being run on the CPU.  SCANNERTOOLS_GRAY_BITS (15 default, 14) selects the luma table
 // width of the OpenCV build being replaced.
@@ -30,7 +31,12 @@ const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
     {u8"COLOR_GRAY2BGR", ST_COLOR_GRAY2BGR}, {u8"COLOR_GRAY2RGB", ST_COLOR_GRAY2RGB},
     {u8"COLOR_BGR2YCrCb", ST_COLOR_BGR2YCrCb}, {u8"COLOR_RGB2YCrCb", ST_COLOR_RGB2YCrCb},
     {u8"COLOR_YCrCb2BGR", ST_COLOR_YCrCb2BGR}, {u8"COLOR_YCrCb2RGB", ST_COLOR_YCrCb2RGB},
-    {u8"COLOR_BGR2HSV", ST_COLOR_BGR2HSV},
+    {u8"COLOR_BGR2HSV", ST_COLOR_BGR2HSV},   {u8"COLOR_RGB2HSV", ST_COLOR_RGB2HSV},
+    {u8"COLOR_HSV2BGR", ST_COLOR_HSV2BGR},   {u8"COLOR_HSV2RGB", ST_COLOR_HSV2RGB},
+    {u8"COLOR_BGR2HSV_FULL", ST_COLOR_BGR2HSV_FULL}, {u8"COLOR_RGB2HSV_FULL", ST_COLOR_RGB2HSV_FULL},
+    {u8"COLOR_HSV2BGR_FULL", ST_COLOR_HSV2BGR_FULL}, {u8"COLOR_HSV2RGB_FULL", ST_COLOR_HSV2RGB_FULL},
+    {u8"COLOR_BGR2YUV", ST_COLOR_BGR2YUV},   {u8"COLOR_RGB2YUV", ST_COLOR_RGB2YUV},
+    {u8"COLOR_YUV2BGR", ST_COLOR_YUV2BGR},   {u8"COLOR_YUV2RGB", ST_COLOR_YUV2RGB},
 };
 }
 

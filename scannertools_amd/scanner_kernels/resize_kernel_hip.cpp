@@ -7,8 +7,9 @@
 // min = 3, preserve_aspect = 4, interpolation = 5}, scannertools_imgproc.proto:33-39) and the same
 // target-size rules (resize_kernel.cpp:44-62).  The per-frame cv::resize / cvc::resize calls are
 // replaced by ONE st_resize_u8_batch() call per execute().  Implemented interpolations:
-// INTER_LINEAR (the reference's default, :31), INTER_NEAREST, INTER_CUBIC and INTER_AREA; the other
-// names of the reference's table (:10-19: INTER_LANCZOS4 and the warp flags) are rejected when the
+// INTER_LINEAR (the reference's default, :31), INTER_NEAREST, INTER_CUBIC, INTER_AREA and
+// INTER_LANCZOS4; the other names of the reference's table (:10-19: INTER_MAX and the warp flags, which
+// are not interpolation modes) are rejected when the
 // stream starts instead of being run on the CPU.
 #include <map>
 
@@ -74,9 +75,9 @@ class ResizeKernelHIPImpl : public BatchedKernel {
     LOG_IF(FATAL, !parse_resize_args(args, &args_)) << "Resize: could not parse ResizeArgs";
     interp_type_ = 1;  // cv::INTER_LINEAR (resize_kernel.cpp:31)
     if (INTERP_TYPES.count(args_.interpolation) > 0) interp_type_ = INTERP_TYPES.at(args_.interpolation);
-    LOG_IF(FATAL, interp_type_ < ST_INTER_NEAREST || interp_type_ > ST_INTER_AREA)
+    LOG_IF(FATAL, interp_type_ < ST_INTER_NEAREST || interp_type_ > ST_INTER_LANCZOS4)
         << "Resize: interpolation " << args_.interpolation << " is not implemented on this device "
-        << "(INTER_NEAREST, INTER_LINEAR, INTER_CUBIC and INTER_AREA are)";
+        << "(INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA and INTER_LANCZOS4 are)";
   }
 
   void execute(const BatchedElements& input_columns, BatchedElements& output_columns) override {

@@ -30,14 +30,17 @@ def test_histogram_and_color_against_opencv():
     bits = _gray_bits()
     np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_BGR2GRAY, bits)[..., 0], cv2.cvtColor(f, cv2.COLOR_BGR2GRAY))
     np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_RGB2GRAY, bits)[..., 0], cv2.cvtColor(f, cv2.COLOR_RGB2GRAY))
-    for name in ("COLOR_BGR2RGB", "COLOR_BGR2HSV", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB"):
+    for name in ("COLOR_BGR2RGB", "COLOR_BGR2HSV", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB",
+                 "COLOR_RGB2HSV", "COLOR_HSV2BGR", "COLOR_HSV2RGB", "COLOR_BGR2HSV_FULL", "COLOR_RGB2HSV_FULL",
+                 "COLOR_HSV2BGR_FULL", "COLOR_HSV2RGB_FULL", "COLOR_BGR2YUV", "COLOR_RGB2YUV", "COLOR_YUV2BGR", "COLOR_YUV2RGB"):
         np.testing.assert_array_equal(oracle.cvt_color(f, getattr(oracle, name)), cv2.cvtColor(f, getattr(cv2, name)), err_msg=name)
 
 
 def test_resize_against_opencv():
     f = random_frames(1, 1, 97, 131)[0]
     modes = ((oracle.INTER_NEAREST, cv2.INTER_NEAREST), (oracle.INTER_LINEAR, cv2.INTER_LINEAR),
-             (oracle.INTER_CUBIC, cv2.INTER_CUBIC), (oracle.INTER_AREA, cv2.INTER_AREA))
+             (oracle.INTER_CUBIC, cv2.INTER_CUBIC), (oracle.INTER_AREA, cv2.INTER_AREA),
+             (oracle.INTER_LANCZOS4, cv2.INTER_LANCZOS4))
     for (dw, dh) in ((426 // 4, 60), (65, 48), (262, 194), (131, 97), (43, 97), (200, 30)):
         for om, cm in modes:
             np.testing.assert_array_equal(oracle.resize_u8(f, dw, dh, om), cv2.resize(f, (dw, dh), interpolation=cm),

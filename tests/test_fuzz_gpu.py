@@ -33,7 +33,7 @@ def test_fuzz_integer_ops(hip_ctx, seed):
         got = hip_ctx.box_blur(fr, k).cpu().numpy()
         for i in range(n):
             np.testing.assert_array_equal(got[i], oracle.box_blur(frames[i], k), err_msg="blur %dx%d k %d" % (h, w, k))
-        dh, dw, interp = int(rng.integers(1, 120)), int(rng.integers(1, 150)), int(rng.integers(0, 4))
+        dh, dw, interp = int(rng.integers(1, 120)), int(rng.integers(1, 150)), int(rng.integers(0, 5))
         got = hip_ctx.resize(fr, dw, dh, interp).cpu().numpy()
         for i in range(n):
             np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh, interp),

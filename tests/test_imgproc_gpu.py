@@ -97,12 +97,13 @@ def test_resize_linear_matches_oracle(hip_ctx, sh, sw, dh, dw):
 @pytest.mark.parametrize("sh,sw,dh,dw", [(480, 640, 240, 426), (48, 60, 16, 20), (48, 60, 24, 30), (48, 60, 13, 21),
                                          (37, 53, 80, 91), (48, 60, 20, 90), (48, 60, 100, 13), (100, 100, 1, 1),
                                          (1080, 1920, 360, 640), (9, 7, 9, 7)])
-@pytest.mark.parametrize("interp", ["cubic", "area"])
+@pytest.mark.parametrize("interp", ["cubic", "area", "lanczos4"])
 def test_resize_cubic_and_area_match_oracle(hip_ctx, sh, sw, dh, dw, interp):
-    """INTER_CUBIC; INTER_AREA with integer cells (3x, 2x), fractional cells, enlargement on one or
-    both axes, identity."""
-    from scannertools_amd._native import INTER_AREA, INTER_CUBIC
-    code, ocode = (INTER_CUBIC, oracle.INTER_CUBIC) if interp == "cubic" else (INTER_AREA, oracle.INTER_AREA)
+    """INTER_CUBIC; INTER_LANCZOS4; INTER_AREA with integer cells (3x, 2x), fractional cells,
+    enlargement on one or both axes, identity."""
+    from scannertools_amd._native import INTER_AREA, INTER_CUBIC, INTER_LANCZOS4
+    code, ocode = {"cubic": (INTER_CUBIC, oracle.INTER_CUBIC), "area": (INTER_AREA, oracle.INTER_AREA),
+                   "lanczos4": (INTER_LANCZOS4, oracle.INTER_LANCZOS4)}[interp]
     frames = random_frames(sh + sw + dw, 2, sh, sw)
     got = hip_ctx.resize(torch.from_numpy(frames).cuda(), dw, dh, code).cpu().numpy()
     for i in range(2):
@@ -122,7 +123,10 @@ def test_resize_channels_nearest_and_identities(hip_ctx, cn):
     const = np.full((1, 33, 71, cn), 201, np.uint8)
     assert (hip_ctx.resize(torch.from_numpy(const).cuda(), 19, 100).cpu().numpy() == 201).all()
     with pytest.raises(StError):
-        hip_ctx.resize(torch.from_numpy(f).cuda(), 10, 10, interpolation=4)      # INTER_LANCZOS4: not implemented
+        hip_ctx.resize(torch.from_numpy(f).cuda(), 10, 10, interpolation=7)      # INTER_MAX: a mask, not a mode
+    from scannertools_amd._native import INTER_LANCZOS4
+    got = hip_ctx.resize(torch.from_numpy(f).cuda(), 77, 31, INTER_LANCZOS4).cpu().numpy()
+    np.testing.assert_array_equal(got[1], oracle.resize_u8(f[1], 77, 31, oracle.INTER_LANCZOS4))
 
 
 @pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
@@ -174,7 +178,11 @@ def test_resize_op_target_size_rules():
 # ---- ConvertColor -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,code", [("COLOR_BGR2RGB", 4), ("COLOR_RGB2BGR", 4), ("COLOR_BGR2GRAY", 6),
                                        ("COLOR_RGB2GRAY", 7), ("COLOR_BGR2HSV", 40), ("COLOR_BGR2YCrCb", 36),
-                                       ("COLOR_RGB2YCrCb", 37), ("COLOR_YCrCb2BGR", 38), ("COLOR_YCrCb2RGB", 39)])
+                                       ("COLOR_RGB2YCrCb", 37), ("COLOR_YCrCb2BGR", 38), ("COLOR_YCrCb2RGB", 39),
+                                       ("COLOR_RGB2HSV", 41), ("COLOR_HSV2BGR", 54), ("COLOR_HSV2RGB", 55),
+                                       ("COLOR_BGR2HSV_FULL", 66), ("COLOR_RGB2HSV_FULL", 67), ("COLOR_HSV2BGR_FULL", 70),
+                                       ("COLOR_HSV2RGB_FULL", 71), ("COLOR_BGR2YUV", 82), ("COLOR_RGB2YUV", 83),
+                                       ("COLOR_YUV2BGR", 84), ("COLOR_YUV2RGB", 85)])
 @pytest.mark.parametrize("h,w", [(1, 1), (37, 53), (480, 640)])
 def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
     frames = random_frames(h + w + code, 2, h, w)
@@ -200,6 +208,13 @@ def test_cvt_color_exhaustive_hsv_and_known_answers(hip_ctx):
     g = np.random.default_rng(0).integers(0, 256, (1, 9, 11, 1), dtype=np.uint8)
     rgb = hip_ctx.cvt_color(torch.from_numpy(g).cuda(), "COLOR_GRAY2RGB").cpu().numpy()
     assert rgb.shape == (1, 9, 11, 3) and (rgb == g).all()
+    # the whole 8-bit cube (stride 3 per component + the top value) through the codes whose
+    # arithmetic is not a plain integer table: HSV -> RGB runs in float on both sides
+    v = np.unique(np.concatenate([np.arange(0, 256, 3), [254, 255]])).astype(np.uint8)
+    cube = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, len(v), len(v) * len(v), 3))
+    for name in ("COLOR_HSV2BGR", "COLOR_HSV2RGB_FULL", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2YUV", "COLOR_YUV2BGR"):
+        got = hip_ctx.cvt_color(torch.from_numpy(cube).cuda(), name).cpu().numpy()
+        np.testing.assert_array_equal(got[0], oracle.cvt_color(cube[0], getattr(oracle, name)), err_msg=name)
     with pytest.raises(ValueError):
         hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2XYZ")
     with pytest.raises(ValueError):
@@ -215,13 +230,13 @@ def test_hsv_histogram_pipeline(device):
     frames = random_frames(9, 5, 60, 80)
     sc.ingest_frames('v', frames)
     frame = sc.io.Input([NamedVideoStream(sc, 'v')])
-    hsv = sc.ops.ConvertColor(frame=frame, conversion='COLOR_BGR2HSV', device=device, batch=3)
+    hsv = sc.ops.ConvertColor(frame=frame, conversion='COLOR_RGB2HSV', device=device, batch=3)   # old/cpp_ops/imgproc.cpp:41
     hist = sc.ops.Histogram(frame=hsv, device=device, batch=2)
     gray = sc.ops.ConvertColor(frame=frame, conversion='COLOR_RGB2GRAY', device=device)
     o_hist, o_gray = NamedStream(sc, 'hh'), NamedStream(sc, 'gg')
     sc.run([sc.io.Output(hist, [o_hist]), sc.io.Output(gray, [o_gray])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
     for i, (hh, gg) in enumerate(zip(o_hist.load(), o_gray.load())):
-        np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(oracle.cvt_color(frames[i], oracle.COLOR_BGR2HSV), 16))
+        np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(oracle.cvt_color(frames[i], oracle.COLOR_RGB2HSV), 16))
         assert gg.shape == (60, 80, 1)
         np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))
 

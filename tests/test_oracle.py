@@ -221,8 +221,13 @@ def test_resize_oracle_identities():
     cub = oracle.resize_u8(smooth, 120, 96, oracle.INTER_CUBIC).astype(int)
     lin = oracle.resize_u8(smooth, 120, 96).astype(int)
     assert np.abs(cub - lin)[:, 4:-4].max() <= 1                         # cubic reproduces a ramp
+    # INTER_LANCZOS4: constants preserved, a ramp reproduced away from the edges, weights of an axis sum to 2048 +- rounding
+    for (w, h) in ((32, 24), (21, 13), (100, 77), (90, 20)):
+        assert (oracle.resize_u8(const, w, h, oracle.INTER_LANCZOS4) == 137).all()
+    lz = oracle.resize_u8(smooth, 120, 96, oracle.INTER_LANCZOS4).astype(int)
+    assert np.abs(lz - lin)[:, 8:-8].max() <= 1
     with pytest.raises(ValueError):
-        oracle.resize_u8(f, 10, 10, 4)
+        oracle.resize_u8(f, 10, 10, 7)
 
 
 def test_cvt_color_oracle_known_answers():
@@ -266,6 +271,48 @@ def test_ycrcb_oracle_known_answers():
     rt = oracle.cvt_color(oracle.cvt_color(f, oracle.COLOR_RGB2YCrCb), oracle.COLOR_YCrCb2RGB)
     interior = (got[..., 1] > 0) & (got[..., 1] < 255) & (got[..., 2] > 0) & (got[..., 2] < 255)
     assert np.abs(rt.astype(int) - f)[interior].max() <= 2
+
+
+def test_hsv_inverse_and_yuv_oracle_known_answers():
+    """HSV -> RGB (float path): primaries, the colorsys definition within rounding, forward/backward
+    round trip within the hue quantisation; RGB2HSV is BGR2HSV on swapped bytes; the _FULL variants
+    use hue ranges 256 / 255; 8-bit YUV: the float definition within rounding and a round trip."""
+    import colorsys
+    hsv = np.array([[[120, 255, 255], [60, 255, 255], [0, 255, 255], [0, 0, 255], [0, 0, 0], [90, 128, 200]]], np.uint8)
+    bgr = oracle.cvt_color(hsv, oracle.COLOR_HSV2BGR)[0]
+    assert bgr[:5].tolist() == [[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]
+    np.testing.assert_array_equal(oracle.cvt_color(hsv, oracle.COLOR_HSV2RGB), oracle.cvt_color(hsv, oracle.COLOR_HSV2BGR)[..., ::-1])
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    f[..., 0] %= 180
+    rgb = oracle.cvt_color(f, oracle.COLOR_HSV2RGB).astype(float)
+    for (h, s, v), px in zip(f.reshape(-1, 3)[:300], rgb.reshape(-1, 3)[:300]):
+        ref = np.array(colorsys.hsv_to_rgb(h / 180., s / 255., v / 255.)) * 255
+        assert np.abs(px - ref).max() <= 0.51, (h, s, v, px, ref)
+    g = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(oracle.cvt_color(g, oracle.COLOR_RGB2HSV), oracle.cvt_color(g[..., ::-1].copy(), oracle.COLOR_BGR2HSV))
+    back = oracle.cvt_color(oracle.cvt_color(g, oracle.COLOR_BGR2HSV), oracle.COLOR_HSV2BGR).astype(int)
+    assert np.abs(back - g).max() <= 6                      # hue is quantised to 2 degrees
+    full = oracle.cvt_color(g, oracle.COLOR_BGR2HSV_FULL).astype(int)
+    base = oracle.cvt_color(g, oracle.COLOR_BGR2HSV).astype(int)
+    np.testing.assert_array_equal(full[..., 1:], base[..., 1:])
+    dh = np.abs(full[..., 0] - base[..., 0] * 256 / 180)
+    assert np.minimum(dh, 256 - dh).max() <= 1.5           # the hue circle wraps
+    backf = oracle.cvt_color(oracle.cvt_color(g, oracle.COLOR_RGB2HSV_FULL), oracle.COLOR_HSV2RGB_FULL).astype(int)
+    assert np.abs(backf - g).max() <= 10                   # forward range 256, backward 255 (as in cvtColor) + quantisation
+    # YUV
+    px = np.array([[[255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    assert oracle.cvt_color(px, oracle.COLOR_BGR2YUV)[0].tolist() == [[255, 128, 128], [0, 128, 128], [128, 128, 128]]
+    yuv = oracle.cvt_color(g, oracle.COLOR_RGB2YUV).astype(float)
+    r, gg, b = [g[..., i].astype(float) for i in range(3)]
+    Y = 0.299 * r + 0.587 * gg + 0.114 * b
+    assert np.abs(yuv[..., 0] - Y).max() <= 0.51
+    assert np.abs(yuv[..., 1] - np.clip((b - Y) * 0.492 + 128, 0, 255)).max() <= 1.01
+    assert np.abs(yuv[..., 2] - np.clip((r - Y) * 0.877 + 128, 0, 255)).max() <= 1.01
+    np.testing.assert_array_equal(oracle.cvt_color(g, oracle.COLOR_BGR2YUV), oracle.cvt_color(g[..., ::-1].copy(), oracle.COLOR_RGB2YUV))
+    rt = oracle.cvt_color(oracle.cvt_color(g, oracle.COLOR_RGB2YUV), oracle.COLOR_YUV2RGB).astype(int)
+    ok = (yuv[..., 1] > 0) & (yuv[..., 1] < 255) & (yuv[..., 2] > 0) & (yuv[..., 2] < 255)
+    assert np.abs(rt - g)[ok].max() <= 3
 
 
 def test_resize_oracle_against_torch_conventions():
