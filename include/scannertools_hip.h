@@ -81,7 +81,9 @@ enum st_kernel_id {
   ST_K_BLUR_OP = 8,     /* the Blur op's box filter (not the Farneback blur, which is ST_K_BLUR_UPDATE) */
   ST_K_RESIZE = 9,
   ST_K_CVT_COLOR = 10,
-  ST_K_COUNT = 11
+  ST_K_CPM2_INPUT = 11,
+  ST_K_CPM2_LIMBS = 12,
+  ST_K_COUNT = 13
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -234,6 +236,35 @@ enum st_color_code {
 int st_cvt_color_out_channels(int code, int in_channels);
 int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                           int code, int gray_bits, uint8_t* const* out_dev);
+
+/* ---- Pose path (scannertools_caffe) ------------------------------------
+ * Geometry of the CPM2 network input for a frame of (h, w) at `scale`, as CPM2InputKernel::new_frame_info
+ * and CPM2OutputKernel::new_frame_info derive it (scannertools_caffe_cpp/cpm2_input_kernel_gpu.cpp:44-55,
+ * cpm2_output_kernel_cpu.cpp:123-137): resize = (int)(size * scale) in float, padded up to a multiple of 8.
+ * Host-only (no context). */
+int st_cpm2_geometry(int h, int w, float scale, int* resize_h, int* resize_w, int* net_h, int* net_w);
+
+/* CPM2Input: replaces the per-frame body of CPM2InputKernel::execute
+ * (cpm2_input_kernel_gpu.cpp:104-140: cvtColor RGB2BGR, resize INTER_CUBIC, copyMakeBorder with 128,
+ * convertTo(F32, 1/256, -0.5), split, three plane copies, cudaMemcpy2DAsync) for a whole batch in one
+ * launch.  frames: n device pointers to (h, w, 3) uint8 RGB frames; out: n device pointers to dense
+ * planar (3, net_h, net_w) float32 frames (planes B, G, R), the FrameInfo(3, net_h, net_w, F32) frame the
+ * reference hands to insert_frame (:96-103).  Arithmetic: OpenCV's CPU functions of the same names (the
+ * reference file calls their cv::cuda twins, whose bicubic is a different filter; see st_pose.hip). */
+int st_cpm2_input_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, float scale,
+                        float* const* out_dev);
+
+/* CPM2Output, candidate scoring: replaces the pair loop of CPM2OutputKernel::connect_limbs_coco
+ * (cpm2_output_kernel_cpu.cpp:424-487) for all 19 limbs of the COCO_18 model and a batch of frames.
+ * heatmaps: n device pointers to (57, net_h, net_w) float32 maps ("cpm2_resized_map"); peaks: n device
+ * pointers to (18, max_peaks + 1, 3) float32 joint candidates ("cpm2_joints": row 0 of a part = [count,
+ * -, -], rows 1.. = (x, y, score)).  scores_dev: n * 19 * max_peaks * max_peaks float32; entry
+ * [f][k][i-1][j-1] is the mean part-affinity score sum/count of candidate pair (i, j) of limb k when
+ * more than min_above of the 10 samples exceed inter_threshold, else -1 (the reference's values:
+ * inter_threshold 0.05, min_above 9, max_peaks 64; :795-801). */
+int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev, const float* const* peaks_dev, int n,
+                        int net_h, int net_w, int max_peaks, float inter_threshold, int min_above,
+                        float* scores_dev);
 
 #ifdef __cplusplus
 }

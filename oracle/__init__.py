@@ -270,6 +270,146 @@ def cvt_color(frame, code, gray_bits=15):
     return out
 
 
+def cpm2_geometry(h, w, scale):
+    """(resize_h, resize_w, net_h, net_w) as cpm2_input_kernel_gpu.cpp:44-55 derives them."""
+    v = [ctypes.c_int() for _ in range(4)]
+    if lib().orc_cpm2_geometry(h, w, ctypes.c_float(scale), *[ctypes.byref(x) for x in v]):
+        raise ValueError("empty network input")
+    return tuple(x.value for x in v)
+
+
+def cpm2_input(frame, scale):
+    """(h,w,3) uint8 RGB -> (3,net_h,net_w) float32: the CPM2Input op."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, _ = frame.shape
+    _, _, nh, nw = cpm2_geometry(h, w, scale)
+    out = np.empty((3, nh, nw), np.float32)
+    assert lib().orc_cpm2_input(_p(frame), h, w, ctypes.c_float(scale), _p(out)) == 0
+    return out
+
+
+# COCO_18 tables of the CPM2Output op (cpm2_output_kernel_cpu.cpp:84-88)
+CPM2_LIMB_SEQ = [1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8, 8, 9, 9, 10, 1, 11, 11, 12, 12, 13, 1, 0, 0, 14, 14, 16, 0, 15, 15,
+                 17, 2, 16, 5, 17]
+CPM2_MAP_IDX = [31, 32, 39, 40, 33, 34, 35, 36, 41, 42, 43, 44, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 47, 48, 49,
+                50, 53, 54, 51, 52, 55, 56, 37, 38, 45, 46]
+
+
+def _c_round(x):
+    """C round(): half away from zero."""
+    import math
+    x = float(x)
+    return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
+
+
+def cpm2_limb_scores(heatmap, peaks, inter_threshold=0.05, min_above=9):
+    """Candidate scoring of connect_limbs_coco (cpm2_output_kernel_cpu.cpp:424-487) in float32, pair
+    by pair: heatmap (57,H,W), peaks (18,max_peaks+1,3) -> (19,max_peaks,max_peaks), -1 = rejected."""
+    f32 = np.float32
+    heatmap = np.asarray(heatmap, f32)
+    pk = np.asarray(peaks, f32)
+    _, H, W = heatmap.shape
+    mp = pk.shape[1] - 1
+    out = np.full((19, mp, mp), -1, f32)
+    thr = f32(inter_threshold)
+    for k in range(19):
+        map_x, map_y = heatmap[CPM2_MAP_IDX[2 * k]].ravel(), heatmap[CPM2_MAP_IDX[2 * k + 1]].ravel()
+        candA, candB = pk[CPM2_LIMB_SEQ[2 * k]].ravel(), pk[CPM2_LIMB_SEQ[2 * k + 1]].ravel()
+        nA, nB = int(candA[0]), int(candB[0])
+        for i in range(1, nA + 1):
+            for j in range(1, nB + 1):
+                s_x, s_y = candA[i * 3], candA[i * 3 + 1]
+                d_x, d_y = f32(candB[j * 3] - candA[i * 3]), f32(candB[j * 3 + 1] - candA[i * 3 + 1])
+                norm_vec = np.sqrt(f32(f32(d_x * d_x) + f32(d_y * d_y)))
+                if norm_vec < 1e-6:
+                    continue
+                vec_x, vec_y = f32(d_x / norm_vec), f32(d_y / norm_vec)
+                total, count = f32(0), 0
+                for lm in range(10):
+                    my = _c_round(f32(s_y + f32(f32(f32(lm) * d_y) / f32(10))))
+                    mx = _c_round(f32(s_x + f32(f32(f32(lm) * d_x) / f32(10))))
+                    mx, my = min(mx, W - 1), min(my, H - 1)
+                    assert mx >= 0 and my >= 0                     # CHECK_GE in the reference
+                    idx = my * W + mx
+                    score = f32(f32(vec_x * map_x[idx]) + f32(vec_y * map_y[idx]))
+                    if score > thr:
+                        total = f32(total + score)
+                        count += 1
+                if count > min_above:
+                    out[k, i - 1, j - 1] = f32(total / f32(count))
+    return out
+
+
+def cpm2_connect_limbs_coco(heatmap, peaks, frame_h, frame_w, scores=None, max_people=96, min_subset_cnt=3,
+                            min_subset_score=0.4, inter_threshold=0.05, min_above=9):
+    """connect_limbs_coco (cpm2_output_kernel_cpu.cpp:362-689) row by row, with the reference's row-of-
+    doubles bookkeeping: people as float32 (n,18,3) in original-frame coordinates.  Candidates are
+    ordered with a stable sort (the reference's std::sort leaves ties unspecified)."""
+    f32 = np.float32
+    pk = np.asarray(peaks, f32)
+    _, H, W = np.asarray(heatmap).shape
+    mp = pk.shape[1] - 1
+    flat = pk.ravel()
+    if scores is None:
+        scores = cpm2_limb_scores(heatmap, peaks, inter_threshold, min_above)
+    num_parts, off = 18, 3 * (mp + 1)
+    CNT, SCORE, SIZE = num_parts + 2, num_parts + 1, num_parts + 3
+    subset = []
+    for k in range(19):
+        pa, pb = CPM2_LIMB_SEQ[2 * k], CPM2_LIMB_SEQ[2 * k + 1]
+        candA, candB = pk[pa].ravel(), pk[pb].ravel()
+        nA, nB = int(candA[0]), int(candB[0])
+        if nA == 0 and nB == 0:
+            continue
+        if nA == 0 or nB == 0:
+            part, cand, n = (pb, candB, nB) if nA == 0 else (pa, candA, nA)
+            for i in range(1, n + 1):
+                o = part * off + i * 3 + 2
+                if not any(row[part] == o for row in subset):
+                    row = [0.0] * SIZE
+                    row[part], row[CNT], row[SCORE] = float(o), 1.0, float(cand[i * 3 + 2])
+                    subset.append(row)
+            continue
+        temp = [(i, j, float(scores[k, i - 1, j - 1])) for i in range(1, nA + 1) for j in range(1, nB + 1)
+                if scores[k, i - 1, j - 1] >= 0]
+        temp.sort(key=lambda r: -r[2])
+        num, usedA, usedB, conns = min(nA, nB), set(), set(), []
+        for i, j, sc in temp:
+            if len(conns) == num:
+                break
+            if i not in usedA and j not in usedB:
+                conns.append((pa * off + i * 3 + 2, pb * off + j * 3 + 2, float(f32(sc))))
+                usedA.add(i); usedB.add(j)
+        for a, b, sc in conns:
+            hits = 0
+            if k != 0:
+                for row in subset:
+                    if row[pa] == a:
+                        row[pb] = float(b)
+                        hits += 1
+                        row[CNT] += 1
+                        row[SCORE] = row[SCORE] + float(flat[b]) + sc
+            if hits == 0:
+                row = [0.0] * SIZE
+                row[pa], row[pb], row[CNT] = float(a), float(b), 2.0
+                row[SCORE] = float(f32(flat[a] + flat[b])) + sc
+                subset.append(row)
+    people = []
+    for row in subset:
+        if row[CNT] >= min_subset_cnt and row[SCORE] / row[CNT] > float(f32(min_subset_score)):
+            j3 = np.zeros((num_parts, 3), f32)
+            for j in range(num_parts):
+                idx = int(row[j])
+                if idx:
+                    j3[j, 2] = flat[idx]
+                    j3[j, 1] = f32(f32(flat[idx - 1] * f32(frame_h)) / f32(H))
+                    j3[j, 0] = f32(f32(flat[idx - 2] * f32(frame_w)) / f32(W))
+            people.append(j3)
+            if len(people) == max_people:
+                break
+    return np.stack(people) if people else np.zeros((0, num_parts, 3), f32)
+
+
 def shot_boundaries(histograms):
     """Restatement of shot_detection.py:11-28 (A8).  ``histograms``: sequence of N items,
     each indexable as [channel][bin] (3 channels).  Returns the list of boundary indices

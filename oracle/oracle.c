@@ -1214,3 +1214,42 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CPM2Input op -- CPM2InputKernel::execute,
+ * /root/reference/scannertools_caffe/scannertools_caffe_cpp/cpm2_input_kernel_gpu.cpp:104-140, stated
+ * with the OpenCV CPU functions of the same names, one after the other as the reference calls them:
+ * cvtColor(RGB2BGR) -> resize(INTER_CUBIC) to ((int)(w*scale), (int)(h*scale)) -> copyMakeBorder(bottom,
+ * right up to a multiple of 8, BORDER_CONSTANT 128) -> convertTo(CV_32FC3, 1/256, -0.5) -> split into a
+ * planar (3, net_h, net_w) array.  (The reference file uses cv::cuda::resize, whose bicubic is another
+ * filter; not the parity target -- SURVEY.md section 0.4.)  PARITY UNPINNED against real OpenCV output like
+ * the Resize op whose restatement it reuses.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int orc_cpm2_geometry(int h, int w, float scale, int* rh, int* rw, int* nh, int* nw) {
+  if (h <= 0 || w <= 0 || !(scale > 0)) return 1;
+  const int resize_width = (int)(w * scale), resize_height = (int)(h * scale);  /* :48-49 */
+  if (resize_width <= 0 || resize_height <= 0) return 1;
+  const int width_padding = (resize_width % 8) ? 8 - (resize_width % 8) : 0;
+  const int height_padding = (resize_height % 8) ? 8 - (resize_height % 8) : 0;
+  *rh = resize_height; *rw = resize_width;
+  *nh = resize_height + height_padding; *nw = resize_width + width_padding;
+  return 0;
+}
+
+ORC_API int orc_cpm2_input(const uint8_t* rgb, int h, int w, float scale, float* out) {
+  int rh, rw, nh, nw;
+  if (orc_cpm2_geometry(h, w, scale, &rh, &rw, &nh, &nw)) return 1;
+  uint8_t* bgr = (uint8_t*)malloc((size_t)h * w * 3);
+  uint8_t* resized = (uint8_t*)malloc((size_t)rh * rw * 3);
+  orc_cvt_color_u8(rgb, h, w, 3, ORC_BGR2RGB, 15, bgr);
+  orc_resize_u8(bgr, h, w, 3, resized, rh, rw, 2 /* INTER_CUBIC */);
+  const size_t plane = (size_t)nh * nw;
+  for (int y = 0; y < nh; ++y)
+    for (int x = 0; x < nw; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const uint8_t v = (x < rw && y < rh) ? resized[((size_t)y * rw + x) * 3 + c] : 128;  /* copyMakeBorder */
+        out[c * plane + (size_t)y * nw + x] = (float)v * (1.0f / 256.0f) + -0.5f;             /* convertTo */
+      }
+  free(bgr); free(resized);
+  return 0;
+}

@@ -4,6 +4,7 @@
 // (optical_flow_kernel_gpu.cpp:12,45-46), Kernel (blur_kernel_cpu.cpp:25,51-52);
 // REGISTER_KERNEL(...).device().batch().num_devices() (histogram_kernel_cpu.cpp:54-57).
 #pragma once
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -98,6 +99,17 @@ class VideoKernel {
   void check_frame(const DeviceHandle& /*device*/, const Element& element) {
     const Frame* f = element.as_const_frame();
     FrameInfo info = f->as_frame_info();
+    if (!have_info_ || info != frame_info_) {
+      frame_info_ = info;
+      have_info_ = true;
+      new_frame_info();
+    }
+  }
+  // the FrameInfo travels as a bytes element (InfoFromFrame op, misc/info_from_frame_kernel.cpp:17-27):
+  // the raw struct, on the kernel's device (host in every use of the reference: cpm2_output_kernel_cpu.cpp:147)
+  void check_frame_info(const DeviceHandle& /*device*/, const Element& element) {
+    FrameInfo info;
+    if (element.size >= sizeof(FrameInfo)) memcpy((void*)&info, element.buffer, sizeof(FrameInfo));
     if (!have_info_ || info != frame_info_) {
       frame_info_ = info;
       have_info_ = true;

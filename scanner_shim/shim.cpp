@@ -378,6 +378,61 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
   return outs;
 }
 
+// Several input columns (Batched / Plain kernels, no stencil): column c, row r is ptrs[c * n + r]; frame
+// columns carry a dense frame of shape shapes[3c..3c+2] and type types[c], byte columns sizes[c * n + r]
+// bytes.  Frame columns live on the kernel's device, byte columns where the caller put them (the
+// reference's only multi-input op on this path reads its byte column on the host).  Returns the first
+// output column.
+SHIM_EXPORT void* stshim_run_columns(void* k, int n_cols, int n, const void* const* ptrs, const size_t* sizes,
+                                     const int* is_frame, const int* shapes, const int* types, int batch, char* err,
+                                     size_t err_len) {
+  auto* ek = (EngineKernel*)k;
+  if (!ek || n_cols < 1 || n < 0 || (n > 0 && !ptrs)) { set_err(err, err_len, "bad arguments"); return nullptr; }
+  if (ek->reg.kind != KernelKind::Batched && ek->reg.kind != KernelKind::Plain) {
+    set_err(err, err_len, "stshim_run_columns drives Batched and Plain kernels only");
+    return nullptr;
+  }
+  if (batch < 1 || ek->reg.kind != KernelKind::Batched) batch = 1;
+  std::vector<std::vector<Frame>> frames(n_cols);
+  for (int c = 0; c < n_cols; ++c)
+    if (is_frame[c]) {
+      FrameInfo info(shapes[3 * c], shapes[3 * c + 1], shapes[3 * c + 2], (FrameType)types[c]);
+      frames[c].reserve(n);
+      for (int r = 0; r < n; ++r) frames[c].emplace_back(info, (u8*)ptrs[(size_t)c * n + r]);
+    }
+  auto elem = [&](int c, int r) {
+    Element e = is_frame[c] ? Element(&frames[c][r]) : Element((u8*)ptrs[(size_t)c * n + r], sizes[(size_t)c * n + r]);
+    e.index = r;
+    return e;
+  };
+  auto* outs = new EngineOutputs();
+  outs->device = ek->device;
+  g_last_execute_seconds = 0.0;
+  for (int r0 = 0; r0 < n; r0 += batch) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int nb = std::min(batch, n - r0);
+    BatchedElements out_cols(1);
+    if (ek->reg.kind == KernelKind::Batched) {
+      BatchedElements in(n_cols);
+      for (int c = 0; c < n_cols; ++c)
+        for (int i = 0; i < nb; ++i) in[c].push_back(elem(c, r0 + i));
+      static_cast<BatchedKernel*>(ek->kernel.get())->execute(in, out_cols);
+    } else {
+      Elements in, o;
+      for (int c = 0; c < n_cols; ++c) in.push_back(elem(c, r0));
+      static_cast<Kernel*>(ek->kernel.get())->execute(in, o);
+      out_cols[0] = o;
+    }
+    g_last_execute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    for (auto& e : out_cols[0]) outs->elements.push_back(e);
+    if ((int)out_cols[0].size() != nb) {
+      set_err(err, err_len, "kernel produced " + std::to_string(out_cols[0].size()) + " outputs for " + std::to_string(nb) + " rows");
+      return outs;
+    }
+  }
+  return outs;
+}
+
 SHIM_EXPORT int stshim_outputs_count(void* o) { return o ? (int)((EngineOutputs*)o)->elements.size() : 0; }
 
 SHIM_EXPORT int stshim_output_get(void* o, int i, const void** data, size_t* size, int* is_frame, int* shape3, int* type) {

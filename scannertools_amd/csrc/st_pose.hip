@@ -1,0 +1,234 @@
+// Pose path of scannertools_caffe (BASELINE config 5): the two deterministic
+// ends of the CPM2 / OpenPose COCO-18 pipeline, for gfx950.
+//
+//   CPM2Input   /root/reference/scannertools_caffe/scannertools_caffe_cpp/cpm2_input_kernel_gpu.cpp:104-140
+//               cvtColor(RGB2BGR) -> resize(INTER_CUBIC, frame * scale) -> copyMakeBorder(bottom / right to a
+//               multiple of 8, value 128) -> convertTo(F32, 1/256, -0.5) -> split -> planar (3, H, W):
+//               SIX passes over the frame in the reference, ONE kernel here (k_cpm2_input): every thread
+//               produces one pixel of the network input in all three planes.
+//               The arithmetic is that of the OpenCV *CPU* functions of the same names (cv::resize's 8-bit
+//               bicubic: A = -0.75, half-pixel centres, 11-bit fixed-point taps -- the same restatement as the
+//               Resize op); the reference file calls their cv::cuda twins, whose bicubic is a different filter
+//               (A = -0.5, no half-pixel shift), and like the other --build-cuda wrappers it is not the parity
+//               target.
+//   CPM2Output  .../cpm2_output_kernel_cpu.cpp:424-487 (connect_limbs_coco, candidate scoring): for every limb
+//               of the COCO model and every pair of candidate joints, ten samples of the part-affinity field
+//               along the segment.  The heat maps are 57 planes of the network's input size (55 MB per 1080p
+//               frame at scale 0.34) and live where the network wrote them; k_cpm2_limb_scores samples them
+//               in place and hands back max_peaks^2 floats per limb, so the maps never cross PCIe.  The greedy
+//               assembly of people from the scored pairs is sequential host work (kernel class).
+#include <cmath>
+#include <cstring>
+
+#include "st_internal.h"
+
+namespace {
+
+// ---- CPM2Input ------------------------------------------------------------------------------------
+struct Cpm2InArgs {
+  const uint8_t* const* src;  // n RGB frames (sh, sw, 3)
+  float* const* dst;          // n planar (3, nh, nw) float frames
+  int sh, sw, rh, rw, nh, nw;
+  double scale_x, scale_y;    // source / resized size ratios as cv::resize computes them
+};
+
+__device__ __forceinline__ int p_coef(float v) {  // saturate_cast<short>(float): cvRound + saturation
+  const float r = rintf(v);
+  return r < -32768.f ? -32768 : (r > 32767.f ? 32767 : (int)r);
+}
+__device__ __forceinline__ void p_cubic(float x, float* c) {  // cv::interpolateCubic, A = -0.75
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ __launch_bounds__(256) void k_cpm2_input(Cpm2InArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= a.nw) return;
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  float* __restrict__ dst = a.dst[blockIdx.z];
+  const size_t plane = (size_t)a.nh * a.nw, o = (size_t)y * a.nw + x;
+  if (x >= a.rw || y >= a.rh) {  // copyMakeBorder value 128: 128 / 256 - 0.5
+    dst[o] = dst[plane + o] = dst[2 * plane + o] = 128 * (1.0f / 256.0f) + -0.5f;
+    return;
+  }
+  int v8[3];
+  if (a.rw == a.sw && a.rh == a.sh) {  // cv::resize copies when the sizes are equal
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v8[c] = src[((size_t)y * a.sw + x) * 3 + c];
+  } else {
+    float fx = (float)((x + 0.5) * a.scale_x - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= sx;
+    float fy = (float)((y + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    float cx[4], cy[4];
+    p_cubic(fx, cx);
+    p_cubic(fy, cy);
+    int ax[4], by[4], xs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ax[k] = p_coef(cx[k] * 2048);
+      by[k] = p_coef(cy[k] * 2048);
+      const int xx = sx - 1 + k;
+      xs[k] = (xx < 0 ? 0 : (xx > a.sw - 1 ? a.sw - 1 : xx)) * 3;
+    }
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = sy - 1 + k;
+      const uint8_t* S = src + (size_t)(yy < 0 ? 0 : (yy > a.sh - 1 ? a.sh - 1 : yy)) * a.sw * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        acc[c] += (S[xs[0] + c] * ax[0] + S[xs[1] + c] * ax[1] + S[xs[2] + c] * ax[2] + S[xs[3] + c] * ax[3]) * by[k];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int q = (acc[c] + (1 << 21)) >> 22;
+      v8[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+    }
+  }
+  // planes in B, G, R order: the frame is RGB and the reference swaps it to BGR before the split
+  dst[o] = (float)v8[2] * (1.0f / 256.0f) + -0.5f;
+  dst[plane + o] = (float)v8[1] * (1.0f / 256.0f) + -0.5f;
+  dst[2 * plane + o] = (float)v8[0] * (1.0f / 256.0f) + -0.5f;
+}
+
+// ---- CPM2Output: limb candidate scores ---------------------------------------------------------------
+// COCO_18 model tables (cpm2_output_kernel_cpu.cpp:84-88): joint pair of each of the 19 limbs and the two
+// part-affinity planes (x, y) of each
+__constant__ int kLimbSeq[38] = {1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8, 8, 9, 9, 10, 1, 11,
+                                 11, 12, 12, 13, 1, 0, 0, 14, 14, 16, 0, 15, 15, 17, 2, 16, 5, 17};
+__constant__ int kMapIdx[38] = {31, 32, 39, 40, 33, 34, 35, 36, 41, 42, 43, 44, 19, 20, 21, 22, 23, 24, 25,
+                                26, 27, 28, 29, 30, 47, 48, 49, 50, 53, 54, 51, 52, 55, 56, 37, 38, 45, 46};
+
+struct LimbArgs {
+  const float* const* heatmaps;  // n x (57, h, w)
+  const float* const* peaks;     // n x (parts, max_peaks + 1, 3): row 0 = [count, -, -], rows 1.. = (x, y, score)
+  float* scores;                 // n x 19 x max_peaks x max_peaks
+  int h, w, max_peaks, min_above;
+  float threshold;
+};
+
+__global__ __launch_bounds__(256) void k_cpm2_limb_scores(LimbArgs a) {
+  const int k = blockIdx.x, f = blockIdx.y;
+  const float* __restrict__ hm = a.heatmaps[f];
+  const float* __restrict__ pk = a.peaks[f];
+  const size_t plane = (size_t)a.h * a.w;
+  const float* __restrict__ map_x = hm + (size_t)kMapIdx[2 * k] * plane;
+  const float* __restrict__ map_y = hm + (size_t)kMapIdx[2 * k + 1] * plane;
+  const int peaks_offset = 3 * (a.max_peaks + 1);
+  const float* __restrict__ candA = pk + kLimbSeq[2 * k] * peaks_offset;
+  const float* __restrict__ candB = pk + kLimbSeq[2 * k + 1] * peaks_offset;
+  int nA = (int)candA[0], nB = (int)candB[0];
+  nA = nA < 0 ? 0 : (nA > a.max_peaks ? a.max_peaks : nA);
+  nB = nB < 0 ? 0 : (nB > a.max_peaks ? a.max_peaks : nB);
+  float* __restrict__ out = a.scores + ((size_t)f * 19 + k) * a.max_peaks * a.max_peaks;
+  const int num_inter = 10;
+  for (int p = threadIdx.x; p < a.max_peaks * a.max_peaks; p += 256) {
+    const int i = p / a.max_peaks + 1, j = p - (i - 1) * a.max_peaks + 1;
+    float res = -1.f;
+    if (i <= nA && j <= nB) {
+      const float s_x = candA[i * 3], s_y = candA[i * 3 + 1];
+      const float d_x = candB[j * 3] - candA[i * 3], d_y = candB[j * 3 + 1] - candA[i * 3 + 1];
+      const float norm_vec = sqrtf(d_x * d_x + d_y * d_y);
+      if (!(norm_vec < 1e-6)) {  // coincident peaks are not connected
+        const float vec_x = d_x / norm_vec, vec_y = d_y / norm_vec;
+        float sum = 0;
+        int count = 0;
+        for (int lm = 0; lm < num_inter; lm++) {
+          int my = (int)roundf(s_y + lm * d_y / num_inter);
+          int mx = (int)roundf(s_x + lm * d_x / num_inter);
+          if (mx >= a.w) mx = a.w - 1;
+          if (my >= a.h) my = a.h - 1;
+          if (mx < 0) mx = 0;  // the reference aborts here (CHECK_GE); peaks inside the map never get there
+          if (my < 0) my = 0;
+          const int idx = my * a.w + mx;
+          const float score = vec_x * map_x[idx] + vec_y * map_y[idx];
+          if (score > a.threshold) { sum = sum + score; count++; }
+        }
+        if (count > a.min_above) res = sum / count;
+      }
+    }
+    out[p] = res;
+  }
+}
+
+}  // namespace
+
+ST_EXPORT int st_cpm2_geometry(int h, int w, float scale, int* resize_h, int* resize_w, int* net_h, int* net_w) {
+  if (h <= 0 || w <= 0 || !(scale > 0)) return ST_ERR_INVALID;
+  // cpm2_input_kernel_gpu.cpp:48-55: i32 = i32 * f32 (float product, truncated), padding to a multiple of 8
+  const int rw = (int)(w * scale), rh = (int)(h * scale);
+  if (rw <= 0 || rh <= 0) return ST_ERR_INVALID;
+  const int wp = (rw % 8) ? 8 - (rw % 8) : 0, hp = (rh % 8) ? 8 - (rh % 8) : 0;
+  if (resize_h) *resize_h = rh;
+  if (resize_w) *resize_w = rw;
+  if (net_h) *net_h = rh + hp;
+  if (net_w) *net_w = rw + wp;
+  return ST_OK;
+}
+
+ST_EXPORT int st_cpm2_input_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, float scale,
+                                  float* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  int rh, rw, nh, nw;
+  if (n < 0 || st_cpm2_geometry(h, w, scale, &rh, &rw, &nh, &nw) != ST_OK || (long long)h * w > 200000000LL ||
+      (long long)nh * nw > 200000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "cpm2_input: bad arguments (n=%d h=%d w=%d scale=%g)", n, h, w, (double)scale);
+  if (nh > 65535) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "cpm2_input: network input taller than 65535 rows");
+  if (n == 0) return ST_OK;
+  if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_input: null argument");
+  for (int i = 0; i < n; ++i)
+    if (!frames_dev[i] || !out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_input: row %d is null", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const uint8_t** d_src = (const uint8_t**)st_ws_alloc(ctx, tb);
+  float** d_dst = (float**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  Cpm2InArgs a;
+  a.sh = h; a.sw = w; a.rh = rh; a.rw = rw; a.nh = nh; a.nw = nw;
+  a.scale_x = 1. / ((double)rw / w);
+  a.scale_y = 1. / ((double)rh / h);
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.src = d_src + f0; a.dst = d_dst + f0;
+    st_timed t(ctx, ST_K_CPM2_INPUT);
+    hipLaunchKernelGGL(k_cpm2_input, dim3((nw + 255) / 256, nh, nf), dim3(256), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+
+ST_EXPORT int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev, const float* const* peaks_dev, int n,
+                                  int net_h, int net_w, int max_peaks, float inter_threshold, int min_above,
+                                  float* scores_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || net_h <= 0 || net_w <= 0 || max_peaks < 1 || max_peaks > 1024 || (long long)net_h * net_w > 35000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "cpm2_limb_scores: bad arguments (n=%d %dx%d max_peaks=%d)", n, net_h, net_w, max_peaks);
+  if (n == 0) return ST_OK;
+  if (!heatmaps_dev || !peaks_dev || !scores_dev) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_limb_scores: null argument");
+  for (int i = 0; i < n; ++i)
+    if (!heatmaps_dev[i] || !peaks_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_limb_scores: row %d is null", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const float** d_hm = (const float**)st_ws_alloc(ctx, tb);
+  const float** d_pk = (const float**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_hm, heatmaps_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_pk, peaks_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  LimbArgs a;
+  a.h = net_h; a.w = net_w; a.max_peaks = max_peaks; a.min_above = min_above; a.threshold = inter_threshold;
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.heatmaps = d_hm + f0; a.peaks = d_pk + f0;
+    a.scores = scores_dev + (size_t)f0 * 19 * max_peaks * max_peaks;
+    st_timed t(ctx, ST_K_CPM2_LIMBS);
+    hipLaunchKernelGGL(k_cpm2_limb_scores, dim3(19, nf), dim3(256), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}

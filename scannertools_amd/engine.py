@@ -57,18 +57,20 @@ class PerfParams:
 
 _FRAME_DTYPES = {0: np.uint8, 1: np.float32, 2: np.float64}
 
-_LIB = None
+CAFFE_LIB = os.path.join(_HERE, "lib", "libscannertools_caffe.so")
+
+_LIBS = {}
 
 
-def _imgproc():
-    """dlopen the op library; its static initialisers register ops and kernels (the mechanism of
-    scannertools_infra/__init__.py:90-100 -> scannerpy.op.register_module)."""
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(IMGPROC_LIB):
-            raise RuntimeError("libscannertools_imgproc.so is not built (%s); run __graft_entry__.build()" % IMGPROC_LIB)
+def _load_op_library(path):
+    """dlopen an op library; its static initialisers register ops and kernels (the mechanism of
+    scannertools_infra/__init__.py:90-100 -> scannerpy.op.register_module).  Every library carries
+    its own registry and mini engine (scanner_shim/shim.cpp)."""
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise RuntimeError("%s is not built (%s); run __graft_entry__.build()" % (os.path.basename(path), path))
         _native.lib()  # loads torch's HIP runtime + libscannertools_hip.so first
-        L = ctypes.CDLL(IMGPROC_LIB)
+        L = ctypes.CDLL(path)
         vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         L.stshim_num_kernels.restype = ci
         L.stshim_kernel_info.argtypes = [ci, ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -80,6 +82,9 @@ def _imgproc():
         L.stshim_run_frames.restype = vp
         L.stshim_run_frames.argtypes = [vp, ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, ctypes.POINTER(ci), ci,
                                         ctypes.c_char_p, sz]
+        L.stshim_run_columns.restype = vp
+        L.stshim_run_columns.argtypes = [vp, ci, ci, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ci),
+                                         ctypes.POINTER(ci), ctypes.POINTER(ci), ci, ctypes.c_char_p, sz]
         L.stshim_outputs_count.argtypes = [vp]
         L.stshim_output_get.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ci),
                                         ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -88,13 +93,31 @@ def _imgproc():
         L.stshim_live_buffers.restype = sz
         L.stshim_last_execute_seconds.restype = ctypes.c_double
         L.stshim_live_buffers.argtypes = [ci]
-        _LIB = L
-    return _LIB
+        _LIBS[path] = L
+    return _LIBS[path]
 
 
-def registered_kernels():
-    """[(op name, device type, kind, can_batch)] of the loaded op library."""
-    L = _imgproc()
+def _imgproc():
+    return _load_op_library(IMGPROC_LIB)
+
+
+def _caffe():
+    """libscannertools_caffe.so: the pose ops (scannertools_caffe's op library)."""
+    return _load_op_library(CAFFE_LIB)
+
+
+def _lib_for_op(name):
+    """The op library that registers `name` (imgproc first, then caffe)."""
+    for get in (_imgproc, _caffe):
+        L = get()
+        if L.stshim_op_info(name.encode(), None, None, None, None, 0, None) == 0:
+            return L
+    raise RuntimeError("no loaded op library registers op %r" % name)
+
+
+def registered_kernels(library="imgproc"):
+    """[(op name, device type, kind, can_batch)] of an op library ("imgproc" or "caffe")."""
+    L = _caffe() if library == "caffe" else _imgproc()
     out = []
     for i in range(L.stshim_num_kernels()):
         name = ctypes.create_string_buffer(64)
@@ -105,7 +128,10 @@ def registered_kernels():
 
 
 def op_info(name):
-    L = _imgproc()
+    try:
+        L = _lib_for_op(name)
+    except RuntimeError:
+        return None
     n_in, n_out, isf, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     st = (ctypes.c_int * 16)()
     if L.stshim_op_info(name.encode(), ctypes.byref(n_in), ctypes.byref(n_out), ctypes.byref(isf), st, 16, ctypes.byref(ns)):
@@ -176,7 +202,7 @@ class _CppOpNode(_Node):
         import torch
         if not idx:
             return []
-        L = _imgproc()
+        L = _lib_for_op(self.name)
         n_total = self.parent.length()
         err = ctypes.create_string_buffer(512)
         dev_id = self.client.device_id
@@ -244,6 +270,96 @@ class _CppOpNode(_Node):
         if L.stshim_output_copy(res, i, buf, size.value):
             raise RuntimeError("copying output row %d failed" % i)
         return buf.raw
+
+
+class _FrameInfoNode(_Node):
+    """InfoFromFrame (scannertools_cpp/misc/info_from_frame_kernel.cpp:17-27): per row the raw
+    FrameInfo struct {int32 shape[3]; int32 type} of the parent's frame, as bytes."""
+
+    def __init__(self, parent):
+        self.parent = parent
+
+    def length(self):
+        return self.parent.length()
+
+    def rows(self, idx):
+        import struct
+        out = []
+        for f in self.parent.rows(idx):
+            h, w, c = f.shape
+            ftype = 0 if str(f.dtype).endswith("uint8") else 1
+            out.append(struct.pack("<4i", h, w, c, ftype))
+        return out
+
+
+class _CppMultiOpNode(_Node):
+    """A C++ op with several input columns (frames and/or bytes), no stencil: CPM2Output."""
+
+    def __init__(self, client, name, parents, device, batch, args):
+        self.client, self.name, self.parents = client, name, parents
+        self.device = DeviceType.CPU if device is None else device
+        self.batch = int(batch) if batch else 1
+        self.args = args or b""
+
+    def length(self):
+        n = {p.length() for p in self.parents}
+        if len(n) != 1:
+            raise RuntimeError("op %s: input columns have different lengths %s" % (self.name, sorted(n)))
+        return n.pop()
+
+    def rows(self, idx):
+        import torch
+        if not idx:
+            return []
+        L = _lib_for_op(self.name)
+        err = ctypes.create_string_buffer(512)
+        dev_id = self.client.device_id
+        k = L.stshim_kernel_create(self.name.encode(), self.device, dev_id, self.args, len(self.args), err, 512)
+        if not k:
+            raise RuntimeError("cannot create kernel for op %s on device type %d: %s" % (self.name, self.device, err.value.decode()))
+        try:
+            n, nc = len(idx), len(self.parents)
+            cols = [p.rows(idx) for p in self.parents]
+            keep, ptrs, sizes = [], [], []
+            is_frame, shapes, types = [], [], []
+            for col in cols:
+                first = col[0]
+                if isinstance(first, (bytes, bytearray)):
+                    is_frame.append(0); shapes += [0, 0, 0]; types.append(0)
+                    for e in col:
+                        b = ctypes.create_string_buffer(bytes(e), len(e))
+                        keep.append(b)
+                        ptrs.append(ctypes.addressof(b)); sizes.append(len(e))
+                else:
+                    if self.device == DeviceType.GPU:
+                        fr = [f if (isinstance(f, torch.Tensor) and f.is_cuda) else torch.as_tensor(np.ascontiguousarray(f)).cuda(dev_id) for f in col]
+                        p = [f.data_ptr() for f in fr]
+                    else:
+                        fr = [np.ascontiguousarray(f.cpu().numpy() if isinstance(f, torch.Tensor) else f) for f in col]
+                        p = [f.ctypes.data for f in fr]
+                    keep.append(fr)
+                    sh = tuple(fr[0].shape)
+                    if any(tuple(f.shape) != sh for f in fr) or len(sh) != 3:
+                        raise ValueError("op %s: frames of a column must share one 3-d shape" % self.name)
+                    is_frame.append(1); shapes += list(sh)
+                    types.append(0 if fr[0].dtype in (np.uint8, torch.uint8) else 1)
+                    ptrs += p; sizes += [0] * n
+            if self.device == DeviceType.GPU:
+                torch.cuda.synchronize(dev_id)
+            res = L.stshim_run_columns(k, nc, n, (ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_size_t * len(sizes))(*sizes),
+                                       (ctypes.c_int * nc)(*is_frame), (ctypes.c_int * (3 * nc))(*shapes),
+                                       (ctypes.c_int * nc)(*types), self.batch, err, 512)
+            self.client.execute_seconds += L.stshim_last_execute_seconds()
+            if not res or err.value:
+                if res:
+                    L.stshim_outputs_free(res)
+                raise RuntimeError("op %s failed: %s" % (self.name, err.value.decode()))
+            try:
+                return [_CppOpNode._fetch(L, res, i) for i in range(n)]
+            finally:
+                L.stshim_outputs_free(res)
+        finally:
+            L.stshim_kernel_destroy(k)
 
 
 class _PyOpNode(_Node):
@@ -420,6 +536,24 @@ class _Ops:
         from . import vis as _vis
         dev = self.sc.device_id
         return _PyMapNode(lambda frames, flows: _vis.draw_flow_rows(frames, flows, device=dev), [frame, flow])
+
+    def InfoFromFrame(self, frame):
+        """sc.ops.InfoFromFrame(frame=frame): the frame's FrameInfo as a bytes column."""
+        return _FrameInfoNode(frame)
+
+    def CPM2Input(self, frame, scale, device=None, batch=None):
+        """sc.ops.CPM2Input(frame=..., args CPM2Args{scale}) (cpm2_input_kernel_gpu.cpp:184)."""
+        from . import _proto
+        return _CppOpNode(self.sc, "CPM2Input", frame, device, batch, None, _proto.encode([(2, "float", float(scale))]))
+
+    def CPM2Output(self, cpm2_resized_map, cpm2_joints, original_frame_info, scale, device=None, batch=None):
+        """sc.ops.CPM2Output(cpm2_resized_map=..., cpm2_joints=..., original_frame_info=...)
+        (cpm2_output_kernel_cpu.cpp:805-810); rows read with scannertools_amd.types.poses."""
+        from . import _proto
+        node = _CppMultiOpNode(self.sc, "CPM2Output", [cpm2_resized_map, cpm2_joints, original_frame_info], device, batch,
+                               _proto.encode([(2, "float", float(scale))]))
+        node.reader = _types.poses
+        return node
 
     def ShotBoundaries(self, histograms):
         """sc.ops.ShotBoundaries(histograms=hist) (tests/test_all.py:227)."""

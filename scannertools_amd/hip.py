@@ -263,6 +263,48 @@ class HipContext:
         self._check(self._L.st_cvt_color_u8_batch(self._h, tf, n, h, w, c, int(code), int(gray_bits), to))
         return out
 
+    # -- pose path (scannertools_caffe) -------------------------------------------------------
+    def cpm2_input(self, frames, scale, out=None):
+        """CPM2Input (scannertools_caffe_cpp/cpm2_input_kernel_gpu.cpp:104-140): (n,h,w,3) uint8 RGB frames
+        -> (n,3,net_h,net_w) float32 network input (planes B,G,R; bicubic resize by ``scale``, padded to
+        a multiple of 8 with 128, x/256 - 0.5)."""
+        self._bind()
+        fr = list(frames) if isinstance(frames, (list, tuple)) else list(frames.unbind(0))
+        n = len(fr)
+        if n == 0:
+            return torch.zeros((0, 3, 0, 0), dtype=torch.float32, device=self.device)
+        h, w, _ = fr[0].shape
+        for f in fr:
+            _require_cuda(f, torch.uint8, "frame", self.device)
+            if tuple(f.shape) != (h, w, 3):
+                raise ValueError("all frames must be (h,w,3) with equal shape")
+        _, _, nh, nw = cpm2_geometry(h, w, scale)
+        out = (torch.empty((n, 3, nh, nw), dtype=torch.float32, device=self.device) if out is None
+               else _check_out(out, (n, 3, nh, nw), torch.float32, self.device))
+        tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cpm2_input_batch(self._h, tf, n, h, w, float(scale), to))
+        return out
+
+    def cpm2_limb_scores(self, heatmaps, peaks, inter_threshold=0.05, min_above=9):
+        """Candidate-pair scores of CPM2Output (cpm2_output_kernel_cpu.cpp:424-487): heatmaps
+        (n,57,H,W) float32, peaks (n,18,max_peaks+1,3) float32 -> (n,19,max_peaks,max_peaks) float32."""
+        self._bind()
+        _require_cuda(heatmaps, torch.float32, "heatmaps", self.device)
+        _require_cuda(peaks, torch.float32, "peaks", self.device)
+        n, c, H, W = heatmaps.shape
+        if c != 57 or peaks.dim() != 4 or peaks.shape[0] != n or peaks.shape[1] != 18 or peaks.shape[3] != 3:
+            raise ValueError("heatmaps must be (n,57,H,W) and peaks (n,18,max_peaks+1,3)")
+        mp = peaks.shape[2] - 1
+        out = torch.empty((n, 19, mp, mp), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        th = (ctypes.c_void_p * n)(*[heatmaps[i].data_ptr() for i in range(n)])
+        tp = (ctypes.c_void_p * n)(*[peaks[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cpm2_limb_scores(self._h, th, tp, n, H, W, mp, float(inter_threshold), int(min_above),
+                                                ctypes.c_void_p(out.data_ptr())))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.
@@ -410,6 +452,15 @@ def unpack_r(flat, h, w):
     """Inverse of :func:`pack_r`."""
     n = h * w
     return torch.cat([flat[:4 * n].view(h, w, 4), flat[4 * n:].view(h, w, 1)], dim=2).contiguous()
+
+
+def cpm2_geometry(h, w, scale):
+    """(resize_h, resize_w, net_h, net_w) of the CPM2 network input for an (h, w) frame at ``scale``."""
+    v = [ctypes.c_int() for _ in range(4)]
+    st = _native.lib().st_cpm2_geometry(h, w, float(scale), *[ctypes.byref(x) for x in v])
+    if st != 0:
+        raise StError(st, "st_cpm2_geometry(%d, %d, %r)" % (h, w, scale))
+    return tuple(x.value for x in v)
 
 
 def fb_levels(h, w, params=None):

@@ -26,3 +26,30 @@ def flow_histograms(buf, protobufs=None):
     if buf is None:
         return None
     return np.split(np.frombuffer(buf, dtype=np.dtype(np.int32)), 2)
+
+
+def poses(buf, protobufs=None):
+    """Reader of the CPM2Output op's element (cpm2_output_kernel_cpu.cpp:177-180:
+    serialize_proto_vector_of_vectors<scanner::Point>): u64 people; per person u64 joints; per joint
+    an i32 byte size and the proto3 bytes of Point{float x = 1; y = 2; score = 3}.
+    Returns float32 (people, 18, 3)."""
+    import struct
+    (n,), off = struct.unpack_from("<Q", buf, 0), 8
+    out = []
+    for _ in range(n):
+        (m,) = struct.unpack_from("<Q", buf, off)
+        off += 8
+        person = np.zeros((m, 3), np.float32)
+        for j in range(m):
+            (sz,) = struct.unpack_from("<i", buf, off)
+            off += 4
+            end = off + sz
+            while off < end:
+                tag = buf[off]
+                field, wire = tag >> 3, tag & 7
+                if wire != 5 or not 1 <= field <= 3:
+                    raise ValueError("unexpected field in a Point message")
+                person[j, field - 1] = struct.unpack_from("<f", buf, off + 1)[0]
+                off += 5
+        out.append(person)
+    return np.stack(out) if out else np.zeros((0, 18, 3), np.float32)

@@ -47,3 +47,58 @@ def planar5(a):
 def interleaved5(a):
     """(5,h,w) -> (h,w,5)."""
     return np.ascontiguousarray(np.moveaxis(a, 0, -1))
+
+
+def synthetic_pose_maps(seed, H, W, n_people, max_peaks=64, clutter=3, drop=0.1):
+    """Network outputs of the CPM2 pose model for planted people (COCO_18): heat maps (57,H,W) whose
+    part-affinity planes carry the unit vector of every planted limb along its segment (+ noise), and
+    the joint candidates (18,max_peaks+1,3) an NMS layer would report: the planted joints (some
+    dropped), jittered, plus `clutter` false candidates per part.  Returns (heatmap, peaks, truth) with
+    truth (n_people,18,2) joint positions (NaN where dropped)."""
+    import oracle
+    rng = np.random.default_rng(seed)
+    hm = (rng.standard_normal((57, H, W)) * 0.01).astype(np.float32)
+    # people stand side by side, each in its own column of the map, so that no limb crosses another person's
+    centres = np.array([[(p + 0.5) * W / max(n_people, 1), 0.52 * H] for p in range(n_people)]).reshape(n_people, 2)
+    # a loose stick figure around each centre (offsets in units of body size)
+    layout = np.array([[0, -1.0], [0, -0.7], [-0.3, -0.7], [-0.45, -0.35], [-0.5, 0.0], [0.3, -0.7], [0.45, -0.35], [0.5, 0.0],
+                       [-0.2, 0.0], [-0.22, 0.5], [-0.24, 1.0], [0.2, 0.0], [0.22, 0.5], [0.24, 1.0], [-0.08, -1.08],
+                       [0.08, -1.08], [-0.17, -1.0], [0.17, -1.0]])
+    truth = np.full((n_people, 18, 2), np.nan)
+    peaks = np.zeros((18, max_peaks + 1, 3), np.float32)
+    for p in range(n_people):
+        size = min(0.4 * H, 0.8 * W / n_people) * rng.uniform(0.8, 1.0)
+        pts = centres[p] + layout * size + rng.normal(0, 0.01 * size, (18, 2))
+        pts[:, 0] = np.clip(pts[:, 0], 2, W - 3)
+        pts[:, 1] = np.clip(pts[:, 1], 2, H - 3)
+        keep = rng.random(18) > drop
+        keep[1] = True
+        for k in range(19):
+            a, b = oracle.CPM2_LIMB_SEQ[2 * k], oracle.CPM2_LIMB_SEQ[2 * k + 1]
+            d = pts[b] - pts[a]
+            n = np.hypot(*d)
+            if n < 1e-3:
+                continue
+            u = d / n
+            for t in np.linspace(0, 1, int(2 * n) + 2):
+                cx, cy = pts[a] + t * d
+                x0, y0 = int(round(cx)), int(round(cy))
+                for yy in range(max(0, y0 - 2), min(H, y0 + 3)):
+                    for xx in range(max(0, x0 - 2), min(W, x0 + 3)):
+                        hm[oracle.CPM2_MAP_IDX[2 * k], yy, xx] = u[0]
+                        hm[oracle.CPM2_MAP_IDX[2 * k + 1], yy, xx] = u[1]
+        for j in range(18):
+            if keep[j]:
+                truth[p, j] = pts[j]
+                c = int(peaks[j, 0, 0]) + 1
+                peaks[j, c] = (np.round(pts[j, 0]), np.round(pts[j, 1]), rng.uniform(0.5, 0.95))
+                peaks[j, 0, 0] = c
+    for j in range(18):
+        for _ in range(clutter):
+            c = int(peaks[j, 0, 0]) + 1
+            if c > max_peaks:
+                break
+            peaks[j, c] = (rng.integers(0, W), rng.integers(0, H), rng.uniform(0.1, 0.4))
+            peaks[j, 0, 0] = c
+    hm += (rng.standard_normal(hm.shape) * 0.02).astype(np.float32)
+    return hm, peaks, truth
