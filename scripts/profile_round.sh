@@ -8,9 +8,10 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/round_$tag
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --no-cpu-baseline > $out/trace.log 2>&1
+# the headline region only (the CPU baseline and the extra records run other sizes / no kernels)
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --no-cpu-baseline --no-extras > $out/trace.log 2>&1
 pass() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/$name.log 2>&1
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
