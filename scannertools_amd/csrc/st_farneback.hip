@@ -543,7 +543,9 @@ __global__ __launch_bounds__(256) void k_pyr_dec(PyrDecArgs a) {
 // bit-identical to theirs.
 // ---------------------------------------------------------------------------------------------
 struct PyrFusedArgs {
-  const uint8_t* gray;          // n x (h*w)
+  const uint8_t* gray;          // n x (h*w), or
+  const uint8_t* const* frames; // RGB instance: device table of n (h,w,3) frames, converted on the fly
+  int cb, cg, cr, rnd, shift;   // luma table of the RGB instance (see launch_gray)
   float* img0; float* img1; float* img2; float* img3;  // n x (h>>k)*(w>>k)
   int h, w, rows_per_seg;       // rows_per_seg: source rows per segment, multiple of 8
   int strip_w;                  // source columns per workgroup strip
@@ -590,6 +592,30 @@ __device__ __forceinline__ unsigned pf_load4(const uint8_t* __restrict__ row, in
 
 __device__ __forceinline__ float pf_byte(unsigned d, int k) { return (float)((d >> (8 * k)) & 0xffu); }
 
+// The same four gray bytes computed from the RGB frame (k_gray4's arithmetic: OpenCV's BGR table on RGB
+// bytes), so that the gray image never goes through memory: 12 source bytes as three aligned dwords.
+// Needs 4-byte aligned frames and w % 4 == 0 (checked on the host).
+__device__ __forceinline__ unsigned pf_gray1(const uint8_t* __restrict__ px, const PyrFusedArgs& a) {
+  return (unsigned)((px[0] * a.cb + px[1] * a.cg + px[2] * a.cr + a.rnd) >> a.shift);
+}
+__device__ __forceinline__ unsigned pf_load4_rgb(const uint8_t* __restrict__ row, int col0, int w, const PyrFusedArgs& a) {
+  if (col0 >= 0 && col0 + 3 < w) {
+    const unsigned* __restrict__ q = reinterpret_cast<const unsigned*>(row + 3 * col0);
+    const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+    const unsigned g0 = ((w0 & 0xff) * a.cb + ((w0 >> 8) & 0xff) * a.cg + ((w0 >> 16) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const unsigned g1 = ((w0 >> 24) * a.cb + (w1 & 0xff) * a.cg + ((w1 >> 8) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const unsigned g2 = (((w1 >> 16) & 0xff) * a.cb + (w1 >> 24) * a.cg + (w2 & 0xff) * a.cr + a.rnd) >> a.shift;
+    const unsigned g3 = (((w2 >> 8) & 0xff) * a.cb + ((w2 >> 16) & 0xff) * a.cg + (w2 >> 24) * a.cr + a.rnd) >> a.shift;
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+  }
+  if (col0 >= w + 8 || col0 < -8) return 0u;  // never read
+  unsigned v = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) v |= pf_gray1(row + 3 * d_reflect101(col0 + k, w), a) << (8 * k);
+  return v;
+}
+
+template <bool RGB>
 __global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
   __shared__ unsigned srow[2][PF_RB][PF_ROWDW];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -598,7 +624,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
   const int X0 = blockIdx.x * SW;
   const int Y0 = blockIdx.y * a.rows_per_seg, Y1 = min(h, Y0 + a.rows_per_seg);
   const size_t np = (size_t)h * w;
-  const uint8_t* __restrict__ g = a.gray + (size_t)blockIdx.z * np;
+  const uint8_t* __restrict__ g = RGB ? a.frames[blockIdx.z] : a.gray + (size_t)blockIdx.z * np;
+  const int gw = RGB ? 3 * w : w;  // bytes per source row
   float* __restrict__ o0 = a.img0 + (size_t)blockIdx.z * np;
   float* __restrict__ o1 = a.img1 + (size_t)blockIdx.z * (np >> 2);
   float* __restrict__ o2 = a.img2 + (size_t)blockIdx.z * (np >> 4);
@@ -626,8 +653,10 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
   auto fetch = [&](int ybase) {
 #pragma unroll
     for (int r = 0; r < PF_RB; ++r)
-      pre[r] = pf_load4(g + (size_t)d_reflect101(ybase + r, h) * w, X0 + 4 * t, w);
-    if (t < 32) preh = pf_load4(g + (size_t)d_reflect101(ybase + hrow, h) * w, hcol, w);
+      pre[r] = RGB ? pf_load4_rgb(g + (size_t)d_reflect101(ybase + r, h) * gw, X0 + 4 * t, w, a)
+                   : pf_load4(g + (size_t)d_reflect101(ybase + r, h) * gw, X0 + 4 * t, w);
+    if (t < 32) preh = RGB ? pf_load4_rgb(g + (size_t)d_reflect101(ybase + hrow, h) * gw, hcol, w, a)
+                           : pf_load4(g + (size_t)d_reflect101(ybase + hrow, h) * gw, hcol, w);
   };
   auto stash = [&](int buf) {
     if (4 * t < SW) {  // threads beyond the strip would overwrite its right halo
@@ -2047,10 +2076,16 @@ bool pyr_fused_ok(int h, int w, const st_fb_params& p) {
 }
 
 // imgs[k]: n x (h>>k)*(w>>k) floats
-int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const st_fb_params& p, float* const imgs[4]) {
+// gray != null: from the gray images; else from the RGB frames of the device table `frames` (4-byte
+// aligned), the luma conversion folded into the loads
+int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* frames, int n, int h, int w,
+                     const st_fb_params& p, float* const imgs[4]) {
   PyrFusedArgs a;
   memset(&a, 0, sizeof(a));
-  a.gray = gray; a.img0 = imgs[0]; a.img1 = imgs[1]; a.img2 = imgs[2]; a.img3 = imgs[3];
+  a.gray = gray; a.frames = frames;
+  if (p.gray_bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }
+  a.shift = p.gray_bits; a.rnd = 1 << (p.gray_bits - 1);
+  a.img0 = imgs[0]; a.img1 = imgs[1]; a.img2 = imgs[2]; a.img3 = imgs[3];
   a.h = h; a.w = w;
   float* taps[4] = {a.k0, a.k1, a.k2, a.k3};
   for (int k = 0; k <= 3; ++k) {
@@ -2076,7 +2111,8 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, cons
   if (rows < min_rows) rows = h < min_rows ? h : min_rows;
   a.rows_per_seg = rows;
   st_timed t(ctx, ST_K_PYR);
-  hipLaunchKernelGGL(k_pyr_fused, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
+  if (gray) hipLaunchKernelGGL(k_pyr_fused<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_pyr_fused<true>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
@@ -2302,8 +2338,13 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   // per-frame stages: each distinct frame once
   bool aligned4 = true;
   for (int i = 0; i < nf; ++i) aligned4 = aligned4 && ((uintptr_t)frames[i] & 3) == 0;
-  ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
-  if (pyr1) ST_TRY(launch_pyr_fused(ctx, gray, nf, h, w, p, imgs));
+  // ST_PYR_FOLD_GRAY=1: the luma conversion rides on the loads of the one-pass pyramid (no gray pass, no
+  // gray image in memory).  Bit-identical, but measured SLOWER (32.5 vs 31.6 ms per 256-pair step: 12
+  // bytes per lane at a 12-byte lane stride, three loads per row instead of one, on a kernel that is
+  // already VALU-bound), so the separate k_gray4 pass stays the default.
+  const bool pyr_rgb = pyr1 && aligned4 && ctx->fold_gray;
+  if (!pyr_rgb) ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
+  if (pyr1) ST_TRY(launch_pyr_fused(ctx, pyr_rgb ? nullptr : gray, d_frames, nf, h, w, p, imgs));
   // Small batches: the flow iterations of the coarse levels are latency-bound launches of a few
   // dozen workgroups, so the polynomial expansions of the finer levels (independent of them) run
   // on a second stream meanwhile; each level's first iteration waits for its expansion.
@@ -2507,7 +2548,7 @@ ST_EXPORT int st_fb_pyr_image(st_ctx* ctx, const uint8_t* gray_dev, int h, int w
       imgs[k] = k == level ? img_dev : (float*)st_ws_alloc(ctx, sizeof(float) * (np0 >> (2 * k)));
       if (!imgs[k]) return st_set_error(ctx, ST_ERR_OOM, "pyr: scratch exhausted");
     }
-    return launch_pyr_fused(ctx, gray_dev, 1, h, w, p, imgs);
+    return launch_pyr_fused(ctx, gray_dev, nullptr, 1, h, w, p, imgs);
   }
   return launch_pyr(ctx, gray_dev, 1, h, w, g, img_dev);
 }

@@ -301,10 +301,10 @@ def test_flow_batch_equals_single(hip_ctx, h, w, n):
 
 def test_schedules_agree_bitwise(mode_ctxs):
     """Every scheduling mode (kernel choice, pairs per workgroup) gives the same bits end to end."""
-    for (h, w, n) in ((135, 240, 3), (203, 317, 4), (544, 960, 5)):
+    for (h, w, n) in ((135, 240, 3), (203, 317, 4), (544, 960, 5), (256, 1032, 2)):
         d = cu(texture_stream(h, n, h, w)[0])
         ref = mode_ctxs["march"].optical_flow(d).cpu().numpy()
-        for mode in ("default", "march2", "tile"):
+        for mode in ("default", "march2", "tile", "foldgray"):
             np.testing.assert_array_equal(mode_ctxs[mode].optical_flow(d).cpu().numpy(), ref, err_msg="%s %dx%d" % (mode, h, w))
 
 
@@ -353,6 +353,7 @@ def test_flow_1080p_batch_launch_geometry(mode_ctxs):
         _check_flow(got[i].cpu().numpy(), oracle.optical_flow_rgb(np_frames[i], np_frames[i + 1]))
     ref2 = mode_ctxs["march2"].optical_flow(d)
     assert torch.equal(got, ref2)
+    assert torch.equal(got, mode_ctxs["foldgray"].optical_flow(d))
     # an odd pair count leaves half a workgroup idle in the last group of the two-pair schedule
     odd = mode_ctxs["march2"].optical_flow(d[:4])
     assert torch.equal(odd, got[:3])
