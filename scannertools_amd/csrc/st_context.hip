@@ -58,7 +58,6 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (const char* e = getenv("ST_ITER_TILE")) c->tile_mode = atoi(e);
   if (const char* e = getenv("ST_ITER_TILE_PX")) c->tile_px = atoll(e);
   c->fold_gray = getenv("ST_PYR_FOLD_GRAY") != nullptr;
-  if (const char* e = getenv("ST_PAIRS_PER_WG")) c->pairs_per_wg = atoi(e) == 2 ? 2 : 1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   *out_ctx = c;

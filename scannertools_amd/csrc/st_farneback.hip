@@ -9,8 +9,8 @@
 //                                                       level for other geometries)
 //     FarnebackPolyExp                              ->  k_polyexp        (row-marching, LDS exchange)
 //     resize(prevFlow)*2 + FarnebackUpdateMatrices
-//       + FarnebackUpdateFlow_Blur                  ->  k_flow_iter      (one launch per iteration: M is
-//                                                       recomputed on the fly, never stored)
+//       + FarnebackUpdateFlow_Blur                  ->  k_flow_iter3 / k_flow_iter_tile (one launch per
+//                                                       iteration: M is recomputed on the fly, never stored)
 //     the same stages unfused                       ->  k_update_matrices, k_blur_update(_v2)
 //                                                       (window sizes other than 15, stage tests)
 // All kernels are batched over frames / pairs through blockIdx.z.  The operand order and the
@@ -1411,9 +1411,9 @@ __global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
   }
 }
 
-// ST_ABLATE (build-time bit mask, experiments only -- results are then meaningless): 1 no window
-// sums / solve, 2 no UpdateMatrices arithmetic, 4 no expansion loads, 8 no running column sums,
-// 16 no flow stores.  Timing a build with one part removed shows what that part costs in place.
+// ST_ABLATE (build-time bit mask, experiments only -- results are then meaningless): 4 = k_flow_iter3
+// without its expansion loads.  Timing a build with a part removed shows what that part costs in place
+// (profiles/README.md lists the round-2 ablations of the previous kernel generation).
 #ifndef ST_ABLATE
 #define ST_ABLATE 0
 #endif
@@ -1439,11 +1439,9 @@ struct IterArgs {
   float* flow_out;          // per pair (h,w,2), or
   float* const* flow_ptrs;  // device table of per-pair output frames (used when non-null)
   int h, w, ch, cw, rows_per_seg;
-  int n_pairs;              // pairs in this launch (the last workgroup of a two-pair launch may hold one)
   double scale_x, scale_y;  // coarse/fine size ratios as cv::resize computes them
   float mul;                // 1/pyr_scale
   double scale;             // 1/(block_size^2)
-  long long* prof;          // ST_PROF builds only: per-phase s_memtime stamps of a few workgroups
 };
 
 enum { FLOW_ZERO = 0, FLOW_FIELD = 1, FLOW_COARSE = 2, FLOW_ANY = 3,
@@ -1522,20 +1520,54 @@ __device__ __forceinline__ float2 flow_finish(const IterArgs& a, const float* __
   return make_float2(0.f, 0.f);
 }
 
-// Level transition with scale_y == 0.5 exactly: the RB = 3 fine rows of a batch (y0 <= y1 <= y2 <= y0+2)
-// read coarse rows s, s+1, s+2 only (s = floor((y0+0.5)/2 - 0.5)), so the batch's neighbourhood is
-// three 16-byte loads per thread instead of six, and 12 registers instead of 24 across phase 2.
-struct FlowRaw3 {
-  f4u8 row[3];
-};
+// row index of the first coarse row a fine row y0 interpolates from (level transitions)
 __device__ __forceinline__ int coarse_row0(const IterArgs& a, int y0) {
   return (int)floorf((float)((y0 + 0.5) * a.scale_y - 0.5));
 }
-__device__ __forceinline__ void coarse3_issue(const IterArgs& a, const float* __restrict__ C, const CoarseX& cx, int y0,
-                                              FlowRaw3& r) {
+
+template <int MODE = FLOW_ANY>
+__device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
+                                               const float* __restrict__ C, const CoarseX& cx, int x, int y) {
+  FlowRaw r;
+  flow_issue<MODE>(a, fin, C, cx, x, y, r);
+  return flow_finish<MODE>(a, fin, C, cx, y, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_flow_iter3: the marching iteration restructured around what the round-2 measurements showed: the
+// kernel's time follows its VALU instruction count (two waves per SIMD, ~60 % of the time issuing
+// VALU), and 63 of the 112 double-precision instructions per pixel were the horizontal window sums,
+// restarted every 3 pixels.  Here
+//   * phase 2 runs once per GROUP = 8 rows on (row, 8-pixel segment) threads: one fresh 15-term sum and
+//     seven slides per thread and channel, 36 instead of 63 double-precision instructions per pixel,
+//     and two barriers per 8 rows instead of per 3;
+//   * the ring has 16 statically indexed slots (the entering row overwrites the row that left one step
+//     earlier), so a 16-row period = two groups is unrolled and nothing is shifted, for every flow
+//     source;
+//   * phase 1 runs GROUP / RB batches of RB rows back to back between two barriers (RB = 4 for the zero
+//     / field sources, 2 for the level transitions, whose up-sampling needs the registers);
+//   * the column sums are re-anchored every 32 rows (fresh sum of the ring in row order).
+// LDS rows are stored with one pad word per 8 columns: phase 2's lanes are 8 columns apart, 9 words with
+// the padding, which keeps their reads conflict-free.
+// Canonical association (shared with k_flow_iter_tile): vertical anchors at rows 32 j, horizontal
+// anchors at columns 8 i.
+// ---------------------------------------------------------------------------------------------
+constexpr int F3_GROUP = 8, F3_SW = 8, F3_NSEG = B2_OUT / F3_SW, F3_RING = 16, F3_ANCHOR = 32;
+constexpr int F3_PADW = B2_T + B2_T / 8;
+static_assert(B2_OUT % F3_SW == 0 && F3_GROUP * F3_NSEG <= B2_T && F3_ANCHOR % F3_RING == 0 && F3_RING % F3_GROUP == 0, "bad v3 geometry");
+__device__ __forceinline__ constexpr int f3_pos(int x) { return x + (x >> 3); }
+
+// coarse rows s .. s + RB/2 + 1 cover the RB fine rows of a batch when the coarse level is exactly half as tall
+template <int RB>
+struct FlowRawN {
+  f4u8 row[RB / 2 + 2];
+};
+template <int RB>
+__device__ __forceinline__ void coarseN_issue(const IterArgs& a, const float* __restrict__ C, const CoarseX& cx, int y0,
+                                              FlowRawN<RB>& r) {
   const int s = coarse_row0(a, y0);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < RB / 2 + 2; ++j) {
     const int yy = d_clamp(s + j, 0, a.ch - 1);
     if (cx.pair) {
       r.row[j] = *reinterpret_cast<const f4u8*>(reinterpret_cast<const char*>(C) + 8u * (unsigned)(yy * a.cw + cx.sx));
@@ -1545,12 +1577,16 @@ __device__ __forceinline__ void coarse3_issue(const IterArgs& a, const float* __
     }
   }
 }
-__device__ __forceinline__ float2 coarse3_finish(const IterArgs& a, const CoarseX& cx, int y0, int y, const FlowRaw3& r) {
+template <int RB>
+__device__ __forceinline__ float2 coarseN_finish(const IterArgs& a, const CoarseX& cx, int y0, int y, const FlowRawN<RB>& r) {
   float fy = (float)((y + 0.5) * a.scale_y - 0.5);
   const int sy = (int)floorf(fy);
   fy -= sy;
-  const bool up = sy != coarse_row0(a, y0);  // sy - s is 0 or 1
-  const f4u8 pa = up ? r.row[1] : r.row[0], pb = up ? r.row[2] : r.row[1];
+  const int idx = sy - coarse_row0(a, y0);  // 0 .. RB/2
+  f4u8 pa = r.row[0], pb = r.row[1];
+#pragma unroll
+  for (int j = 1; j <= RB / 2; ++j)
+    if (idx == j) { pa = r.row[j]; pb = r.row[j + 1]; }
   const float a1 = cx.a1, a0 = cx.a0, b0 = 1.f - fy, b1 = fy;
   float2 ta, tb;
   if (cx.pair) {
@@ -1563,39 +1599,22 @@ __device__ __forceinline__ float2 coarse3_finish(const IterArgs& a, const Coarse
   return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
 }
 
-template <int MODE = FLOW_ANY>
-__device__ __forceinline__ float2 iter_flow_at(const IterArgs& a, const float* __restrict__ fin,
-                                               const float* __restrict__ C, const CoarseX& cx, int x, int y) {
-  FlowRaw r;
-  flow_issue<MODE>(a, fin, C, cx, x, y, r);
-  return flow_finish<MODE>(a, fin, C, cx, y, r);
-}
-
-// NP = pairs per workgroup.  NP == 2: a 512-thread workgroup marches pairs 2z and 2z+1 of a strip in
-// lock-step (they share both barriers of every batch).  In a stream of consecutive pairs the
-// expansion of the middle frame is R1 of the first pair and R0 of the second, so the two halves ask
-// for the same lines of it within one batch and it leaves HBM once instead of twice.
-template <int M, int RB, typename VT, int MODE, int NP, int SW>
-__global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterArgs a) {
+template <int M, int RB, int MODE>
+__global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   constexpr int W = 2 * M + 1;
-  constexpr int NSEG = B2_OUT / SW;  // phase-2 segments per row (SW pixels each)
-  static_assert(W % RB == 0 && M <= B2_HALO && B2_OUT % SW == 0 && RB * NSEG <= B2_T, "bad batch geometry");
-  __shared__ VT Vs[NP][RB][5][B2_T];
-  __shared__ float2 Fs[NP][RB][B2_T];
-  const int half = NP == 2 ? (int)(threadIdx.x >> 8) : 0;  // wave-uniform
-  const int tid = NP == 2 ? (int)(threadIdx.x & (B2_T - 1)) : (int)threadIdx.x;
-  VT(*V)[5][B2_T] = Vs[half];
-  float2(*F)[B2_T] = Fs[half];
+  static_assert(W == F3_RING - 1 && F3_GROUP % RB == 0 && M <= B2_HALO, "ring of 16 = window of 15 + the entering row");
+  __shared__ float Vs[F3_GROUP][5][F3_PADW];
+  __shared__ float2 Fs[F3_GROUP][F3_PADW];
+  const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
   const int np = h * w;
-  // the idle half of an odd launch repeats the last pair without storing (it must meet the barriers)
-  const int pr_raw = (int)blockIdx.z * NP + half;
-  const int pr = NP == 2 ? min(pr_raw, a.n_pairs - 1) : pr_raw;
+  const int pr = blockIdx.z;
   const int x = (int)blockIdx.x * B2_OUT - B2_HALO + tid;
   const int xc = d_clamp(x, 0, w - 1);
   const int y0 = blockIdx.y * a.rows_per_seg;
   const int y1 = min(h, y0 + a.rows_per_seg);
-  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w && (NP == 1 || pr_raw < a.n_pairs);
+  const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
+  const int vpos = f3_pos(tid);
 
   const float* __restrict__ R0;
   const float* __restrict__ R1;
@@ -1611,8 +1630,8 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
   const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
-  // ring slot s holds M of source row y0 - M + s (clamped) at entry; vs = window sum of row y0
-  float ring[W][5];
+  // ring slot s holds M of source row y0 - M + s (clamped), s = 0 .. 14; slot 15 takes the first entering row
+  float ring[F3_RING][5];
 #pragma unroll
   for (int s0 = 0; s0 < W; s0 += 3) {
     UmLoads Li[3];
@@ -1627,6 +1646,8 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
     for (int i = 0; i < 3; ++i) um_finish(Li[i], h, w, xc, d_clamp(y0 - M + s0 + i, 0, h - 1), f[i], ring[s0 + i]);
     __builtin_amdgcn_sched_barrier(0);  // bound the loads kept in flight
   }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) ring[F3_RING - 1][c] = 0.f;
   double vs[5];
   if (y0 == 0) {
     // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
@@ -1650,9 +1671,8 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
       for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
   }
 
-  // Software pipeline: the gathers of batch b+1 are issued at the end of phase 1 of batch b and
-  // stay in flight across both barriers and phases 2/3; the flows they need were fetched one
-  // batch earlier still.
+  // software pipeline over batches of RB rows: L holds the gathers of the batch about to be consumed, fl
+  // their flows, fn the flows of the batch after it, raw the flow loads of the batch after that
   float2 fl[RB], fn[RB];
   UmLoads L[RB];
 #pragma unroll
@@ -1662,35 +1682,20 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+  FlowRaw raw[MODE == FLOW_COARSE2 ? 1 : RB];
+  FlowRawN<RB> rawn;
+  if (MODE == FLOW_COARSE2) {
+    coarseN_issue<RB>(a, C, cx, d_clamp(y0 + 2 * RB + M + 1, 0, h - 1), rawn);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(y0 + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+  }
 
-#ifdef ST_PROF
-  int pslot = 0;
-  const bool pon = a.prof && tid == 64 && blockIdx.x == 3 && blockIdx.y == 1 && (blockIdx.z == 0 || blockIdx.z == 20);
-  long long* pbuf = a.prof + (blockIdx.z == 0 ? 0 : 4096);
-#define PSTAMP() do { __builtin_amdgcn_sched_barrier(0); if (pon && pslot < 4000) pbuf[pslot++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PSTAMP() do {} while (0)
-#endif
-  // One ring period (W rows = W/RB batches) per trip of the outer loop, the batches inside it
-  // unrolled: batch bb replaces ring slots RB*bb .. RB*bb+RB-1, all indices are compile-time
-  // constants and the ring never moves (shifting it cost 60 register moves per batch).  The body
-  // is ~10 KB per batch since the flow source is a template parameter, so the five copies fit the
-  // 64 KB instruction cache (the first unrolled version, 100 KB, did not).
-  // (The level-transition instance keeps the rolled, shifting form: unrolled it spills.)
-  constexpr bool UNR = MODE != FLOW_COARSE && MODE != FLOW_COARSE2;
-  constexpr int NB = UNR ? W / RB : 1;
-  int since_anchor = 0;  // batches since the last anchor row (rolled form)
 #pragma unroll 1
-  for (int ybase = y0; ybase < y1; ybase += NB * RB) {
-    // Anchor rows: at every row y = 15 j > 0 the column sums restart from the fresh sum of the 15
-    // ring rows y-7 .. y+7, added in row order (the slots are in row order at a period boundary).
-    // The sums of a row therefore depend on the frame pair alone, not on where the launch cut the
-    // frame into segments (segments start at multiples of 15) nor on how many pairs share the launch;
-    // k_flow_iter_tile forms the same sums in the same order.  The reference carries one running sum
-    // down the whole frame; re-anchoring bounds the drift of the float-rounded row differences to 14
-    // rows, so this is also the closer of the two to the exact window sum.
-    if (UNR ? ybase > y0 : since_anchor == W / RB) {
-      since_anchor = 0;
+  for (int ybase = y0; ybase < y1; ybase += F3_RING) {
+    // anchor rows 32 j > 0: the column sums restart from the fresh sum of the 15 window rows in row order
+    // (at the top of a 16-row period slot s holds row ybase - 7 + s)
+    if (ybase > y0 && (ybase - y0) % F3_ANCHOR == 0) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) vs[c] = 0;
 #pragma unroll
@@ -1700,41 +1705,34 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
         __builtin_amdgcn_sched_barrier(0);  // one row's conversions live at a time
       }
     }
-    ++since_anchor;
 #pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-      const int ybb = ybase + bb * RB;
-      if (ybb >= y1) break;  // uniform over the workgroup
-      {
-        PSTAMP();
-        // ---- phase 3 of the PREVIOUS batch first: its flow rows go out ahead of this batch's
-        // loads, so that the stores do not queue behind them in the memory pipeline ----
-        if (writer && ybb > y0 && !(ST_ABLATE & 16)) {
+    for (int g = 0; g < F3_RING / F3_GROUP; ++g) {
+      const int yg = ybase + g * F3_GROUP;
+      if (yg >= y1) break;  // uniform over the workgroup
+      // ---- flow rows of the PREVIOUS group go out ahead of this group's loads
+      if (writer && yg > y0) {
 #pragma unroll
-          for (int r = 0; r < RB; ++r)
-            *reinterpret_cast<float2*>(fout + 2 * (size_t)((ybb - RB + r) * w + x)) = F[r][tid];
-        }
-        // ---- phase 1: per entering row, finish its UpdateMatrices (loads issued one batch ago),
-        // slide the column sums, and immediately re-issue that row's register set for the next batch ----
+        for (int r = 0; r < F3_GROUP; ++r)
+          *reinterpret_cast<float2*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)) = Fs[r][vpos];
+      }
+      // ---- phase 1: GROUP / RB batches back to back
+      // phase 1 carries the loads: a wave in it goes ahead of the co-resident wave's phase-2 arithmetic, so
+      // that the gathers are in flight as early as possible (measured: -3 % on the launch)
+      __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int bb = 0; bb < F3_GROUP / RB; ++bb) {
+        const int ybb = yg + bb * RB;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
+          const int t = g * F3_GROUP + bb * RB + r;  // row of the 16-row period: compile-time constant
           float m[5];
-          if (ST_ABLATE & 2) {  // ablation: loads consumed, no UpdateMatrices arithmetic
-            m[0] = L[r].q.x + L[r].t0.x; m[1] = L[r].q.y + L[r].t1.y; m[2] = L[r].b0.z + L[r].qs;
-            m[3] = L[r].b1.w + L[r].ts.x; m[4] = L[r].bs.y + fl[r].x;
-          } else {
-            um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
-          }
+          um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
-            if (ST_ABLATE & 8) {  // ablation: no running column sums
-              V[r][c][tid] = (VT)(m[c] + ring[bb * RB + r][c]);
-            } else {
-              V[r][c][tid] = (VT)vs[c];
-              const float d = m[c] - ring[bb * RB + r][c];
-              vs[c] += d;
-            }
-            ring[bb * RB + r][c] = m[c];  // rolled form: parked in the slot it frees, rotated below
+            Vs[bb * RB + r][c][vpos] = (float)vs[c];
+            const float d = m[c] - ring[t % F3_RING][c];
+            vs[c] += d;
+            ring[(t + W) % F3_RING][c] = m[c];
           }
           fl[r] = fn[r];
           if (ST_ABLATE & 4) {  // ablation: no expansion loads
@@ -1744,114 +1742,92 @@ __global__ __launch_bounds__(B2_T * NP, NP == 2 ? 1 : 2) void k_flow_iter(IterAr
             um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
           }
         }
-        if (!UNR) {
-          float tmp[RB][5];
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) tmp[r][c] = ring[r][c];
-#pragma unroll
-          for (int j = 0; j + RB < W; ++j)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) ring[j][c] = ring[j + RB][c];
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) ring[W - RB + r][c] = tmp[r][c];
-        }
-        // flows of the batch after next: requested here, turned into vectors after phase 2 (the
-        // up-sampling arithmetic of the level transition must not wait on loads issued just now)
-        FlowRaw raw[MODE == FLOW_COARSE2 ? 1 : RB];
-        FlowRaw3 raw3;
+        // flows: the loads requested one batch ago (rows of batch b+2) become vectors now, and the rows of
+        // batch b+3 are requested -- never a wait on loads issued in the same batch
         if (MODE == FLOW_COARSE2) {
-          coarse3_issue(a, C, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), raw3);
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            fn[r] = coarseN_finish<RB>(a, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), rawn);
+          coarseN_issue<RB>(a, C, cx, d_clamp(ybb + 3 * RB + M + 1, 0, h - 1), rawn);
         } else {
 #pragma unroll
-          for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+          for (int r = 0; r < RB; ++r) fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+#pragma unroll
+          for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 3 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
         }
-        PSTAMP();
-        __syncthreads();
-        PSTAMP();
-        // ---- phase 2: horizontal window + solve ----
-        if (tid < RB * NSEG) {
-          const int r = tid / NSEG, sg = tid - r * NSEG;
-          const int j0 = B2_HALO + sg * SW;
-          if (ST_ABLATE & 1) {  // ablation: no window sums, no solve
-#pragma unroll
-            for (int i = 0; i < SW; ++i) F[r][j0 + i] = make_float2((float)V[r][3][j0 + i], (float)V[r][4][j0 + i]);
-          } else {
-          double t[5];
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            const VT* vp = &V[r][c][j0 - M];
-            double acc = vp[0];
-#pragma unroll
-            for (int i = 1; i < W; ++i) acc += (double)vp[i];
-            t[c] = acc;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int i = 0; i < SW; ++i) {
-            if (i > 0) {
-#pragma unroll
-              for (int c = 0; c < 5; ++c) {
-                t[c] += (double)V[r][c][j0 + i + M] - (double)V[r][c][j0 + i - M - 1];
-              }
-            }
-            const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
-            const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
-            const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
-            F[r][j0 + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          if (MODE == FLOW_COARSE2)
-            fn[r] = coarse3_finish(a, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw3);
-          else
-            fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
-        }
-        PSTAMP();
-        __syncthreads();
-        PSTAMP();
       }
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+      // ---- phase 2: horizontal window sums + solve; thread = (row of the group, 8-pixel segment)
+      if (tid < F3_GROUP * F3_NSEG) {
+        const int r = tid / F3_NSEG, sg = tid - r * F3_NSEG;
+        const int j0 = B2_HALO + sg * F3_SW;          // first column of the segment (multiple of 8)
+        const float* __restrict__ vrow = &Vs[r][0][j0 + (j0 >> 3)];  // f3_pos(j0 + k) = f3_pos(j0) + k + ((k + 0) >> 3) for k >= 0
+        double t[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const float* vp = vrow + c * F3_PADW;
+          // columns j0 - 7 .. j0 + 7: padded offsets -8 .. -2 (columns j0-7 .. j0-1), 0 .. 7
+          double acc = vp[-8];
+#pragma unroll
+          for (int k = -6; k <= 7; ++k) acc += (double)vp[k < 0 ? k - 1 : k];
+          t[c] = acc;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < F3_SW; ++i) {
+          if (i > 0) {
+            // entering column j0 + i + 7 (8 .. 14 past j0: padded +1), leaving column j0 + i - 8
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+              const float* vp = vrow + c * F3_PADW;
+              const int ke = i + 7, kl = i - 8;  // relative to j0
+              t[c] += (double)vp[ke >= 8 ? ke + 1 : ke] - (double)vp[kl < 0 ? (kl < -8 ? kl - 2 : kl - 1) : kl];
+            }
+          }
+          const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
+          const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
+          const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
+          Fs[r][j0 + (j0 >> 3) + i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
     }
   }
-  // flow of the last batch
+  // flow of the last group
   if (writer) {
-    const int ylast = y0 + ((y1 - y0 - 1) / RB) * RB;
+    const int ylast = y0 + ((y1 - y0 - 1) / F3_GROUP) * F3_GROUP;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = 0; r < F3_GROUP; ++r) {
       const int y = ylast + r;
-      if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = F[r][tid];
+      if (y < y1) *reinterpret_cast<float2*>(fout + 2 * (size_t)(y * w + x)) = Fs[r][vpos];
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_flow_iter_tile: the same iteration for launches too small to fill the chip by marching
-// (few pairs, coarse pyramid levels).  A workgroup produces one 30 x 30 tile: UpdateMatrices on
+// (few pairs, coarse pyramid levels).  A workgroup produces one 32 x 32 tile: UpdateMatrices on
 // the tile plus its 7-pixel apron (replicated at the frame border, as the box filter's
 // BORDER_REPLICATE requires) into LDS, then the window sums in EXACTLY the association of
-// k_flow_iter -- vertically: anchored at rows 15 j (fresh sum of the 15 rows in row order; the
+// k_flow_iter3 -- vertically: anchored at rows 32 j (fresh sum of the 15 rows in row order; the
 // reference's initialisation order at row 0), float-rounded row differences added in double in
-// between, handed over as float; horizontally: fresh 15-term sum in double at columns 3 i, two
-// slides after it -- and the same solve.  Tiles start at multiples of 30 in both directions, so
-// the anchors fall on tile rows 0 and 15 and on every third tile column, and the two kernels agree
-// bit for bit: which of them a launch takes is a scheduling matter only.
-// 2.15x redundant UpdateMatrices work, but thousands of short independent workgroups instead of a
+// between, handed over as float; horizontally: fresh 15-term sum in double at columns 8 i, seven
+// slides after it -- and the same solve.  Tiles start at multiples of 32 in both directions, so
+// the anchors fall on the tile's first row and on every eighth tile column, and the two kernels
+// agree bit for bit: which of them a launch takes is a scheduling matter only.
+// 2.1x redundant UpdateMatrices work, but thousands of short independent workgroups instead of a
 // few dozen long ones: a level-3 launch drops from ~25 us to ~10 us.
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_T = 30, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
-static_assert(FT_T % (2 * FT_M + 1) == 0 && FT_T % 3 == 0 && B2_OUT % 3 == 0, "tile anchors must coincide with k_flow_iter's");
+constexpr int FT_T = 32, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
+static_assert(FT_T == F3_ANCHOR && FT_T % F3_SW == 0 && B2_OUT % F3_SW == 0, "tile anchors must coincide with k_flow_iter3's");
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
   constexpr int W = 2 * FT_M + 1;
-  __shared__ float Mt[5][FT_S][FT_S];  // 38.7 + 26.4 KB: just inside the 64 KB of static LDS; the access
-  __shared__ float Vt[5][FT_T][FT_S];  // patterns below are conflict-free without padding (lane strides 1 and 3)
+  __shared__ float Mt[5][FT_S][FT_S];
+  __shared__ float Vt[5][FT_T][FT_S];
   const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
   const int np = h * w;
@@ -1882,15 +1858,11 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
     for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
   }
   __syncthreads();
-  // ---- phase 2: column sums of the two 15-row periods of the tile; item = (channel, period, column)
-  for (int i = tid; i < 5 * 2 * FT_S; i += 256) {
-    const int c = i / (2 * FT_S), rem = i - c * (2 * FT_S);
-    const int p = rem / FT_S, col = rem - p * FT_S;
-    const int ya = Y0 + W * p;  // anchor row
-    if (ya >= h) continue;
-    const int la = W * p;       // Mt row of source row ya - 7
+  // ---- phase 2: column sums of the tile's 32 rows from the anchor at its first row; item = (channel, column)
+  for (int i = tid; i < 5 * FT_S; i += 256) {
+    const int c = i / FT_S, col = i - c * FT_S;
     double vs;
-    if (ya == 0) {
+    if (Y0 == 0) {
       // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
       vs = (double)(Mt[c][FT_M][col] * (float)(FT_M + 2));
 #pragma unroll
@@ -1900,24 +1872,24 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
     } else {
       vs = 0;
 #pragma unroll
-      for (int s2 = 0; s2 < W; ++s2) vs += (double)Mt[c][la + s2][col];
+      for (int s2 = 0; s2 < W; ++s2) vs += (double)Mt[c][s2][col];
     }
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      Vt[c][la + j][col] = (float)vs;
-      if (j + 1 < W) {
-        const float d = Mt[c][la + j + W][col] - Mt[c][la + j][col];
+#pragma unroll 4
+    for (int j = 0; j < FT_T; ++j) {
+      Vt[c][j][col] = (float)vs;
+      if (j + 1 < FT_T) {
+        const float d = Mt[c][j + W][col] - Mt[c][j][col];
         vs += d;
       }
     }
   }
   __syncthreads();
-  // ---- phase 3: row sums + solve; item = (row, 3-pixel group), groups start at x = 3 i
-  for (int i = tid; i < FT_T * (FT_T / 3); i += 256) {
-    const int r = i / (FT_T / 3), g = i - r * (FT_T / 3);
+  // ---- phase 3: row sums + solve; item = (row, 8-pixel group), groups start at x = 8 i
+  for (int i = tid; i < FT_T * (FT_T / F3_SW); i += 256) {
+    const int r = i / (FT_T / F3_SW), g = i - r * (FT_T / F3_SW);
     const int y = Y0 + r;
     if (y >= h) continue;
-    const int j0 = FT_M + 3 * g;  // Vt column of the group's first pixel
+    const int j0 = FT_M + F3_SW * g;  // Vt column of the group's first pixel
     double t[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -1928,7 +1900,7 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
       t[c] = acc;
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < F3_SW; ++k) {
       if (k > 0) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) t[c] += (double)Vt[c][r][j0 + k + FT_M] - (double)Vt[c][r][j0 + k - FT_M - 1];
@@ -1936,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
       const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
       const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
       const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
-      const int x = X0 + 3 * g + k;
+      const int x = X0 + F3_SW * g + k;
       if (x < w)
         *reinterpret_cast<float2*>(fout + 2 * ((size_t)y * w + x)) =
             make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
@@ -2172,11 +2144,10 @@ int launch_blur(st_ctx* ctx, BlurArgs a, int n_pairs) {
 int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   // Launches whose marching form would be a handful of short segments take the tile kernel: by
   // default when the launch covers <= 600 k pixels in total (one 1080p pair: levels 1-3).  Both
-  // kernels form the window sums in the same association (anchored every 15 rows / 3 columns), so
+  // kernels form the window sums in the same association (anchored every 32 rows / 8 columns), so
   // the choice, like the segment height below, changes the schedule and not one bit of the result:
   // a pair's flow does not depend on how many pairs share the call.  ST_ITER_TILE=0 / 1 (read at
   // st_ctx_create) force the marching / the tile kernel (A/B runs, parity tests of each kernel).
-  a.n_pairs = n_pairs;
   const bool tile = ctx->tile_mode == 1 || (ctx->tile_mode != 0 && (long long)n_pairs * a.h * a.w <= ctx->tile_px);
   if (tile && (a.h + FT_T - 1) / FT_T <= 65535) {
     dim3 grid((a.w + FT_T - 1) / FT_T, (a.h + FT_T - 1) / FT_T, n_pairs);
@@ -2188,74 +2159,34 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     return ST_OK;
   }
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
-  // ST_PAIRS_PER_WG=2: two pairs per workgroup (512 threads, one workgroup per CU); default one pair
-  // per 256-thread workgroup (faster as measured -- see st_internal.h).
-  const int npw = (ctx->pairs_per_wg == 2 && n_pairs >= 2) ? 2 : 1;
-  const int groups = (n_pairs + npw - 1) / npw;
-  // Segment height = whole ring periods (15 rows).  Eight waves are resident per CU at this
-  // register budget (two 256-thread or one 512-thread workgroup), so a launch runs in rounds of
-  // resident workgroups that each cost their rows plus the 15 rows of ring initialisation: pick
-  // the segment count that minimises rounds x (rows + 15) -- one round of tall segments when the
-  // batch is large (256 pairs x 8 strips = exactly four rounds), more, shorter segments when that
-  // fills a partial round.
-  const long long resident = (long long)ctx->num_cus * (2 / npw);
-  const int periods = (a.h + 14) / 15;
-  int rows = periods * 15;
+  // Segment height = whole anchor periods (32 rows).  Two workgroups are resident per CU (register and
+  // LDS budget), so a launch runs in rounds of resident workgroups that each cost their rows plus
+  // the 15 rows of ring initialisation: pick the segment count that minimises rounds x (rows + 15)
+  // -- one round of tall segments when the batch is large (256 pairs x 8 strips = exactly four
+  // rounds), more, shorter segments when that fills a partial round.
+  const long long resident = (long long)ctx->num_cus * 2;
+  const int periods = (a.h + F3_ANCHOR - 1) / F3_ANCHOR;
+  int rows = periods * F3_ANCHOR;
   double best = 1e300;
   for (int segs = 1; segs <= periods; ++segs) {
-    const int r = (periods + segs - 1) / segs * 15;
+    const int r = (periods + segs - 1) / segs * F3_ANCHOR;
     const long long nseg = (a.h + r - 1) / r;
-    const long long wgs = (long long)strips * groups * nseg;
+    const long long wgs = (long long)strips * n_pairs * nseg;
     const long long rounds = (wgs + resident - 1) / resident;
     const double cost = (double)rounds * (r + 15);
     if (cost < best * 0.999) { best = cost; rows = r; }
   }
   static const int force_rows = getenv("ST_ITER_ROWS") ? atoi(getenv("ST_ITER_ROWS")) : 0;  // experiments
-  if (force_rows >= 15 && force_rows % 15 == 0 && force_rows < rows) rows = force_rows;
+  if (force_rows >= F3_ANCHOR && force_rows % F3_ANCHOR == 0 && force_rows < rows) rows = force_rows;
   a.rows_per_seg = rows;
-  dim3 grid(strips, (a.h + rows - 1) / rows, groups);
+  dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
-#ifdef ST_PROF
-  static long long* prof_buf = nullptr;
-  if (!prof_buf) { (void)hipMalloc((void**)&prof_buf, 8192 * sizeof(long long)); }
-  (void)hipMemsetAsync(prof_buf, 0, 8192 * sizeof(long long), ctx->stream);
-  a.prof = (a.h >= 1000) ? prof_buf : nullptr;
-#endif
   const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-#define ST_LAUNCH_ITER(MODE_, NP_, VT_, SW_) \
-  hipLaunchKernelGGL((k_flow_iter<7, 3, VT_, MODE_, NP_, SW_>), grid, dim3(B2_T * NP_), 0, ctx->stream, a)
-#define ST_LAUNCH_MODES(NP_, VT_, SW_)                                      \
-  do {                                                                      \
-    if (mode == FLOW_COARSE2) ST_LAUNCH_ITER(FLOW_COARSE2, NP_, VT_, SW_);   \
-    else if (mode == FLOW_COARSE) ST_LAUNCH_ITER(FLOW_COARSE, NP_, VT_, SW_); \
-    else if (mode == FLOW_FIELD) ST_LAUNCH_ITER(FLOW_FIELD, NP_, VT_, SW_);  \
-    else ST_LAUNCH_ITER(FLOW_ZERO, NP_, VT_, SW_);                           \
-  } while (0)
-  if (npw == 2) ST_LAUNCH_MODES(2, float, 3);
-  else ST_LAUNCH_MODES(1, float, 3);
-#undef ST_LAUNCH_MODES
-#undef ST_LAUNCH_ITER
+  if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE2>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
-#ifdef ST_PROF
-  if (a.prof && getenv("ST_PROF_DUMP")) {
-    static int dumped = 0;
-    if (dumped++ == 8) {  // one warm level-0 launch
-      std::vector<long long> hbuf(8192);
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipMemcpy(hbuf.data(), prof_buf, 8192 * sizeof(long long), hipMemcpyDeviceToHost);
-      for (int wgi = 0; wgi < 2; ++wgi) {
-        long long* q = hbuf.data() + wgi * 4096;
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        int nb = 0;
-        for (int i = 0; i + 6 < 4000 && q[i + 6]; i += 6, ++nb)
-          for (int j = 0; j < 6; ++j) acc[j] += (double)(q[i + j + 1] - q[i + j]);
-        fprintf(stderr, "[prof wg%d] batches %d  cycles between the 6 stamps of a batch: %.0f %.0f %.0f %.0f %.0f %.0f  total %.0f\n",
-                wgi, nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb,
-                (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / nb);
-      }
-    }
-  }
-#endif
   return ST_OK;
 }
 

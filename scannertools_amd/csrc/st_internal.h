@@ -30,10 +30,6 @@ struct st_ctx {
   // bit, so this is a scheduling switch only.
   int tile_mode = -1;
   long long tile_px = 600000;
-  // pairs marched per workgroup by k_flow_iter (ST_PAIRS_PER_WG: 1 or 2).  Two pairs in lock-step
-  // share the middle frame's expansion on chip, but the 8-wave barriers cost more than the saved
-  // traffic returns (measured: 2.24 vs 2.01 ms per launch at 256 pairs of 1080p), so 1 is the default.
-  int pairs_per_wg = 1;
   bool fold_gray = false;  // ST_PYR_FOLD_GRAY=1: luma conversion inside the one-pass pyramid (slower; A/B switch)
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_events[8] = {};

@@ -36,11 +36,10 @@ def hip_ctx():
     ctx.close()
 
 
-# k_flow_iter scheduling modes (ST_ITER_TILE / ST_PAIRS_PER_WG are read when a context is created):
-#   default  kernel by launch size, one pair per workgroup      march    marching kernel everywhere, one pair
-#   tile     tile kernel everywhere                             march2   marching kernel, two pairs per workgroup
+# flow-iteration scheduling modes (the environment is read when a context is created):
+#   default  kernel by launch size       march  marching kernel (k_flow_iter3) everywhere
+#   tile     tile kernel everywhere
 FLOW_MODES = {"default": {}, "march": {"ST_ITER_TILE": "0"}, "tile": {"ST_ITER_TILE": "1"},
-              "march2": {"ST_ITER_TILE": "0", "ST_PAIRS_PER_WG": "2"},
               # the luma conversion folded into the one-pass pyramid instead of the separate gray pass
               "foldgray": {"ST_PYR_FOLD_GRAY": "1"}}
 
@@ -49,7 +48,7 @@ def make_mode_ctx(mode, **kw):
     """A HipContext created under the environment of one scheduling mode."""
     from scannertools_amd.hip import HipContext
     env = FLOW_MODES[mode]
-    keys = ("ST_ITER_TILE", "ST_PAIRS_PER_WG", "ST_PYR_FOLD_GRAY")
+    keys = ("ST_ITER_TILE", "ST_PYR_FOLD_GRAY")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:

@@ -3,18 +3,18 @@
 Stage tests compare each kernel with the oracle's restatement of the same OpenCV routine on
 identical inputs.  The library is built with -ffp-contract=off and follows the scalar operand
 order, so every stage whose arithmetic is per-pixel (gray, pyramid, polynomial expansion,
-UpdateMatrices) must be BIT-EXACT.  The box filter re-anchors its running double sums every 15
-rows / 3 columns (the reference accumulates float-rounded differences from the top / left of the
+UpdateMatrices) must be BIT-EXACT.  The box filter re-anchors its running double sums every 32
+rows / 8 columns (the reference accumulates float-rounded differences from the top / left of the
 image), so blur-dependent outputs are compared within a tolerance:
   stage   UpdateFlow_Blur : |d flow| <= 1e-4 px, |d M'| <= 1e-4 * max|M'|
   end-to-end flow         : relative L2 <= 1e-4 and max-abs <= 5e-3 px on textured pairs
 (north-star bound: relative L2 <= 1e-3, max-abs <= 1e-2 px).
 
-The flow iteration has two kernels (marching k_flow_iter with one or two pairs per workgroup, and
-k_flow_iter_tile) and a launch-size rule that picks between them; the ``flow_ctx`` fixture runs a
-test under every scheduling mode (conftest.FLOW_MODES), so each kernel instance -- zero / field /
-coarse / half-height coarse flow source x one / two pairs per workgroup x tile -- is compared with
-the oracle, and ``test_schedules_agree_bitwise`` checks that the modes agree to the last bit.
+The flow iteration has two kernels (marching k_flow_iter3 and k_flow_iter_tile) and a launch-size
+rule that picks between them; the ``flow_ctx`` fixture runs a test under every scheduling mode
+(conftest.FLOW_MODES), so each kernel instance -- zero / field / coarse / half-height coarse flow
+source, marching and tile -- is compared with the oracle, and ``test_schedules_agree_bitwise``
+checks that the modes agree to the last bit.
 """
 import numpy as np
 import pytest
@@ -215,7 +215,7 @@ def _iteration_cases(h, w):
 @pytest.mark.parametrize("h,w", ITER_SIZES)
 def test_flow_iteration_parity(mode_ctxs, h, w):
     """One fused iteration == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources,
-    under the marching kernel (k_flow_iter) and the tile kernel (k_flow_iter_tile) alike; and the two
+    under the marching kernel (k_flow_iter3) and the tile kernel (k_flow_iter_tile) alike; and the two
     kernels agree bit for bit."""
     R0, R1, cases = _iteration_cases(h, w)
     r0, r1 = cu(R0), cu(R1)
@@ -304,7 +304,7 @@ def test_schedules_agree_bitwise(mode_ctxs):
     for (h, w, n) in ((135, 240, 3), (203, 317, 4), (544, 960, 5), (256, 1032, 2)):
         d = cu(texture_stream(h, n, h, w)[0])
         ref = mode_ctxs["march"].optical_flow(d).cpu().numpy()
-        for mode in ("default", "march2", "tile", "foldgray"):
+        for mode in ("default", "tile", "foldgray"):
             np.testing.assert_array_equal(mode_ctxs[mode].optical_flow(d).cpu().numpy(), ref, err_msg="%s %dx%d" % (mode, h, w))
 
 
@@ -342,21 +342,17 @@ def _torch_stream(n, h, w, seed, step=2):
 
 def test_flow_1080p_batch_launch_geometry(mode_ctxs):
     """24 pairs of 1080p in one call: every pyramid level takes the marching kernel (all four flow
-    sources of k_flow_iter, multi-round segment geometry as in the 256-pair benchmark call); a
-    sample of the pairs against the oracle, all of them against the two-pairs-per-workgroup
-    schedule."""
+    sources of k_flow_iter3, multi-round segment geometry as in the 256-pair benchmark call); a
+    sample of the pairs against the oracle, all of them against the schedule that folds the luma
+    conversion into the pyramid, and a sub-batch against the full batch."""
     h, w, n = 1080, 1920, 25
     d = _torch_stream(n, h, w, 9)
     got = mode_ctxs["default"].optical_flow(d)
     np_frames = d.cpu().numpy()
     for i in (0, 7, 16, 23):
         _check_flow(got[i].cpu().numpy(), oracle.optical_flow_rgb(np_frames[i], np_frames[i + 1]))
-    ref2 = mode_ctxs["march2"].optical_flow(d)
-    assert torch.equal(got, ref2)
     assert torch.equal(got, mode_ctxs["foldgray"].optical_flow(d))
-    # an odd pair count leaves half a workgroup idle in the last group of the two-pair schedule
-    odd = mode_ctxs["march2"].optical_flow(d[:4])
-    assert torch.equal(odd, got[:3])
+    assert torch.equal(mode_ctxs["default"].optical_flow(d[:4]), got[:3])
 
 
 @pytest.mark.parametrize("h,w", [(1, 1), (1, 40), (40, 1), (2, 2), (3, 5), (31, 33)])
