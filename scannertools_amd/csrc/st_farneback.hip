@@ -1599,9 +1599,10 @@ __device__ __forceinline__ float2 coarseN_finish(const IterArgs& a, const Coarse
   return make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
 }
 
-template <int M, int RB, int MODE>
+template <int M, int RB, int MODE, int D>
 __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   constexpr int W = 2 * M + 1;
+  static_assert((F3_RING / RB) % D == 0, "the gather queue must rotate a whole number of times per ring period");
   static_assert(W == F3_RING - 1 && F3_GROUP % RB == 0 && M <= B2_HALO, "ring of 16 = window of 15 + the entering row");
   __shared__ float Vs[F3_GROUP][5][F3_PADW];
   __shared__ float2 Fs[F3_GROUP][F3_PADW];
@@ -1671,24 +1672,28 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
       for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s][c];
   }
 
-  // software pipeline over batches of RB rows: L holds the gathers of the batch about to be consumed, fl
-  // their flows, fn the flows of the batch after it, raw the flow loads of the batch after that
-  float2 fl[RB], fn[RB];
-  UmLoads L[RB];
+  // software pipeline over batches of RB rows: L is a queue of D batches of gathers in flight (fcur their
+  // flows), fnext the flows of the batch that enters the queue next, raw the flow loads of the batch after it.
+  // (D = 2 -- four rows of gathers in flight -- would hide more of the load latency, which is a third of
+  // this kernel's time, but does not fit: 133 spilled registers for the field source.  D = 1 everywhere.)
+  float2 fcur[D][RB], fnext[RB];
+  UmLoads L[D][RB];
 #pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    fl[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + r + M + 1, 0, h - 1));
-    um_issue(R0, R1, np, h, w, xc, d_clamp(y0 + r + M + 1, 0, h - 1), fl[r], L[r]);
-  }
+  for (int d = 0; d < D; ++d)
 #pragma unroll
-  for (int r = 0; r < RB; ++r) fn[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + RB + r + M + 1, 0, h - 1));
+    for (int r = 0; r < RB; ++r) {
+      fcur[d][r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + d * RB + r + M + 1, 0, h - 1));
+      um_issue(R0, R1, np, h, w, xc, d_clamp(y0 + d * RB + r + M + 1, 0, h - 1), fcur[d][r], L[d][r]);
+    }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) fnext[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, d_clamp(y0 + D * RB + r + M + 1, 0, h - 1));
   FlowRaw raw[MODE == FLOW_COARSE2 ? 1 : RB];
   FlowRawN<RB> rawn;
   if (MODE == FLOW_COARSE2) {
-    coarseN_issue<RB>(a, C, cx, d_clamp(y0 + 2 * RB + M + 1, 0, h - 1), rawn);
+    coarseN_issue<RB>(a, C, cx, d_clamp(y0 + (D + 1) * RB + M + 1, 0, h - 1), rawn);
   } else {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(y0 + 2 * RB + r + M + 1, 0, h - 1), raw[r]);
+    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(y0 + (D + 1) * RB + r + M + 1, 0, h - 1), raw[r]);
   }
 
 #pragma unroll 1
@@ -1722,11 +1727,12 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
 #pragma unroll
       for (int bb = 0; bb < F3_GROUP / RB; ++bb) {
         const int ybb = yg + bb * RB;
+        const int q = (g * (F3_GROUP / RB) + bb) % D;  // queue slot of this batch: compile-time constant
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int t = g * F3_GROUP + bb * RB + r;  // row of the 16-row period: compile-time constant
           float m[5];
-          um_finish(L[r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fl[r], m);
+          um_finish(L[q][r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fcur[q][r], m);
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             Vs[bb * RB + r][c][vpos] = (float)vs[c];
@@ -1734,26 +1740,27 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
             vs[c] += d;
             ring[(t + W) % F3_RING][c] = m[c];
           }
-          fl[r] = fn[r];
+          fcur[q][r] = fnext[r];
           if (ST_ABLATE & 4) {  // ablation: no expansion loads
-            L[r].q = make_float4(fl[r].x, fl[r].y, m[0], m[1]); L[r].qs = m[2];
-            L[r].t0 = L[r].t1 = L[r].b0 = L[r].b1 = L[r].q; L[r].ts.x = L[r].ts.y = L[r].bs.x = L[r].bs.y = m[3];
+            L[q][r].q = make_float4(fnext[r].x, fnext[r].y, m[0], m[1]); L[q][r].qs = m[2];
+            L[q][r].t0 = L[q][r].t1 = L[q][r].b0 = L[q][r].b1 = L[q][r].q;
+            L[q][r].ts.x = L[q][r].ts.y = L[q][r].bs.x = L[q][r].bs.y = m[3];
           } else {
-            um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + RB + r + M + 1, 0, h - 1), fl[r], L[r]);
+            um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + D * RB + r + M + 1, 0, h - 1), fcur[q][r], L[q][r]);
           }
         }
-        // flows: the loads requested one batch ago (rows of batch b+2) become vectors now, and the rows of
-        // batch b+3 are requested -- never a wait on loads issued in the same batch
+        // flows: the loads requested one batch ago become vectors now and the next rows are requested --
+        // never a wait on loads issued in the same batch
         if (MODE == FLOW_COARSE2) {
 #pragma unroll
           for (int r = 0; r < RB; ++r)
-            fn[r] = coarseN_finish<RB>(a, cx, d_clamp(ybb + 2 * RB + M + 1, 0, h - 1), d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), rawn);
-          coarseN_issue<RB>(a, C, cx, d_clamp(ybb + 3 * RB + M + 1, 0, h - 1), rawn);
+            fnext[r] = coarseN_finish<RB>(a, cx, d_clamp(ybb + (D + 1) * RB + M + 1, 0, h - 1), d_clamp(ybb + (D + 1) * RB + r + M + 1, 0, h - 1), rawn);
+          coarseN_issue<RB>(a, C, cx, d_clamp(ybb + (D + 2) * RB + M + 1, 0, h - 1), rawn);
         } else {
 #pragma unroll
-          for (int r = 0; r < RB; ++r) fn[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + 2 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+          for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, d_clamp(ybb + (D + 1) * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
 #pragma unroll
-          for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + 3 * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+          for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, d_clamp(ybb + (D + 2) * RB + r + M + 1, 0, h - 1), raw[MODE == FLOW_COARSE2 ? 0 : r]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -2182,10 +2189,10 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
   const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-  if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE2>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_FIELD>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_ZERO>), grid, dim3(B2_T), 0, ctx->stream, a);
+  if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE2, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_FIELD, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_ZERO, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
