@@ -1601,6 +1601,7 @@ __device__ __forceinline__ float2 coarseN_finish(const IterArgs& a, const Coarse
 
 template <int M, int RB, int MODE, int D>
 __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
   constexpr int W = 2 * M + 1;
   static_assert((F3_RING / RB) % D == 0, "the gather queue must rotate a whole number of times per ring period");
   static_assert(W == F3_RING - 1 && F3_GROUP % RB == 0 && M <= B2_HALO, "ring of 16 = window of 15 + the entering row");
@@ -1717,8 +1718,13 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
       // ---- flow rows of the PREVIOUS group go out ahead of this group's loads
       if (writer && yg > y0) {
 #pragma unroll
-        for (int r = 0; r < F3_GROUP; ++r)
-          *reinterpret_cast<float2*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)) = Fs[r][vpos];
+        for (int r = 0; r < F3_GROUP; ++r) {
+          // non-temporal: the next reader is another launch, tens of gigabytes later
+          const float2 fv = Fs[r][vpos];
+          f2v v2;
+          v2.x = fv.x; v2.y = fv.y;
+          __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)));
+        }
       }
       // ---- phase 1: GROUP / RB batches back to back
       // phase 1 carries the loads: a wave in it goes ahead of the co-resident wave's phase-2 arithmetic, so
