@@ -17,7 +17,7 @@ parent touches the GPU; the parent relays rank 0's line and fails if any rank fa
 external launcher (torch.distributed.run) WORLD_SIZE must equal --gpus.
 
 The JSON line also carries
-  roofline     : for the dominant kernel (k_flow_iter: UpdateMatrices + 15x15 box blur + 2x2
+  roofline     : for the dominant kernel (k_flow_iter3: UpdateMatrices + 15x15 box blur + 2x2
                  solve, one launch per Farneback iteration): `achieved` = ALGORITHMIC bytes of the
                  stages it covers (SURVEY.md 8d model) / HIP-event time measured live over the
                  timed region on the stream the kernels run on; `traffic` = HBM bytes per launch
@@ -79,7 +79,7 @@ def fb_geometry(h, w):
 
 
 def iter_model_bytes(h, w, pairs):
-    """Algorithmic bytes of the stages k_flow_iter covers, per step of `pairs` pairs: UpdateMatrices
+    """Algorithmic bytes of the stages k_flow_iter3 covers, per step of `pairs` pairs: UpdateMatrices
     (60 B/px + 8 B/px of coarse flow on the finer levels), the two fused blur+UpdateMatrices passes
     (80 B/px each) and the final blur (28 B/px) of the stream-amortised model of SURVEY.md 8d:
     248*sum(P_k) + 8*(sum(P_k) - P_0) per pair.  (The kernel itself moves less: M is never
@@ -207,7 +207,7 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         out["config4_4k_batch32"] = {
             "workload": "OpticalFlow + %d-bin Histogram, 3840x2160, 32 pairs per call (33 resident frames)" % bins,
             "frames_per_s": B4 * 4 / dt, "ms_per_step": dt / 4 * 1e3, "steps": 4,
-            "roofline": {"kernel": "k_flow_iter", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_flow_iter3", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": ms / max(launches, 1)},
             "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
         del fr4, fo4, ho4
@@ -365,7 +365,8 @@ def run_rank(args):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (B, h, w) == (256, 1080, 1920):
         try:
-            tj = json.load(open(tpath))["k_flow_iter"]
+            tj = json.load(open(tpath))
+            tj = tj.get("k_flow_iter3") or tj["k_flow_iter"]
             traffic = float(tj["hbm_bytes_per_launch"])
             l2_hit = tj.get("L2_hit_rate")
         except Exception:
@@ -396,7 +397,7 @@ def run_rank(args):
                 "sharding": "contiguous frame shards per GPU + 1 halo frame, no collective",
             },
             "roofline": {
-                "kernel": "k_flow_iter",
+                "kernel": "k_flow_iter3",
                 "bound": "hbm",
                 "achieved": blur_gbs,
                 "achieved_is": "algorithmic bytes of the covered stages (SURVEY 8d model: M priced as if materialised) / measured launch time",
