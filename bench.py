@@ -28,7 +28,8 @@ The JSON line also carries
   histogram    : frames/s and roofline of the Histogram kernel alone (same run, own timed loop).
   cpu_baseline : the CPU oracle (oracle/oracle.c, a port of the OpenCV algorithms the reference
                  calls) on all host cores, median of >= 3 repetitions on a bounded sample.
-  extra        : own timed loops after the headline: config 4 (4K, batch 32), the host-fed
+  extra        : own timed loops after the headline: config 3 (10 000-frame shot detection on this GPU),
+                 config 4 (4K, batch 32), the host-fed
                  (PCIe-inclusive) rates through the DeviceType::CPU kernel classes, Histogram at
                  small batches.  None of these is `value`.
 """
@@ -212,6 +213,28 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
             "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
         del fr4, fo4, ho4
         ctx.release_workspace()
+        torch.cuda.empty_cache()
+
+    # config 3 on this one GPU: Histogram (the reference's 16 bins) over a 10 000-frame 1080p stream with 8
+    # planted cuts, generated chunk by chunk on the device, then ShotBoundaries on the host
+    if not args.no_shots:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("shot_pipeline", os.path.join(ROOT, "scripts", "shot_pipeline.py"))
+        sp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sp)
+        from scannertools_amd.shot_detection import shot_boundaries
+        n3 = 10000
+        cuts = sp.planted_cuts(n3, 8)
+        hist3, t_hist = sp.shard_histograms(torch, ctx, device, 0, n3, 1080, 1920, 16, 250, cuts)
+        t0 = time.perf_counter()
+        res = shot_boundaries(None, list(hist3.cpu().numpy()))
+        t_sb = time.perf_counter() - t0
+        out["config3_shot_detection_10k"] = {
+            "workload": "Histogram (16 bins) on 10 000 x 1080p frames in chunks of 250 + ShotBoundaries on the host; "
+                        "1 GPU holds the whole stream (8 GPUs: scripts/shot_pipeline.py --gpus 8)",
+            "histogram_frames_per_s": n3 / t_hist, "histogram_s": t_hist, "shot_boundaries_s": t_sb,
+            "planted_cuts": cuts, "planted_found": all(c in res[0] for c in cuts), "boundaries_reported": len(res[0])}
+        del hist3
         torch.cuda.empty_cache()
 
     # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the
@@ -505,6 +528,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra records (4K, host-fed, small histogram batches)")
     ap.add_argument("--no-4k", action="store_true")
+    ap.add_argument("--no-shots", action="store_true", help="skip the 10 000-frame shot-detection extra (config 3)")
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=1)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--master-port", type=int, default=0)

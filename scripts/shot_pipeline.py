@@ -24,6 +24,48 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def planted_cuts(n, k):
+    return sorted({int(n * (i + 1) / (k + 1)) for i in range(k)})
+
+
+def shard_histograms(torch, ctx, dev, a, b, h, w, bins, chunk, cuts, seed=99):
+    """Frames [a, b) of the synthetic stream (a per-shot random texture with its own colour statistics
+    and +-3 grey levels of per-frame noise; shots change at `cuts`), generated on `dev` chunk by chunk
+    and run through the Histogram op.  Returns (int32 (b-a, 3, bins) on the device, seconds spent in
+    the Histogram calls -- frame generation is not timed)."""
+    def shot_of(i):
+        return int(np.searchsorted(cuts, i, side="right"))
+
+    def texture(shot):
+        # every shot has its own colour statistics (per-channel gain / offset), like a real cut
+        g = torch.Generator(device=dev).manual_seed(1234 + shot)
+        rs = np.random.default_rng(shot)
+        gain = torch.tensor(rs.uniform(0.25, 1.0, 3), device=dev, dtype=torch.float32)
+        off = torch.tensor(rs.uniform(0.0, 60.0, 3), device=dev, dtype=torch.float32)
+        t = torch.rand((h, w, 3), device=dev, generator=g) * 255.0 * gain + off
+        return t.clamp_(0, 255).to(torch.int16)
+
+    hist = torch.empty((b - a, 3, bins), dtype=torch.int32, device=dev)
+    buf = torch.empty((min(chunk, max(b - a, 1)), h, w, 3), dtype=torch.uint8, device=dev)
+    gn = torch.Generator(device=dev).manual_seed(seed)
+    t_hist = 0.0
+    cur_shot, base = -1, None
+    for c0 in range(a, b, chunk):
+        c1 = min(b, c0 + chunk)
+        for i in range(c0, c1):
+            s = shot_of(i)
+            if s != cur_shot:
+                cur_shot, base = s, texture(s)
+            noise = torch.randint(-3, 4, (h, w, 3), dtype=torch.int16, device=dev, generator=gn)
+            buf[i - c0] = (base + noise).clamp_(0, 255).to(torch.uint8)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ctx.histogram(buf[:c1 - c0], bins, out=hist[c0 - a:c1 - a])
+        torch.cuda.synchronize(dev)
+        t_hist += time.perf_counter() - t0
+    return hist, t_hist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=10000)
@@ -66,40 +108,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, h, w = args.frames, args.height, args.width
-    cuts = sorted({int(n * (i + 1) / (args.cuts + 1)) for i in range(args.cuts)})
+    cuts = planted_cuts(n, args.cuts)
     a, b = shard_range(n, rank, world)
     ctx = HipContext(local)
-
-    def shot_of(i):
-        return int(np.searchsorted(cuts, i, side="right"))
-
-    def texture(shot):
-        # every shot has its own colour statistics (per-channel gain / offset), like a real cut
-        g = torch.Generator(device=dev).manual_seed(1234 + shot)
-        rs = np.random.default_rng(shot)
-        gain = torch.tensor(rs.uniform(0.25, 1.0, 3), device=dev, dtype=torch.float32)
-        off = torch.tensor(rs.uniform(0.0, 60.0, 3), device=dev, dtype=torch.float32)
-        t = torch.rand((h, w, 3), device=dev, generator=g) * 255.0 * gain + off
-        return t.clamp_(0, 255).to(torch.int16)
-
-    hist = torch.empty((b - a, 3, args.bins), dtype=torch.int32, device=dev)
-    buf = torch.empty((args.chunk, h, w, 3), dtype=torch.uint8, device=dev)
-    gn = torch.Generator(device=dev).manual_seed(99 + rank)
-    t_hist = 0.0
-    cur_shot, base = -1, None
-    for c0 in range(a, b, args.chunk):
-        c1 = min(b, c0 + args.chunk)
-        for i in range(c0, c1):
-            s = shot_of(i)
-            if s != cur_shot:
-                cur_shot, base = s, texture(s)
-            noise = torch.randint(-3, 4, (h, w, 3), dtype=torch.int16, device=dev, generator=gn)
-            buf[i - c0] = (base + noise).clamp_(0, 255).to(torch.uint8)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ctx.histogram(buf[:c1 - c0], args.bins, out=hist[c0 - a:c1 - a])
-        torch.cuda.synchronize(dev)
-        t_hist += time.perf_counter() - t0
+    hist, t_hist = shard_histograms(torch, ctx, dev, a, b, h, w, args.bins, args.chunk, cuts, seed=99 + rank)
     if world > 1:
         t = torch.tensor([t_hist], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,7 +145,7 @@ def dry_run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     n = args.frames
-    cuts = sorted({int(n * (i + 1) / (args.cuts + 1)) for i in range(args.cuts)})
+    cuts = planted_cuts(n, args.cuts)
     a, b = shard_range(n, rank, world)
     px = args.height * args.width
     rows = np.empty((b - a, 3, args.bins), np.int32)
