@@ -237,6 +237,46 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         del hist3
         torch.cuda.empty_cache()
 
+    # config 5: 1080p frames -> CPM2Input -> the pose network's convolution stack (random weights, float32 like
+    # the reference's Caffe pass) on the matrix cores; roofline = the f32 MFMA peak
+    if not args.no_pose:
+        from scannertools_amd import pose_net
+        from scannertools_amd.hip import cpm2_geometry
+        nb5, sc5 = 16, 368 / 1080.
+        net = pose_net.PoseNet(ctx, seed=1)
+        fr5 = batches[0][:nb5]
+        _, _, nh5, nw5 = cpm2_geometry(h, w, sc5)
+        fl5 = pose_net.flops(nh5, nw5)
+        net.forward(ctx.cpm2_input(fr5, sc5))
+        sync()
+        ctx.timing_enable([_native.K_CONV])
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            maps = net.forward(ctx.cpm2_input(fr5, sc5))
+        sync()
+        dt5 = (time.perf_counter() - t0) / 2
+        nl5, ms5 = ctx.timing_read(_native.K_CONV)
+        ctx.timing_enable([])
+        # parity of the same code on a small input against the float32 torch network (CPU)
+        g5 = torch.Generator().manual_seed(4)
+        xs5 = torch.rand((1, 3, 48, 80), generator=g5) - 0.5
+        got5 = net.forward(xs5.to(device)).permute(0, 3, 1, 2).cpu()
+        ref5 = net.reference_forward(xs5, device="cpu")
+        tf5 = nb5 * fl5 / (ms5 / 2 * 1e-3) / 1e12
+        out["config5_pose_conv_stack"] = {
+            "workload": "%d x %dx%d frames -> CPM2Input (scale %.4f -> %dx%d) -> OpenPose COCO body network, 92 convolutions "
+                        "+ 3 poolings, random float32 weights" % (nb5, w, h, sc5, nw5, nh5),
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation)",
+            "frames_per_s": nb5 / dt5, "ms_per_batch": dt5 * 1e3, "gflop_per_frame": fl5 / 1e9,
+            "roofline": {"kernel": "k_conv_nhwc_f32", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": tf5 / 157.3, "launches": nl5, "kernel_ms_per_batch": ms5 / 2},
+            "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
+                       "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())},
+            "not_built": "x8 up-sampling + NMS of the Caffe fork between this and CPM2Output (DESIGN section 9)"}
+        del net, maps
+        torch.cuda.empty_cache()
+
     # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the
     # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
     try:
@@ -528,6 +568,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra records (4K, host-fed, small histogram batches)")
     ap.add_argument("--no-4k", action="store_true")
+    ap.add_argument("--no-pose", action="store_true", help="skip the pose-network extra (config 5)")
     ap.add_argument("--no-shots", action="store_true", help="skip the 10 000-frame shot-detection extra (config 3)")
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=1)
     ap.add_argument("--cpu-reps", type=int, default=3)

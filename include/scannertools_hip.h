@@ -83,7 +83,8 @@ enum st_kernel_id {
   ST_K_CVT_COLOR = 10,
   ST_K_CPM2_INPUT = 11,
   ST_K_CPM2_LIMBS = 12,
-  ST_K_COUNT = 13
+  ST_K_CONV = 13,       /* convolution / pooling launches of the pose network */
+  ST_K_COUNT = 14
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -265,6 +266,24 @@ int st_cpm2_input_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, in
 int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev, const float* const* peaks_dev, int n,
                         int net_h, int net_w, int max_peaks, float inter_threshold, int min_above,
                         float* scores_dev);
+
+/* Convolution stack of the pose network (what the Caffe forward pass behind the reference's CPM2 op
+ * computes, scannertools_caffe_cpp/cpm2_kernel.cpp:8-52 / caffe_kernel.cpp; layer list: DESIGN.md section 9).
+ * float32 throughout, as in the reference.  Activations are NHWC float32 device arrays whose channel count
+ * (x_stride / y_stride floats per pixel) is a multiple of 4; a call reads cin channels from channel
+ * x_offset on and writes cout channels from channel y_offset on, so concatenations need no copy.
+ * st_conv2d_nhwc_f32: stride-1 "same" convolution (odd square kernel <= 7) + bias (+ ReLU).  cin must be a
+ * multiple of 16 (pad channels zero).  w_dev: [cout_pad][kh][kw][cin] with cout_pad a multiple of 64 >= cout
+ * (extra rows zero), bias_dev: [cout_pad]. */
+int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                       const float* w_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
+                       float* y_dev, int y_stride, int y_offset);
+/* 2x2 max pooling, stride 2: (n, h, w, c) -> (n, h/2, w/2, c), c a multiple of 4. */
+int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int c, int x_stride, float* y_dev,
+                         int y_stride);
+/* planar (n, c, h, w) -> NHWC (n, h, w, y_stride) with zero pad channels: CPM2Input's frame as the first
+ * layer's operand. */
+int st_planar_to_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int c, int h, int w, float* y_dev, int y_stride);
 
 #ifdef __cplusplus
 }

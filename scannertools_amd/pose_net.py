@@ -1,0 +1,190 @@
+"""The convolution stack between CPM2Input and CPM2Output (BASELINE config 5): the body network of the
+OpenPose COCO-18 model, run layer by layer through ``st_conv2d_nhwc_f32`` / ``st_maxpool2_nhwc_f32``
+(MFMA kernels, csrc/st_conv.hip).
+
+In the reference this is a Caffe forward pass: the ``CPM2`` op (scannertools_caffe_cpp/cpm2_kernel.cpp:8-52,
+a ``CaffeKernel``) or, in the built library, OpenPose's own wrapper (openpose_kernel.cpp:129-168); prototxt
+and caffemodel are downloaded at run time (openpose_kernel.cpp:35-78) and are not in the reference tree.
+The layer list below is the published ``pose_deploy_linevec.prototxt`` of that model, written down from
+knowledge of it ([EXT]; to be re-checked against the real file), and the weights are RANDOM (there is no
+network here): what this module provides is the architecture at full size, float32 like the reference,
+checked layer by layer and end to end against ``torch.nn.functional.conv2d`` on the same weights.
+
+Layout: activations NHWC float32, channel counts padded to multiples of 16 with zero channels.  The stage
+inputs concat(PAF 38, heat maps 19, features 128) live in one 192-channel buffer, stored as [features |
+PAF | heat maps | 7 zero channels] (the features first so that every read starts 16-byte aligned; the
+first layer's weights of stages 2..6 are permuted to match), that the branches write their slices of, so
+no concatenation pass exists.  Output: (n, H/8, W/8, 57) = 19 heat maps followed by 38
+part-affinity planes, the channel order ``cpm2_output_kernel_cpu.cpp:84-88`` indexes (the reference then
+up-samples x8 and runs NMS inside the Caffe fork; not built -- DESIGN.md section 9).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native
+
+# (name, cin, cout, kernel, relu); "pool" = 2x2 max pooling
+TRUNK = [("conv1_1", 3, 64, 3, 1), ("conv1_2", 64, 64, 3, 1), "pool",
+         ("conv2_1", 64, 128, 3, 1), ("conv2_2", 128, 128, 3, 1), "pool",
+         ("conv3_1", 128, 256, 3, 1), ("conv3_2", 256, 256, 3, 1), ("conv3_3", 256, 256, 3, 1), ("conv3_4", 256, 256, 3, 1), "pool",
+         ("conv4_1", 256, 512, 3, 1), ("conv4_2", 512, 512, 3, 1), ("conv4_3_CPM", 512, 256, 3, 1), ("conv4_4_CPM", 256, 128, 3, 1)]
+N_PAF, N_HEAT, N_FEAT = 38, 19, 128
+CAT = N_PAF + N_HEAT + N_FEAT          # 185 channels into stages 2..6
+CAT_PAD = 192
+OFF_FEAT, OFF_PAF, OFF_HEAT = 0, N_FEAT, N_FEAT + N_PAF   # channel offsets inside the stage-input buffer
+# prototxt order of the concatenation is (PAF, heat maps, features): buffer channel -> prototxt channel
+CAT_PERM = list(range(N_PAF + N_HEAT, CAT)) + list(range(0, N_PAF + N_HEAT))
+
+
+def branch_layers(stage, out):
+    """Layers of one branch (L1: out = 38 part-affinity planes, L2: out = 19 heat maps) of a stage."""
+    if stage == 1:
+        return [(128, 128, 3, 1)] * 3 + [(128, 512, 1, 1), (512, out, 1, 0)]
+    return [(CAT, 128, 7, 1)] + [(128, 128, 7, 1)] * 4 + [(128, 128, 1, 1), (128, out, 1, 0)]
+
+
+def all_layers():
+    """Every convolution as (name, cin, cout, k, relu), in execution order."""
+    out = [l for l in TRUNK if l != "pool"]
+    for st in range(1, 7):
+        for br, n in (("L1", N_PAF), ("L2", N_HEAT)):
+            for i, (ci, co, k, r) in enumerate(branch_layers(st, n)):
+                out.append(("stage%d_%s_%d" % (st, br, i + 1), ci, co, k, r))
+    return out
+
+
+def flops(h, w):
+    """2 * MACs of one forward pass on an (h, w) network input."""
+    total, hh, ww = 0, h, w
+    for l in TRUNK:
+        if l == "pool":
+            hh, ww = hh // 2, ww // 2
+        else:
+            total += 2 * hh * ww * l[1] * l[2] * l[3] * l[3]
+    for st in range(1, 7):
+        for n in (N_PAF, N_HEAT):
+            for ci, co, k, _ in branch_layers(st, n):
+                total += 2 * hh * ww * ci * co * k * k
+    return total
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+class PoseNet:
+    """Random-weight instance of the network on one GPU."""
+
+    def __init__(self, ctx, seed=0):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.device = ctx.device
+        g = torch.Generator().manual_seed(seed)
+        self.weights = {}   # name -> (torch weight (cout, cin, k, k), bias (cout,)) float32 on the CPU
+        self.packed = {}    # name -> (w [cout_pad][k][k][cin_pad], bias [cout_pad]) on the device
+        for name, ci, co, k, _ in all_layers():
+            wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))   # He initialisation
+            b = (torch.rand((co,), generator=g) - 0.5) * 0.1
+            self.weights[name] = (wt, b)
+            cip = CAT_PAD if ci == CAT else _pad16(ci)
+            wp = torch.zeros((_pad64(co), k, k, cip))
+            wp[:co, :, :, :ci] = (wt[:, CAT_PERM] if ci == CAT else wt).permute(0, 2, 3, 1)
+            bp = torch.zeros((_pad64(co),))
+            bp[:co] = b
+            self.packed[name] = (wp.contiguous().to(self.device), bp.to(self.device))
+
+    # -- plumbing -------------------------------------------------------------------------------------
+    def _conv(self, name, x, cin, xoff, y, cout, yoff, k, relu):
+        n, h, w, xs = x.shape
+        wp, bp = self.packed[name]
+        L = self.ctx._L
+        self.ctx._bind()
+        self.ctx._check(L.st_conv2d_nhwc_f32(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, cin, xs, xoff,
+                                             ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, cout,
+                                             wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
+
+    def _pool(self, x, c):
+        n, h, w, xs = x.shape
+        y = self.torch.zeros((n, h // 2, w // 2, xs), dtype=self.torch.float32, device=self.device)
+        self.ctx._bind()
+        self.ctx._check(self.ctx._L.st_maxpool2_nhwc_f32(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, c, xs,
+                                                         ctypes.c_void_p(y.data_ptr()), xs))
+        return y
+
+    def forward(self, net_input):
+        """net_input: (n, 3, H, W) float32 on the device (CPM2Input's frames; H, W multiples of 8).
+        Returns (n, H/8, W/8, 57) float32: heat maps 0..18, part-affinity planes 19..56."""
+        torch = self.torch
+        n, c, H, W = net_input.shape
+        assert c == 3 and H % 8 == 0 and W % 8 == 0 and net_input.is_cuda and net_input.dtype == torch.float32
+        x = torch.empty((n, H, W, 16), dtype=torch.float32, device=self.device)
+        self.ctx._bind()
+        self.ctx._check(self.ctx._L.st_planar_to_nhwc_f32(self.ctx._h, ctypes.c_void_p(net_input.contiguous().data_ptr()), n, 3, H, W,
+                                                          ctypes.c_void_p(x.data_ptr()), 16))
+        cur_c = 3
+        cat = [torch.zeros((n, H // 8, W // 8, CAT_PAD), dtype=torch.float32, device=self.device) for _ in range(2)]
+        for l in TRUNK:
+            if l == "pool":
+                x = self._pool(x, x.shape[3])
+                continue
+            name, ci, co, k, relu = l
+            if name == "conv4_4_CPM":
+                y, yoff = cat[0], OFF_FEAT               # the features go straight into the stage-input buffer
+            else:
+                y, yoff = torch.zeros((x.shape[0], x.shape[1], x.shape[2], _pad16(co)), dtype=torch.float32, device=self.device), 0
+            self._conv(name, x, x.shape[3], 0, y, co, yoff, k, relu)
+            x, cur_c = y, co
+        cat[1][..., OFF_FEAT:OFF_FEAT + N_FEAT] = cat[0][..., OFF_FEAT:OFF_FEAT + N_FEAT]
+        h8, w8 = H // 8, W // 8
+        tmp = [torch.zeros((n, h8, w8, 128), dtype=torch.float32, device=self.device) for _ in range(2)]
+        wide = torch.zeros((n, h8, w8, 512), dtype=torch.float32, device=self.device)
+        for st in range(1, 7):
+            src, dst = cat[(st - 1) & 1], cat[st & 1]
+            for br, nout, boff in (("L1", N_PAF, OFF_PAF), ("L2", N_HEAT, OFF_HEAT)):
+                layers = branch_layers(st, nout)
+                x, xc, xoff = (src, N_FEAT, OFF_FEAT) if st == 1 else (src, CAT_PAD, 0)
+                for i, (ci, co, k, relu) in enumerate(layers):
+                    name = "stage%d_%s_%d" % (st, br, i + 1)
+                    last = i == len(layers) - 1
+                    if last:
+                        y, yoff = dst, boff
+                    elif co == 512:
+                        y, yoff = wide, 0
+                    else:
+                        y, yoff = tmp[i & 1], 0
+                    self._conv(name, x, xc, xoff, y, co, yoff, k, relu)
+                    x, xc, xoff = y, y.shape[3], 0
+        final = cat[6 & 1]
+        return torch.cat([final[..., OFF_HEAT:OFF_HEAT + N_HEAT], final[..., OFF_PAF:OFF_PAF + N_PAF]], dim=3).contiguous()
+
+    # -- float32 reference on the same weights (tests, bench parity) ---------------------------------------
+    def reference_forward(self, net_input, device=None):
+        """The same network through torch.nn.functional (float32), NCHW: (n, 57, H/8, W/8)."""
+        torch, F = self.torch, self.torch.nn.functional
+        dev = device or net_input.device
+        x = net_input.to(dev)
+
+        def conv(name, x, relu):
+            wt, b = self.weights[name]
+            y = F.conv2d(x, wt.to(dev), b.to(dev), padding=wt.shape[2] // 2)
+            return F.relu(y) if relu else y
+
+        for l in TRUNK:
+            x = F.max_pool2d(x, 2) if l == "pool" else conv(l[0], x, l[4])
+        feat = x
+        l1 = l2 = None
+        for st in range(1, 7):
+            inp = feat if st == 1 else torch.cat([l1, l2, feat], dim=1)
+            outs = []
+            for br, nout in (("L1", N_PAF), ("L2", N_HEAT)):
+                y = inp
+                for i, (_, _, _, relu) in enumerate(branch_layers(st, nout)):
+                    y = conv("stage%d_%s_%d" % (st, br, i + 1), y, relu)
+                outs.append(y)
+            l1, l2 = outs
+        return torch.cat([l2, l1], dim=1)

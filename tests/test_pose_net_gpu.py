@@ -1,0 +1,108 @@
+"""GPU: the convolution stack of the pose network (MFMA kernels, csrc/st_conv.hip) against
+torch.nn.functional on the same float32 weights -- layer shapes one by one (every kernel size, both block
+widths, channel slices, pixel-count tails) and the whole network end to end."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from scannertools_amd import pose_net
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0):
+    """x_nhwc (n,h,w,C) cuda; wt (co,ci,k,k), b (co,) cpu -> y (n,h,w,cout_total) cuda."""
+    n, h, w, xs = x_nhwc.shape
+    co, ci, k, _ = wt.shape
+    cip = (ci + 15) // 16 * 16
+    assert cip == cin
+    cop = (co + 63) // 64 * 64
+    wp = torch.zeros((cop, k, k, cip))
+    wp[:co, :, :, :ci] = wt.permute(0, 2, 3, 1)
+    bp = torch.zeros((cop,))
+    bp[:co] = b
+    wp, bp = wp.cuda(), bp.cuda()
+    ys = cout_total or (co + 3) // 4 * 4
+    y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
+    hip_ctx._bind()
+    hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_f32(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
+                                                  ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
+                                                  int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
+    return y
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,k,relu", [(1, 9, 13, 3, 64, 3, 1), (2, 23, 31, 16, 128, 3, 1), (1, 17, 19, 128, 38, 1, 0),
+                                                 (2, 12, 20, 64, 19, 7, 0), (1, 46, 82, 185, 128, 7, 1), (3, 8, 8, 512, 512, 3, 1),
+                                                 (1, 5, 7, 32, 200, 5, 1)])
+def test_conv_layer_matches_torch(hip_ctx, n, h, w, ci, co, k, relu):
+    g = torch.Generator().manual_seed(n * 1000 + ci + co + k)
+    x = torch.randn((n, ci, h, w), generator=g)
+    wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))
+    b = torch.randn((co,), generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=k // 2)
+    if relu:
+        ref = torch.relu(ref)
+    cip = (ci + 15) // 16 * 16
+    xn = torch.zeros((n, h, w, cip))
+    xn[..., :ci] = x.permute(0, 2, 3, 1)
+    y = _conv(hip_ctx, xn.cuda(), cip, 0, wt, b, relu)
+    got = y[..., :co].permute(0, 3, 1, 2).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (float((got - ref).abs().max()), scale)
+    assert (y[..., co:] == -7.0).all()                       # nothing written outside the cout channels
+
+
+def test_conv_channel_slices_and_identity_known_answer(hip_ctx):
+    """Reads a channel slice of a wider buffer, writes into a slice of another; a 1x1 identity kernel and a
+    3x3 shift kernel have known answers (asymmetric, so a transposed operand layout cannot pass)."""
+    n, h, w = 1, 11, 14
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn((n, h, w, 48), generator=g)
+    x = buf[..., 16:32]                                       # the slice the layer reads (offset 16)
+    wt = torch.zeros((16, 16, 1, 1))
+    for c in range(16):
+        wt[c, (c + 3) % 16, 0, 0] = 1.0                       # out channel c = in channel c+3: a permutation, not symmetric
+    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt, torch.zeros(16), 0, cout_total=40, yoff=20)
+    got = y.cpu()
+    np.testing.assert_array_equal(got[..., 20:36].numpy(), x[..., [(c + 3) % 16 for c in range(16)]].numpy())
+    assert (got[..., :20] == -7).all() and (got[..., 36:] == -7).all()
+    wt3 = torch.zeros((16, 16, 3, 3))
+    for c in range(16):
+        wt3[c, c, 0, 2] = 1.0                                 # tap (ky=0, kx=2): out(y, x) = in(y-1, x+1), zero outside
+    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt3, torch.zeros(16), 0)
+    exp = torch.zeros((n, h, w, 16))
+    exp[:, 1:, :-1] = x[:, :-1, 1:]
+    np.testing.assert_array_equal(y[..., :16].cpu().numpy(), exp.numpy())
+
+
+def test_maxpool_and_layout(hip_ctx):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((2, 3, 10, 14), generator=g).cuda()
+    nhwc = torch.empty((2, 10, 14, 16), device="cuda")
+    hip_ctx._bind()
+    hip_ctx._check(hip_ctx._L.st_planar_to_nhwc_f32(hip_ctx._h, ctypes.c_void_p(x.data_ptr()), 2, 3, 10, 14,
+                                                     ctypes.c_void_p(nhwc.data_ptr()), 16))
+    assert torch.equal(nhwc[..., :3], x.permute(0, 2, 3, 1)) and (nhwc[..., 3:] == 0).all()
+    y = torch.empty((2, 5, 7, 16), device="cuda")
+    hip_ctx._check(hip_ctx._L.st_maxpool2_nhwc_f32(hip_ctx._h, ctypes.c_void_p(nhwc.data_ptr()), 2, 10, 14, 16, 16,
+                                                    ctypes.c_void_p(y.data_ptr()), 16))
+    ref = torch.nn.functional.max_pool2d(x, 2).permute(0, 2, 3, 1)
+    assert torch.equal(y[..., :3], ref)
+
+
+def test_pose_network_end_to_end(hip_ctx):
+    """All 92 convolutions + 3 poolings on a small input, against the float32 torch network (CPU, so that no
+    other GPU library is in the comparison); the reference's own precision, so the bound is float32 round-off
+    accumulated over the depth."""
+    net = pose_net.PoseNet(hip_ctx, seed=3)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand((2, 3, 48, 80), generator=g) - 0.5)
+    got = net.forward(x.cuda()).permute(0, 3, 1, 2).cpu()
+    ref = net.reference_forward(x, device="cpu")
+    assert got.shape == ref.shape == (2, 57, 6, 10)
+    scale = float(ref.abs().max())
+    assert scale > 1e-3
+    assert float((got - ref).abs().max()) <= 1e-3 * scale, (float((got - ref).abs().max()), scale)
+    assert pose_net.flops(368, 656) > 4e11 and len(pose_net.all_layers()) == 92
