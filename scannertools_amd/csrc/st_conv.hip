@@ -19,8 +19,11 @@
 // of the input shifted by (kh, kw), zero outside the image) and B (BN x 16 weights) are staged through
 // LDS k-major, so that a wave's 32 lanes read 32 consecutive rows / columns of one k: the operand
 // layout of the 32x32x2 instruction (lane l: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]).
-// The next slice's global loads are in flight while the current one is multiplied (registers -> other
-// LDS buffer after the MFMAs; one barrier per slice).
+// Global loads: 4 adjacent lanes fetch the 64 contiguous bytes of one pixel's slice.  The next slice's
+// loads are in flight while the current one is multiplied (registers -> other LDS buffer after the
+// MFMAs; one barrier per slice), and inside a slice the operands of step k+2 are read from LDS before
+// the MFMAs of step k.  A 16-channel slice keeps the kernel at 111 VGPRs / 33 KB of LDS = 4 blocks per
+// CU; 32-channel slices (2 blocks per CU) measured 13 % slower (profiles/README.md).
 #include <cstring>
 
 #include "st_internal.h"
@@ -29,7 +32,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CV_BM = 128, CV_BK = 16, CV_PAD = 4;
+// LDS row padding: with row stride 130 the 4 channel quads x 8 pixels a half-wave stores (LD = 1) fall into 32 different banks
+constexpr int CV_BM = 128, CV_PAD = 2;
 
 struct ConvArgs {
   const float* x;     // input activations
@@ -42,57 +46,80 @@ struct ConvArgs {
   long long m;        // n * h * wd
 };
 
-template <int BN>
-__global__ __launch_bounds__(256) void k_conv_nhwc_f32(ConvArgs a) {
-  constexpr int NB4 = BN * CV_BK / 4 / 256;  // float4 loads of the weight tile per thread (2 or 1)
-  __shared__ float As[2][CV_BK][CV_BM + CV_PAD];
-  __shared__ float Bs[2][CV_BK][BN + CV_PAD];
+// BN: output channels per block (128 or 64); BK: input channels per K slice;
+// LD: 0 = a wave's lanes load 64 consecutive pixels (one channel quad each), 1 = BK/4 adjacent lanes load one
+// pixel's whole slice (contiguous bytes); PF: operands of step kk+2 are read from LDS before the MFMAs of kk
+template <int BN, int BK, int LD, int PF>
+__global__ __launch_bounds__(256, 3) void k_conv_nhwc_f32(ConvArgs a) {
+  constexpr int NA4 = CV_BM * BK / 4 / 256;  // float4 loads of the activation tile per thread
+  constexpr int NB4 = BN * BK / 4 / 256;     // ... of the weight tile
+  constexpr int QP = BK / 4;                 // channel quads per slice
+  constexpr int QA = 256 / CV_BM, QB = 256 / BN;  // LD 0: channel quads covered per load round
+  constexpr int PR = 256 / QP;               // LD 1: pixels (weight rows) covered per load round
+  __shared__ float As[2][BK][CV_BM + CV_PAD];
+  __shared__ float Bs[2][BK][BN + CV_PAD];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const long long m0 = (long long)blockIdx.x * CV_BM;
   const int n0 = blockIdx.y * BN;
 
-  // this thread's pixel of the A tile (fixed over the K walk) and its channel quads
-  const int pm = t & (CV_BM - 1), cqa = t >> 7;  // quads cqa, cqa + 2
-  const long long gm = m0 + pm;
-  const bool mvalid = gm < a.m;
-  int px = 0, py = 0, pn = 0;
-  if (mvalid) {
-    px = (int)(gm % a.wd);
-    const long long r = gm / a.wd;
-    py = (int)(r % a.h);
-    pn = (int)(r / a.h);
+  // this thread's pixels of the A tile (fixed over the K walk) and its channel quad(s)
+  constexpr int NPX = LD ? NA4 : 1;
+  int px[NPX], py[NPX];
+  bool mvalid[NPX];
+  const float* __restrict__ xpix[NPX];
+  const int pm0 = LD ? t / QP : t & (CV_BM - 1), cqa = LD ? t % QP : t / CV_BM;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const long long gm = m0 + pm0 + PR * j;
+    mvalid[j] = gm < a.m;
+    int pn = 0;
+    px[j] = py[j] = 0;
+    if (mvalid[j]) {
+      px[j] = (int)(gm % a.wd);
+      const long long r = gm / a.wd;
+      py[j] = (int)(r % a.h);
+      pn = (int)(r / a.h);
+    }
+    xpix[j] = a.x + ((size_t)((size_t)pn * a.h + py[j]) * a.wd + px[j]) * a.xs + a.xoff + 4 * cqa;
   }
-  // weight tile: output channel and channel quads
-  const int nb = t & (BN - 1), cqb = t / BN;  // BN = 128: quads cqb, cqb + 2; BN = 64: quad cqb (0..3)
+  // weight tile: output channel(s) and channel quad(s)
+  const int nb0 = LD ? t / QP : t & (BN - 1), cqb = LD ? t % QP : t / BN;
+  const float* __restrict__ wpix = a.w + (size_t)(n0 + nb0) * a.kh * a.kw * a.cin + 4 * cqb;
   const size_t wrow = (size_t)a.kh * a.kw * a.cin;
-  const float* __restrict__ wbase = a.w + (size_t)(n0 + nb) * wrow;
 
-  const int cslices = a.cin / CV_BK;
+  const int cslices = a.cin / BK;
   const int nslices = a.kh * a.kw * cslices;
 
-  float4 ra[2], rb[2];
-  auto fetch = [&](int s) {
-    const int kpos = s / cslices, c0 = (s - kpos * cslices) * CV_BK;
-    const int ky = kpos / a.kw, kx = kpos - ky * a.kw;
-    const int yy = py + ky - a.pad, xx = px + kx - a.pad;
-    const bool inb = mvalid && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd;
-    const float* __restrict__ src = a.x + ((size_t)((size_t)pn * a.h + (inb ? yy : 0)) * a.wd + (inb ? xx : 0)) * a.xs + a.xoff + c0;
+  // the K walk (ky, kx, channel slice) advances by counters: no division in the loop
+  int f_ky = 0, f_kx = 0, f_c = 0;
+  float4 ra[NA4], rb[NB4];
+  auto fetch = [&]() {
+    const long long shift = ((long long)(f_ky - a.pad) * a.wd + (f_kx - a.pad)) * a.xs + f_c * BK;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      ra[j] = inb ? *reinterpret_cast<const float4*>(src + 4 * (cqa + 2 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* __restrict__ wsrc = wbase + (size_t)kpos * a.cin + c0;
+    for (int j = 0; j < NA4; ++j) {
+      const int p = LD ? j : 0;
+      const int yy = py[p] + f_ky - a.pad, xx = px[p] + f_kx - a.pad;
+      const bool inb = mvalid[p] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd;
+      const float* __restrict__ src = xpix[p] + shift + (LD ? 0 : 4 * QA * j);
+      ra[j] = inb ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* __restrict__ wsrc = wpix + (size_t)(f_ky * a.kw + f_kx) * a.cin + f_c * BK;
 #pragma unroll
-    for (int j = 0; j < NB4; ++j) rb[j] = *reinterpret_cast<const float4*>(wsrc + 4 * (cqb + (BN == 128 ? 2 : 0) * j));
+    for (int j = 0; j < NB4; ++j) rb[j] = *reinterpret_cast<const float4*>(wsrc + (LD ? PR * j * wrow : (size_t)(4 * QB * j)));
+    if (++f_c == cslices) {
+      f_c = 0;
+      if (++f_kx == a.kw) { f_kx = 0; ++f_ky; }
+    }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = 4 * (cqa + 2 * j);
+    for (int j = 0; j < NA4; ++j) {
+      const int k = LD ? 4 * cqa : 4 * (cqa + QA * j), pm = LD ? pm0 + PR * j : pm0;
       As[buf][k][pm] = ra[j].x; As[buf][k + 1][pm] = ra[j].y; As[buf][k + 2][pm] = ra[j].z; As[buf][k + 3][pm] = ra[j].w;
     }
 #pragma unroll
     for (int j = 0; j < NB4; ++j) {
-      const int k = 4 * (cqb + (BN == 128 ? 2 : 0) * j);
+      const int k = LD ? 4 * cqb : 4 * (cqb + QB * j), nb = LD ? nb0 + PR * j : nb0;
       Bs[buf][k][nb] = rb[j].x; Bs[buf][k + 1][nb] = rb[j].y; Bs[buf][k + 2][nb] = rb[j].z; Bs[buf][k + 3][nb] = rb[j].w;
     }
   };
@@ -109,24 +136,35 @@ __global__ __launch_bounds__(256) void k_conv_nhwc_f32(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  fetch(0);
+  fetch();
   stash(0);
   __syncthreads();
   const int l31 = lane & 31, lk = lane >> 5;
   for (int s = 0; s < nslices; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslices) fetch(s + 1);
+    if (s + 1 < nslices) fetch();
+    float af[2][MT], bf[2][NT];
+    auto rd = [&](int kk, int slot) {
 #pragma unroll
-    for (int kk = 0; kk < CV_BK; kk += 2) {
-      float af[MT], bf[NT];
+      for (int i = 0; i < MT; ++i) af[slot][i] = As[buf][kk + lk][wm + 32 * i + l31];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = As[buf][kk + lk][wm + 32 * i + l31];
+      for (int j = 0; j < NT; ++j) bf[slot][j] = Bs[buf][kk + lk][wn + 32 * j + l31];
+    };
+    if (PF) rd(0, 0);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = Bs[buf][kk + lk][wn + 32 * j + l31];
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int cur = PF ? (kk >> 1) & 1 : 0;
+      if (PF) {
+        if (kk + 2 < BK) rd(kk + 2, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs that hide them
+      } else {
+        rd(kk, 0);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+      if (PF) __builtin_amdgcn_sched_barrier(0);
     }
     if (s + 1 < nslices) stash(buf ^ 1);
     __syncthreads();
@@ -207,7 +245,7 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
   ST_TRY(st_enter(ctx));
   if (!x_dev || !w_dev || !bias_dev || !y_dev || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0)
     return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
-  if (cin % CV_BK || x_offset % 4 || x_stride % 4 || x_offset + cin > x_stride || ((uintptr_t)x_dev & 15) || ((uintptr_t)w_dev & 15))
+  if (cin % 16 || x_offset % 4 || x_stride % 4 || x_offset + cin > x_stride || ((uintptr_t)x_dev & 15) || ((uintptr_t)w_dev & 15))
     return st_set_error(ctx, ST_ERR_INVALID, "conv2d: input channels must be a multiple of 16 inside a 16-byte aligned buffer (cin=%d stride=%d offset=%d)", cin, x_stride, x_offset);
   if (kh != kw || !(kh & 1) || kh > 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: %dx%d kernels (odd square kernels up to 7 are implemented)", kh, kw);
   const int bn = cout_pad % 128 == 0 ? 128 : 64;
@@ -223,8 +261,8 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
   dim3 grid((unsigned)bm, cout_pad / bn);
   st_timed t(ctx, ST_K_CONV);
-  if (bn == 128) hipLaunchKernelGGL(k_conv_nhwc_f32<128>, grid, dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(k_conv_nhwc_f32<64>, grid, dim3(256), 0, ctx->stream, a);
+  if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_f32<128, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_conv_nhwc_f32<64, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
