@@ -242,21 +242,29 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
     if not args.no_pose:
         from scannertools_amd import pose_net
         from scannertools_amd.hip import cpm2_geometry
-        nb5, sc5 = 16, 368 / 1080.
+        nb5, sc5 = 32, 368 / 1080.
         net = pose_net.PoseNet(ctx, seed=1)
         fr5 = batches[0][:nb5]
         _, _, nh5, nw5 = cpm2_geometry(h, w, sc5)
         fl5 = pose_net.flops(nh5, nw5)
-        net.forward(ctx.cpm2_input(fr5, sc5))
+
+        def pose_step():
+            # CPM2Input -> CPM2 (network, `resize`, `nms`) -> the GPU half of CPM2Output (limb candidate scores)
+            maps, joints = net.detect(ctx.cpm2_input(fr5, sc5))
+            return maps, joints, ctx.cpm2_limb_scores(maps, joints)
+
+        pose_step()
         sync()
-        ctx.timing_enable([_native.K_CONV])
+        ids5 = [_native.K_CONV, _native.K_CPM2_INPUT, _native.K_CPM2_RESIZE, _native.K_CPM2_NMS, _native.K_CPM2_LIMBS]
+        ctx.timing_enable(ids5)
         ctx.timing_reset()
         t0 = time.perf_counter()
         for _ in range(2):
-            maps = net.forward(ctx.cpm2_input(fr5, sc5))
+            maps, joints, limb = pose_step()
         sync()
         dt5 = (time.perf_counter() - t0) / 2
-        nl5, ms5 = ctx.timing_read(_native.K_CONV)
+        kms5 = {k: ctx.timing_read(k) for k in ids5}
+        nl5, ms5 = kms5[_native.K_CONV]
         ctx.timing_enable([])
         # parity of the same code on a small input against the float32 torch network (CPU)
         g5 = torch.Generator().manual_seed(4)
@@ -265,16 +273,19 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         ref5 = net.reference_forward(xs5, device="cpu")
         tf5 = nb5 * fl5 / (ms5 / 2 * 1e-3) / 1e12
         out["config5_pose_conv_stack"] = {
-            "workload": "%d x %dx%d frames -> CPM2Input (scale %.4f -> %dx%d) -> OpenPose COCO body network, 92 convolutions "
-                        "+ 3 poolings, random float32 weights" % (nb5, w, h, sc5, nw5, nh5),
+            "workload": "%d x %dx%d frames -> CPM2Input (scale %.4f -> %dx%d) -> CPM2 = OpenPose COCO body network (92 convolutions "
+                        "+ 3 poolings, random float32 weights) + x8 bicubic `resize` + `nms` -> CPM2Output's limb scores; the assembly "
+                        "of people on the host is not in this loop" % (nb5, w, h, sc5, nw5, nh5),
             "dtype": "f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation)",
             "frames_per_s": nb5 / dt5, "ms_per_batch": dt5 * 1e3, "gflop_per_frame": fl5 / 1e9,
             "roofline": {"kernel": "k_conv_nhwc_f32", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": tf5 / 157.3, "launches": nl5, "kernel_ms_per_batch": ms5 / 2},
+            "other_kernels_ms_per_batch": {"cpm2_input": kms5[_native.K_CPM2_INPUT][1] / 2, "resize_maps": kms5[_native.K_CPM2_RESIZE][1] / 2,
+                                           "nms": kms5[_native.K_CPM2_NMS][1] / 2, "limb_scores": kms5[_native.K_CPM2_LIMBS][1] / 2},
+            "resize_maps_GBs": nb5 * 57 * nh5 * nw5 * 4 / (kms5[_native.K_CPM2_RESIZE][1] / 2 * 1e-3) / 1e9,
             "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
-                       "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())},
-            "not_built": "x8 up-sampling + NMS of the Caffe fork between this and CPM2Output (DESIGN section 9)"}
-        del net, maps
+                       "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())}}
+        del net, maps, joints, limb
         torch.cuda.empty_cache()
 
     # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the

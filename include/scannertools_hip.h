@@ -84,7 +84,9 @@ enum st_kernel_id {
   ST_K_CPM2_INPUT = 11,
   ST_K_CPM2_LIMBS = 12,
   ST_K_CONV = 13,       /* convolution / pooling launches of the pose network */
-  ST_K_COUNT = 14
+  ST_K_CPM2_RESIZE = 14,
+  ST_K_CPM2_NMS = 15,
+  ST_K_COUNT = 16
 };
 int st_ctx_timing_enable(st_ctx* ctx, unsigned kernel_mask);
 int st_ctx_timing_reset(st_ctx* ctx);
@@ -284,6 +286,23 @@ int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, i
 /* planar (n, c, h, w) -> NHWC (n, h, w, y_stride) with zero pad channels: CPM2Input's frame as the first
  * layer's operand. */
 int st_planar_to_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int c, int h, int w, float* y_dev, int y_stride);
+
+/* The two layers between the network and CPM2Output, which the reference configures in
+ * CPM2Kernel::net_config (scannertools_caffe_cpp/cpm2_kernel.cpp:13-29: the Caffe fork's ImResizeLayer "resize"
+ * with start scale 1 / target = network input size, and its "nms" layer) and whose outputs are the op's columns
+ * cpm2_resized_map and cpm2_joints (cpm2_kernel.cpp:46-49).  The layers' sources are not in the reference tree:
+ * behaviour restated from the published fork ([EXT], unpinned; csrc/st_pose.hip says what exactly).
+ * st_cpm2_resize_maps: src (n, src_h, src_w, src_stride) channel-last float32 maps -> n planar (nmaps, dst_h,
+ * dst_w) frames (out_dev: host array of n device pointers); output plane c reads source channel chan_map[c]
+ * (host array; NULL = identity); bicubic (Catmull-Rom), one scale. */
+int st_cpm2_resize_maps(st_ctx* ctx, const float* src_dev, int n, int src_h, int src_w, int src_stride,
+                        const int* chan_map, int nmaps, int dst_h, int dst_w, float* const* out_dev);
+/* st_cpm2_nms: peaks of the first `parts` planes of n (>= parts, h, w) maps: strict 8-neighbour maxima above
+ * `threshold`, interior pixels only, raster order, at most max_peaks per part.  joints_dev: n device pointers to
+ * (parts, max_peaks + 1, 3) float32: row 0 = [count, 0, 0], row i = (x, y, score) -- the layout
+ * cpm2_output_kernel_cpu.cpp:481-499 reads. */
+int st_cpm2_nms(st_ctx* ctx, const float* const* maps_dev, int n, int h, int w, int parts, int max_peaks, float threshold,
+                float* const* joints_dev);
 
 #ifdef __cplusplus
 }

@@ -295,6 +295,71 @@ CPM2_MAP_IDX = [31, 32, 39, 40, 33, 34, 35, 36, 41, 42, 43, 44, 19, 20, 21, 22, 
                 50, 53, 54, 51, 52, 55, 56, 37, 38, 45, 46]
 
 
+def _rm_taps(pos, length):
+    """Neighbour indices of the Caffe fork's bicubic resize for float32 positions `pos` ([EXT], see cpm2_resize_maps)."""
+    c = (pos.astype(np.float64) + 1e-5).astype(np.int64)   # int(x + 1e-5): truncation towards zero
+    c = np.maximum(c, 0)
+    n0 = np.where(c - 1 < 0, c, c - 1)
+    n2 = np.where(c + 1 >= length, length - 1, c + 1)
+    n3 = np.where(n2 + 1 >= length, length - 1, n2 + 1)
+    return n0, c, n2, n3
+
+
+def _rm_cubic(v0, v1, v2, v3, d):
+    f = np.float32
+    return ((f(-0.5) * v0 + f(1.5) * v1 - f(1.5) * v2 + f(0.5) * v3) * d * d * d + (v0 - f(2.5) * v1 + f(2.0) * v2 - f(0.5) * v3) * d * d
+            + (f(-0.5) * v0 + f(0.5) * v2) * d + v1)
+
+
+def cpm2_resize_maps(maps, dst_h, dst_w):
+    """The `resize` layer of the Caffe fork behind the reference's CPM2 op (ImResizeLayer with start scale 1 and one
+    scale, configured at scannertools_caffe_cpp/cpm2_kernel.cpp:16-23).  The layer's source is not in the reference
+    tree: restated from the published caffe_rtpose kernel ([EXT], PARITY UNPINNED).  maps: (C, h, w) float32 ->
+    (C, dst_h, dst_w) float32, every operation in float32 in the layer's order (the 1e-5 nudge and the offset's
+    `- 0.5` in double, as the C expression evaluates them)."""
+    maps = np.ascontiguousarray(maps, dtype=np.float32)
+    C, h, w = maps.shape
+    f = np.float32
+    off_x = f(np.float64(f(f(dst_w) / f(w)) / f(2)) - 0.5)
+    off_y = f(np.float64(f(f(dst_h) / f(h)) / f(2)) - 0.5)
+    rx, ry = f(w) / f(dst_w), f(h) / f(dst_h)
+    x_on = (np.arange(dst_w, dtype=np.float32) - off_x) * rx
+    y_on = (np.arange(dst_h, dtype=np.float32) - off_y) * ry
+    xn = _rm_taps(x_on, w)
+    yn = _rm_taps(y_on, h)
+    dx = (x_on - xn[1].astype(np.float32))[None, None, :]
+    dy = (y_on - yn[1].astype(np.float32))[None, :, None]
+    rows = []
+    for i in range(4):
+        r = maps[:, yn[i], :]                                  # (C, dst_h, w)
+        rows.append(_rm_cubic(r[:, :, xn[0]], r[:, :, xn[1]], r[:, :, xn[2]], r[:, :, xn[3]], dx))
+    return _rm_cubic(rows[0], rows[1], rows[2], rows[3], dy).astype(np.float32)
+
+
+def cpm2_nms(maps, parts=18, max_peaks=64, threshold=0.05):
+    """The `nms` layer of the same fork ([EXT], PARITY UNPINNED): per part plane, interior pixels above `threshold`
+    that exceed their 8 neighbours, raster order, the first max_peaks kept.  Returns (parts, max_peaks + 1, 3)
+    float32: row 0 = [count, 0, 0], row i = (x, y, score) -- the layout cpm2_output_kernel_cpu.cpp:481-499 reads."""
+    maps = np.asarray(maps, dtype=np.float32)
+    out = np.zeros((parts, max_peaks + 1, 3), np.float32)
+    for p in range(parts):
+        m = maps[p]
+        c = m[1:-1, 1:-1]
+        peak = c > np.float32(threshold)
+        for dy in (0, 1, 2):
+            for dx in (0, 1, 2):
+                if dy == 1 and dx == 1:
+                    continue
+                peak &= c > m[dy:dy + c.shape[0], dx:dx + c.shape[1]]
+        ys, xs = np.nonzero(peak)                              # row-major = raster order
+        k = min(len(ys), max_peaks)
+        out[p, 0, 0] = k
+        out[p, 1:k + 1, 0] = xs[:k] + 1
+        out[p, 1:k + 1, 1] = ys[:k] + 1
+        out[p, 1:k + 1, 2] = c[ys[:k], xs[:k]]
+    return out
+
+
 def _c_round(x):
     """C round(): half away from zero."""
     import math

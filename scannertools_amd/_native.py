@@ -21,7 +21,7 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_HSV2BGR": 54, "COLOR_HSV2RGB": 55, "COLOR_BGR2HSV_FULL": 66, "COLOR_RGB2HSV_FULL": 67,
                "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
                "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85}
-K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_CPM2_INPUT, K_CPM2_LIMBS, K_CONV, K_COUNT = range(15)
+K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_CPM2_INPUT, K_CPM2_LIMBS, K_CONV, K_CPM2_RESIZE, K_CPM2_NMS, K_COUNT = range(17)
 KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color", "cpm2_input", "cpm2_limbs", "conv"]
 
 
@@ -86,6 +86,8 @@ SIGNATURES = {
     "st_conv2d_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_maxpool2_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),
     "st_planar_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "st_cpm2_resize_maps": (_i, [_vp, _vp, _i, _i, _i, _i, _c.POINTER(_i), _i, _i, _i, _c.POINTER(_vp)]),
+    "st_cpm2_nms": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _c.c_float, _c.POINTER(_vp)]),
 }
 
 _LIB = None

@@ -157,6 +157,150 @@ __global__ __launch_bounds__(256) void k_cpm2_limb_scores(LimbArgs a) {
   }
 }
 
+// ---- between the network and CPM2Output: x8 up-sampling of the 57 maps and peak extraction ---------------
+// In the reference these are the `resize` (ImResizeLayer, configured by cpm2_kernel.cpp:13-29:
+// SetStartScale(1), SetScaleGap(0.1), setTargetDimenions(net input size)) and `nms` layers of the Caffe fork
+// the CPM2 op links against; their sources are NOT under /root/reference.  What is restated here is the
+// published behaviour of those layers ([EXT], from knowledge of the caffe_rtpose / OpenPose sources; unpinned):
+//   resize: per output pixel, source position ((x - off) * src/dst, off = dst/src/2 - 0.5), the 4x4 neighbourhood
+//           around int(pos + 1e-5) with indices clamped to the map, Catmull-Rom cubic (-0.5, 1.5, -1.5, 0.5 | 1,
+//           -2.5, 2, -0.5 | -0.5, 0, 0.5 | 0, 1) along x for the four rows, then along y; one scale (num = 1);
+//   nms:    an interior pixel is a peak if it exceeds the threshold and its 8 neighbours; peaks of a part in
+//           raster order, the first max_peaks kept: row 0 = [count, 0, 0], row i = (x, y, score).
+// Both are HBM-trivial next to the network (55 MB of maps per 1080p frame written once, read once).
+constexpr int RM_ROWS = 16;  // output rows per thread: the four row interpolants are reused while the source row stays
+
+struct ResizeMapsArgs {
+  const float* src;   // (n, sh, sw, stride) float32, channel-last
+  float* const* dst;  // n x (nmaps, th, tw)
+  int sh, sw, stride, nmaps, th, tw;
+  float off_x, off_y, rx, ry;
+  int chan[64];       // source channel of output plane c
+};
+
+__device__ __forceinline__ float rm_cubic(float v0, float v1, float v2, float v3, float d) {
+  return (-0.5f * v0 + 1.5f * v1 - 1.5f * v2 + 0.5f * v3) * d * d * d + (v0 - 2.5f * v1 + 2.f * v2 - 0.5f * v3) * d * d +
+         (-0.5f * v0 + 0.5f * v2) * d + v1;
+}
+
+__device__ __forceinline__ void rm_taps(float pos, int len, int nei[4]) {
+  int c = (int)((double)pos + 1e-5);
+  c = c < 0 ? 0 : c;
+  nei[1] = c;
+  nei[0] = c - 1 < 0 ? c : c - 1;
+  nei[2] = c + 1 >= len ? len - 1 : c + 1;
+  nei[3] = nei[2] + 1 >= len ? len - 1 : nei[2] + 1;
+}
+
+__global__ __launch_bounds__(256) void k_cpm2_resize_maps(ResizeMapsArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.tw) return;
+  const int f = blockIdx.z;
+  const float x_on = ((float)x - a.off_x) * a.rx;
+  int xn[4];
+  rm_taps(x_on, a.sw, xn);
+  const float dx = x_on - (float)xn[1];
+  const float* __restrict__ src = a.src + (size_t)f * a.sh * a.sw * a.stride;
+  float* __restrict__ dst = a.dst[f];
+  const int y0 = blockIdx.y * RM_ROWS, y1 = min(a.th, y0 + RM_ROWS);
+  const int o0 = xn[0] * a.stride, o1 = xn[1] * a.stride, o2 = xn[2] * a.stride, o3 = xn[3] * a.stride;
+  for (int c = 0; c < a.nmaps; ++c) {
+    const float* __restrict__ sc = src + a.chan[c];
+    int cached = -1;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int y = y0; y < y1; ++y) {  // y is uniform over the workgroup, so is the branch below
+      const float y_on = ((float)y - a.off_y) * a.ry;
+      int yn[4];
+      rm_taps(y_on, a.sh, yn);
+      if (yn[1] != cached) {
+        cached = yn[1];
+        const float* r0 = sc + (size_t)yn[0] * a.sw * a.stride;
+        const float* r1 = sc + (size_t)yn[1] * a.sw * a.stride;
+        const float* r2 = sc + (size_t)yn[2] * a.sw * a.stride;
+        const float* r3 = sc + (size_t)yn[3] * a.sw * a.stride;
+        t0 = rm_cubic(r0[o0], r0[o1], r0[o2], r0[o3], dx);
+        t1 = rm_cubic(r1[o0], r1[o1], r1[o2], r1[o3], dx);
+        t2 = rm_cubic(r2[o0], r2[o1], r2[o2], r2[o3], dx);
+        t3 = rm_cubic(r3[o0], r3[o1], r3[o2], r3[o3], dx);
+      }
+      const float dy = y_on - (float)yn[1];
+      dst[((size_t)c * a.th + y) * a.tw + x] = rm_cubic(t0, t1, t2, t3, dy);
+    }
+  }
+}
+
+struct NmsArgs {
+  const float* const* maps;  // n x (>= parts, h, w)
+  float* const* joints;      // n x (parts, max_peaks + 1, 3)
+  int h, w, parts, max_peaks;
+  float threshold;
+};
+
+// one workgroup per (part, frame): the plane in raster order, 1024 pixels per round, ordered compaction
+__global__ __launch_bounds__(256) void k_cpm2_nms(NmsArgs a) {
+  __shared__ int wave_cnt[4];
+  const int part = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* __restrict__ m = a.maps[f] + (size_t)part * a.h * a.w;
+  float* __restrict__ out = a.joints[f] + (size_t)part * (a.max_peaks + 1) * 3;
+  for (int i = tid; i < (a.max_peaks + 1) * 3; i += 256) out[i] = 0.f;
+  __syncthreads();
+  const int total = a.h * a.w;
+  int count = 0;  // peaks found so far (uniform)
+  for (int base = 0; base < total && count < a.max_peaks; base += 1024) {
+    unsigned flags = 0;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = base + 4 * tid + k;
+      if (idx < total) {
+        const int y = idx / a.w, x = idx - y * a.w;
+        if (x > 0 && x < a.w - 1 && y > 0 && y < a.h - 1) {
+          const float v = m[idx];
+          if (v > a.threshold) {
+            const float* __restrict__ up = m + idx - a.w;
+            const float* __restrict__ dn = m + idx + a.w;
+            if (v > up[-1] && v > up[0] && v > up[1] && v > m[idx - 1] && v > m[idx + 1] && v > dn[-1] && v > dn[0] && v > dn[1]) {
+              flags |= 1u << k;
+              ++mine;
+            }
+          }
+        }
+      }
+    }
+    // exclusive scan of `mine` over the workgroup: shuffles inside a wave, LDS across the four waves
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_cnt[wv] = incl;
+    __syncthreads();
+    int before = count + incl - mine, round_total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = wave_cnt[q];
+      if (q < wv) before += c;
+      round_total += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (flags & (1u << k)) {
+        if (before < a.max_peaks) {
+          const int idx = base + 4 * tid + k;
+          const int y = idx / a.w, x = idx - y * a.w;
+          out[(before + 1) * 3] = (float)x;
+          out[(before + 1) * 3 + 1] = (float)y;
+          out[(before + 1) * 3 + 2] = m[idx];
+        }
+        ++before;
+      }
+    count += round_total;
+  }
+  if (tid == 0) out[0] = (float)(count < a.max_peaks ? count : a.max_peaks);
+}
+
 }  // namespace
 
 ST_EXPORT int st_cpm2_geometry(int h, int w, float scale, int* resize_h, int* resize_w, int* net_h, int* net_w) {
@@ -228,6 +372,65 @@ ST_EXPORT int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev,
     a.scores = scores_dev + (size_t)f0 * 19 * max_peaks * max_peaks;
     st_timed t(ctx, ST_K_CPM2_LIMBS);
     hipLaunchKernelGGL(k_cpm2_limb_scores, dim3(19, nf), dim3(256), 0, ctx->stream, a);
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+
+ST_EXPORT int st_cpm2_resize_maps(st_ctx* ctx, const float* src_dev, int n, int src_h, int src_w, int src_stride,
+                                  const int* chan_map, int nmaps, int dst_h, int dst_w, float* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || src_h <= 0 || src_w <= 0 || src_stride <= 0 || nmaps <= 0 || nmaps > 64 || dst_h <= 0 || dst_w <= 0 ||
+      (long long)dst_h * dst_w > 35000000LL || n > 65535)
+    return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_maps: bad arguments (n=%d %dx%d -> %dx%d, %d maps)", n, src_h, src_w, dst_h, dst_w, nmaps);
+  if (n == 0) return ST_OK;
+  if (!src_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_maps: null argument");
+  ResizeMapsArgs a;
+  for (int c = 0; c < nmaps; ++c) {
+    a.chan[c] = chan_map ? chan_map[c] : c;
+    if (a.chan[c] < 0 || a.chan[c] >= src_stride) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_maps: channel %d outside the source pixel", a.chan[c]);
+  }
+  for (int i = 0; i < n; ++i)
+    if (!out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_maps: row %d is null", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, tb));
+  float** d_dst = (float**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  a.src = src_dev; a.dst = d_dst;
+  a.sh = src_h; a.sw = src_w; a.stride = src_stride; a.nmaps = nmaps; a.th = dst_h; a.tw = dst_w;
+  // the layer's own arithmetic: `tw/float(ow)/2 - 0.5` is a float quotient minus a double constant, stored as float
+  a.off_x = (float)((double)((float)dst_w / (float)src_w / 2) - 0.5);
+  a.off_y = (float)((double)((float)dst_h / (float)src_h / 2) - 0.5);
+  a.rx = (float)src_w / (float)dst_w;
+  a.ry = (float)src_h / (float)dst_h;
+  st_timed t(ctx, ST_K_CPM2_RESIZE);
+  hipLaunchKernelGGL(k_cpm2_resize_maps, dim3((dst_w + 255) / 256, (dst_h + RM_ROWS - 1) / RM_ROWS, n), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+ST_EXPORT int st_cpm2_nms(st_ctx* ctx, const float* const* maps_dev, int n, int h, int w, int parts, int max_peaks,
+                          float threshold, float* const* joints_dev) {
+  ST_TRY(st_enter(ctx));
+  if (n < 0 || h <= 0 || w <= 0 || parts <= 0 || parts > 65535 || max_peaks < 1 || max_peaks > 1024 || (long long)h * w > 35000000LL)
+    return st_set_error(ctx, ST_ERR_INVALID, "cpm2_nms: bad arguments (n=%d %dx%d parts=%d max_peaks=%d)", n, h, w, parts, max_peaks);
+  if (n == 0) return ST_OK;
+  if (!maps_dev || !joints_dev) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_nms: null argument");
+  for (int i = 0; i < n; ++i)
+    if (!maps_dev[i] || !joints_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_nms: row %d is null", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, 2 * tb));
+  const float** d_maps = (const float**)st_ws_alloc(ctx, tb);
+  float** d_j = (float**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_maps, maps_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ST_HIP(ctx, hipMemcpyAsync(d_j, joints_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  NmsArgs a;
+  a.h = h; a.w = w; a.parts = parts; a.max_peaks = max_peaks; a.threshold = threshold;
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = n - f0 < 65535 ? n - f0 : 65535;
+    a.maps = d_maps + f0; a.joints = d_j + f0;
+    st_timed t(ctx, ST_K_CPM2_NMS);
+    hipLaunchKernelGGL(k_cpm2_nms, dim3(parts, nf), dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;

@@ -292,6 +292,53 @@ class _FrameInfoNode(_Node):
         return out
 
 
+class _PoseNetOp:
+    """The CPM2 op (scannertools_caffe_cpp/cpm2_kernel.cpp:46-52): cpm2_input -> (cpm2_resized_map, cpm2_joints).
+    In the reference a Caffe forward pass; here scannertools_amd.pose_net.PoseNet (MFMA convolution stack, `resize`
+    and `nms` layers) with weights from a caffemodel file or, without one, random weights from `seed`.  Both
+    outputs stay on the GPU (CUDA tensors), which is what CPM2Output's GPU kernel consumes."""
+
+    def __init__(self, client, parent, weights, seed, batch, max_peaks, nms_threshold):
+        self.client, self.parent = client, parent
+        self.weights, self.seed, self.batch = weights, seed, max(1, int(batch or 1))
+        self.max_peaks, self.nms_threshold = max_peaks, nms_threshold
+        self._net, self._cache = None, {}
+
+    def net(self):
+        if self._net is None:
+            from . import pose_net
+            from .hip import HipContext
+            ctx = HipContext(self.client.device_id)
+            self._net = pose_net.PoseNet(ctx, seed=self.seed, caffemodel=self.weights)
+        return self._net
+
+    def compute(self, idx):
+        import torch
+        key = tuple(idx)
+        if key not in self._cache:
+            net = self.net()
+            frames = self.parent.rows(list(idx))
+            maps, joints = [], []
+            for i in range(0, len(frames), self.batch):
+                x = torch.stack([f if isinstance(f, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(f)) for f in frames[i:i + self.batch]])
+                m, j = net.detect(x.to(net.device), self.max_peaks, self.nms_threshold)
+                maps += list(m)
+                joints += list(j)
+            self._cache = {key: (maps, joints)}
+        return self._cache[key]
+
+
+class _PoseNetColumn(_Node):
+    def __init__(self, op, which):
+        self.op, self.which = op, which
+
+    def length(self):
+        return self.op.parent.length()
+
+    def rows(self, idx):
+        return list(self.op.compute(idx)[self.which]) if idx else []
+
+
 class _CppMultiOpNode(_Node):
     """A C++ op with several input columns (frames and/or bytes), no stencil: CPM2Output."""
 
@@ -545,6 +592,12 @@ class _Ops:
         """sc.ops.CPM2Input(frame=..., args CPM2Args{scale}) (cpm2_input_kernel_gpu.cpp:184)."""
         from . import _proto
         return _CppOpNode(self.sc, "CPM2Input", frame, device, batch, None, _proto.encode([(2, "float", float(scale))]))
+
+    def CPM2(self, cpm2_input, weights=None, seed=0, batch=8, max_peaks=64, nms_threshold=0.05):
+        """sc.ops.CPM2(cpm2_input=...) (cpm2_kernel.cpp:46-52): returns the columns (cpm2_resized_map, cpm2_joints).
+        `weights`: path of the model's caffemodel; None = random weights (architecture only)."""
+        op = _PoseNetOp(self.sc, cpm2_input, weights, seed, batch, max_peaks, nms_threshold)
+        return _PoseNetColumn(op, 0), _PoseNetColumn(op, 1)
 
     def CPM2Output(self, cpm2_resized_map, cpm2_joints, original_frame_info, scale, device=None, batch=None):
         """sc.ops.CPM2Output(cpm2_resized_map=..., cpm2_joints=..., original_frame_info=...)

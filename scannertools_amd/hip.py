@@ -305,6 +305,45 @@ class HipContext:
                                                 ctypes.c_void_p(out.data_ptr())))
         return out
 
+    def cpm2_resize_maps(self, maps, dst_h, dst_w, chan_map=None, nmaps=None, out=None):
+        """The CPM2 network's `resize` layer (cpm2_kernel.cpp:16-23 configures it; [EXT] Caffe fork): maps
+        (n,h,w,C) channel-last float32 -> (n,nmaps,dst_h,dst_w) planar float32, bicubic; output plane c reads
+        channel chan_map[c] (default: the first nmaps channels)."""
+        self._bind()
+        _require_cuda(maps, torch.float32, "maps", self.device)
+        if maps.dim() != 4:
+            raise ValueError("maps must be (n,h,w,C)")
+        n, h, w, C = maps.shape
+        if chan_map is not None:
+            nmaps = len(chan_map)
+        elif nmaps is None:
+            nmaps = C
+        shape = (n, nmaps, int(dst_h), int(dst_w))
+        out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else _check_out(out, shape, torch.float32, self.device)
+        if n == 0:
+            return out
+        cm = (ctypes.c_int * nmaps)(*[int(v) for v in chan_map]) if chan_map is not None else None
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cpm2_resize_maps(self._h, ctypes.c_void_p(maps.data_ptr()), n, h, w, C, cm, nmaps, int(dst_h), int(dst_w), to))
+        return out
+
+    def cpm2_nms(self, maps, parts=18, max_peaks=64, threshold=0.05, out=None):
+        """The CPM2 network's `nms` layer ([EXT] Caffe fork): maps (n,>=parts,H,W) float32 -> joints
+        (n,parts,max_peaks+1,3) float32, row 0 = [count,0,0], rows 1.. = (x, y, score) in raster order."""
+        self._bind()
+        _require_cuda(maps, torch.float32, "maps", self.device)
+        if maps.dim() != 4 or maps.shape[1] < parts:
+            raise ValueError("maps must be (n,>=parts,H,W)")
+        n, _, H, W = maps.shape
+        shape = (n, parts, max_peaks + 1, 3)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else _check_out(out, shape, torch.float32, self.device)
+        if n == 0:
+            return out
+        tm = (ctypes.c_void_p * n)(*[maps[i].data_ptr() for i in range(n)])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cpm2_nms(self._h, tm, n, H, W, int(parts), int(max_peaks), float(threshold), to))
+        return out
+
     # -- OpticalFlow ------------------------------------------------------------------------
     def optical_flow(self, frames, pairs=None, params=None, out=None):
         """Farneback flow for a batch of frame pairs.

@@ -69,6 +69,73 @@ def flops(h, w):
     return total
 
 
+def caffe_layer_names():
+    """Names of the convolution layers in the published prototxt ([EXT]), in all_layers() order: the trunk keeps
+    its VGG names; stage 1 is conv5_{1..5}_CPM_L{1,2}; stages 2..6 are Mconv{1..7}_stage{s}_L{1,2}."""
+    out = [l[0] for l in TRUNK if l != "pool"]
+    for st in range(1, 7):
+        for br in ("L1", "L2"):
+            n = len(branch_layers(st, 1))
+            out += [("conv5_%d_CPM_%s" % (i + 1, br)) if st == 1 else ("Mconv%d_stage%d_%s" % (i + 1, st, br)) for i in range(n)]
+    return out
+
+
+def read_caffemodel(path):
+    """Weights of a Caffe model file: {layer name: [blob, ...]} with every blob a float32 array of its stored
+    shape.  Reads the NetParameter wire format directly (caffe.proto, [EXT]: NetParameter.layer = 100 and the V1
+    `layers` = 2; LayerParameter.name = 1, .blobs = 7 (V1: name = 4, blobs = 6); BlobProto.data = 5 packed float,
+    .shape = 7 {dim = 1}, legacy num/channels/height/width = 1..4)."""
+    from . import _proto
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    out = {}
+
+    def blob(mv):
+        data, dims, legacy = None, [], {}
+        for num, wt, v in _proto.fields(mv):
+            if num == 5 and wt == 2:
+                data = np.frombuffer(v, dtype="<f4")
+            elif num == 5 and wt == 5:   # unpacked repeated float
+                data = np.append(data if data is not None else np.zeros(0, "<f4"), np.frombuffer(v.to_bytes(4, "little"), "<f4"))
+            elif num == 7 and wt == 2:
+                for n2, w2, v2 in _proto.fields(v):
+                    if n2 == 1 and w2 == 2:   # packed int64 dims
+                        dims += _varints(v2)
+                    elif n2 == 1 and w2 == 0:
+                        dims.append(v2)
+            elif num in (1, 2, 3, 4) and wt == 0:
+                legacy[num] = v
+        if data is None:
+            data = np.zeros(0, "<f4")
+        if not dims and legacy:
+            dims = [legacy.get(k, 1) for k in (1, 2, 3, 4)]
+        return np.array(data, dtype=np.float32).reshape(dims) if dims and int(np.prod(dims)) == data.size else np.array(data, dtype=np.float32)
+
+    def _varints(mv):
+        vals, v, shift = [], 0, 0
+        for b in bytes(mv):
+            v |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                vals.append(v)
+                v, shift = 0, 0
+        return vals
+
+    for num, wt, v in _proto.fields(buf):
+        if wt != 2 or num not in (100, 2):
+            continue
+        name_field, blob_field = (1, 7) if num == 100 else (4, 6)
+        name, blobs = None, []
+        for n2, w2, v2 in _proto.fields(v):
+            if n2 == name_field and w2 == 2:
+                name = bytes(v2).decode()
+            elif n2 == blob_field and w2 == 2:
+                blobs.append(blob(v2))
+        if name is not None and blobs:
+            out[name] = blobs
+    return out
+
+
 def _pad16(c):
     return (c + 15) // 16 * 16
 
@@ -80,16 +147,28 @@ def _pad64(c):
 class PoseNet:
     """Random-weight instance of the network on one GPU."""
 
-    def __init__(self, ctx, seed=0):
+    def __init__(self, ctx, seed=0, caffemodel=None):
+        """caffemodel: path of the model's weights (pose_iter_440000.caffemodel of the COCO body model); None =
+        random weights from `seed` (He initialisation)."""
         import torch
         self.ctx, self.torch = ctx, torch
         self.device = ctx.device
         g = torch.Generator().manual_seed(seed)
+        blobs = read_caffemodel(caffemodel) if caffemodel else None
         self.weights = {}   # name -> (torch weight (cout, cin, k, k), bias (cout,)) float32 on the CPU
         self.packed = {}    # name -> (w [cout_pad][k][k][cin_pad], bias [cout_pad]) on the device
-        for name, ci, co, k, _ in all_layers():
-            wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))   # He initialisation
-            b = (torch.rand((co,), generator=g) - 0.5) * 0.1
+        for (name, ci, co, k, _), cname in zip(all_layers(), caffe_layer_names()):
+            if blobs is not None:
+                if cname not in blobs or len(blobs[cname]) < 2:
+                    raise ValueError("caffemodel %s has no weights for layer %s" % (caffemodel, cname))
+                wt = torch.from_numpy(np.ascontiguousarray(blobs[cname][0], dtype=np.float32).reshape(-1))
+                b = torch.from_numpy(np.ascontiguousarray(blobs[cname][1], dtype=np.float32).reshape(-1))
+                if wt.numel() != co * ci * k * k or b.numel() != co:
+                    raise ValueError("layer %s: expected %dx%dx%dx%d weights and %d biases, the file has %d and %d" % (cname, co, ci, k, k, co, wt.numel(), b.numel()))
+                wt = wt.reshape(co, ci, k, k)
+            else:
+                wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))   # He initialisation
+                b = (torch.rand((co,), generator=g) - 0.5) * 0.1
             self.weights[name] = (wt, b)
             cip = CAT_PAD if ci == CAT else _pad16(ci)
             wp = torch.zeros((_pad64(co), k, k, cip))
@@ -119,6 +198,23 @@ class PoseNet:
     def forward(self, net_input):
         """net_input: (n, 3, H, W) float32 on the device (CPM2Input's frames; H, W multiples of 8).
         Returns (n, H/8, W/8, 57) float32: heat maps 0..18, part-affinity planes 19..56."""
+        final = self.forward_raw(net_input)
+        return self.torch.cat([final[..., OFF_HEAT:OFF_HEAT + N_HEAT], final[..., OFF_PAF:OFF_PAF + N_PAF]], dim=3).contiguous()
+
+    def detect(self, net_input, max_peaks=64, nms_threshold=0.05):
+        """The whole CPM2 op (cpm2_kernel.cpp:46-49): network, `resize` layer (x8 bicubic up-sampling to the input
+        size) and `nms` layer.  Returns (cpm2_resized_map (n, 57, H, W), cpm2_joints (n, 18, max_peaks + 1, 3)),
+        the two columns CPM2Output consumes."""
+        n, _, H, W = net_input.shape
+        final = self.forward_raw(net_input)
+        chan = [OFF_HEAT + i for i in range(N_HEAT)] + [OFF_PAF + i for i in range(N_PAF)]
+        maps = self.ctx.cpm2_resize_maps(final, H, W, chan_map=chan)
+        joints = self.ctx.cpm2_nms(maps, parts=N_HEAT - 1, max_peaks=max_peaks, threshold=nms_threshold)
+        return maps, joints
+
+    def forward_raw(self, net_input):
+        """The network up to its last stage: the (n, H/8, W/8, 192) stage buffer [features | PAF 38 | heat maps 19 | pad]
+        whose PAF / heat-map slices are the outputs of stage 6."""
         torch = self.torch
         n, c, H, W = net_input.shape
         assert c == 3 and H % 8 == 0 and W % 8 == 0 and net_input.is_cuda and net_input.dtype == torch.float32
@@ -159,8 +255,7 @@ class PoseNet:
                         y, yoff = tmp[i & 1], 0
                     self._conv(name, x, xc, xoff, y, co, yoff, k, relu)
                     x, xc, xoff = y, y.shape[3], 0
-        final = cat[6 & 1]
-        return torch.cat([final[..., OFF_HEAT:OFF_HEAT + N_HEAT], final[..., OFF_PAF:OFF_PAF + N_PAF]], dim=3).contiguous()
+        return cat[6 & 1]
 
     # -- float32 reference on the same weights (tests, bench parity) ---------------------------------------
     def reference_forward(self, net_input, device=None):

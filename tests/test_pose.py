@@ -165,3 +165,142 @@ def test_cpm2_ops_through_the_kernel_classes():
     assert raw_h == raw_d
     for (hm, peaks, _), g in zip(cases, dev):
         np.testing.assert_array_equal(g, oracle.cpm2_connect_limbs_coco(hm, peaks, fh, fw))
+
+
+# ---- the `resize` and `nms` layers between the network and CPM2Output -----------------------------------------
+def test_resize_maps_oracle_known_answers():
+    """Properties the interpolation formula implies: a constant map stays constant (the cubic's weights sum to 1),
+    an affine ramp is reproduced in the interior (Catmull-Rom is exact on polynomials of degree <= 1 ... 3), and the
+    8x geometry puts output pixel 8k + 3.5 on source pixel k."""
+    const = np.full((2, 6, 9), 0.37, np.float32)
+    np.testing.assert_allclose(oracle.cpm2_resize_maps(const, 48, 72), 0.37, rtol=0, atol=1e-6)
+    yy, xx = np.mgrid[0:12, 0:15].astype(np.float32)
+    ramp = (0.25 * xx + 0.5 * yy)[None]
+    up = oracle.cpm2_resize_maps(ramp, 96, 120)
+    y, x = np.mgrid[0:96, 0:120]
+    expect = 0.25 * ((x - 3.5) / 8.) + 0.5 * ((y - 3.5) / 8.)
+    inner = (slice(None), slice(16, 80), slice(16, 104))
+    np.testing.assert_allclose(up[inner], expect[None][inner], atol=2e-5)
+    assert up.dtype == np.float32 and up.shape == (1, 96, 120)
+    # non-integer ratio: still a convex-ish interpolation of a bounded map (Catmull-Rom overshoot <= 12.5 % per axis)
+    rng = np.random.default_rng(3)
+    m = rng.random((1, 7, 5), dtype=np.float32)
+    r = oracle.cpm2_resize_maps(m, 23, 31)
+    assert r.min() > -0.3 and r.max() < 1.3
+
+
+def test_nms_oracle_known_answers():
+    m = np.zeros((2, 9, 11), np.float32)
+    m[0, 3, 4] = 0.9          # a peak
+    m[0, 3, 8] = 0.04         # below the threshold
+    m[0, 0, 5] = 0.8          # on the border: never a peak
+    m[0, 6, 2] = m[0, 6, 3] = 0.7   # plateau: neither exceeds the other
+    m[0, 7, 9] = 0.6
+    m[1, 1, 1] = 0.3
+    j = oracle.cpm2_nms(m, parts=2, max_peaks=4, threshold=0.05)
+    assert j.shape == (2, 5, 3)
+    np.testing.assert_array_equal(j[0, :3], np.array([[2, 0, 0], [4, 3, 0.9], [9, 7, 0.6]], np.float32))
+    np.testing.assert_array_equal(j[0, 3:], 0)
+    np.testing.assert_array_equal(j[1, :2], np.array([[1, 0, 0], [1, 1, 0.3]], np.float32))
+    # more peaks than max_peaks: the first ones in raster order, count capped
+    many = np.zeros((1, 20, 20), np.float32)
+    many[0, 1:19:2, 1:19:2] = np.linspace(0.1, 0.9, 81).reshape(9, 9)
+    j = oracle.cpm2_nms(many, parts=1, max_peaks=5, threshold=0.05)
+    assert j[0, 0, 0] == 5
+    np.testing.assert_array_equal(j[0, 1:, :2], [[1, 1], [3, 1], [5, 1], [7, 1], [9, 1]])
+
+
+def test_caffemodel_reader_round_trip(tmp_path):
+    """read_caffemodel on a file written with the wire-format helpers: current (`layer` = 100, shape message) and V1
+    (`layers` = 2, num/channels/height/width) layouts; layer names of the published prototxt."""
+    from scannertools_amd import _proto, pose_net
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((4, 3, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+
+    def blob_new(a):
+        return _proto.message(7, _proto.message(1, b"".join(_proto._varint(d) for d in a.shape))) + _proto.message(5, a.astype("<f4").tobytes())
+
+    def blob_v1(a):
+        dims = (list(a.shape) + [1, 1, 1])[:4] if a.ndim > 1 else [1, 1, 1, a.shape[0]]
+        return b"".join(_proto._varint(i + 1 << 3) + _proto._varint(d) for i, d in enumerate(dims)) + _proto.message(5, a.astype("<f4").tobytes())
+
+    new = _proto.message(1, b"net") + _proto.message(100, _proto.message(1, b"conv1_1") + _proto.message(2, b"Convolution") +
+                                                     _proto.message(7, blob_new(w)) + _proto.message(7, blob_new(b)))
+    old = _proto.message(2, _proto.message(4, b"conv1_1") + _proto.message(6, blob_v1(w)) + _proto.message(6, blob_v1(b)))
+    for name, buf in (("new", new), ("old", old)):
+        p = tmp_path / (name + ".caffemodel")
+        p.write_bytes(buf)
+        got = pose_net.read_caffemodel(str(p))
+        assert list(got) == ["conv1_1"]
+        np.testing.assert_array_equal(got["conv1_1"][0].reshape(w.shape), w)
+        np.testing.assert_array_equal(got["conv1_1"][1].reshape(-1), b)
+    with pytest.raises(ValueError):
+        list(_proto.fields(new[:-3]))   # truncated file
+    names = pose_net.caffe_layer_names()
+    assert len(names) == len(pose_net.all_layers()) == 92 and len(set(names)) == 92
+    assert names[12] == "conv5_1_CPM_L1" and names[-1] == "Mconv7_stage6_L2" and names[22] == "Mconv1_stage2_L1"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,C,th,tw,chan", [(2, 6, 9, 57, 48, 72, None), (1, 46, 82, 192, 368, 656, "pose"), (3, 7, 5, 8, 23, 31, [7, 0, 3]),
+                                                (1, 5, 5, 4, 5, 5, None), (1, 12, 16, 3, 6, 8, None)])
+def test_resize_maps_bit_exact(hip_ctx, n, h, w, C, th, tw, chan):
+    import torch
+    from scannertools_amd import pose_net
+    rng = np.random.default_rng(h * w + C)
+    maps = rng.standard_normal((n, h, w, C)).astype(np.float32)
+    if chan == "pose":
+        chan = [pose_net.OFF_HEAT + i for i in range(19)] + [pose_net.OFF_PAF + i for i in range(38)]
+    got = hip_ctx.cpm2_resize_maps(torch.from_numpy(maps).cuda(), th, tw, chan_map=chan).cpu().numpy()
+    sel = chan if chan is not None else list(range(C))
+    for i in range(n):
+        np.testing.assert_array_equal(got[i], oracle.cpm2_resize_maps(np.ascontiguousarray(maps[i].transpose(2, 0, 1)[sel]), th, tw))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,max_peaks,density", [(368, 656, 64, 0.0005), (368, 656, 64, 0.02), (37, 53, 8, 0.05), (3, 3, 4, 1.0), (2, 9, 4, 0.5),
+                                                  (64, 1030, 1024, 0.2)])
+def test_nms_bit_exact(hip_ctx, h, w, max_peaks, density):
+    """Sparse and dense peak populations (more than max_peaks in one 1024-pixel round, peaks on round boundaries,
+    plateaus, borders), rows of other lengths than the workgroup's round."""
+    import torch
+    rng = np.random.default_rng(h + w)
+    maps = (rng.random((2, 20, h, w)) * 0.04).astype(np.float32)
+    mask = rng.random(maps.shape) < density
+    maps[mask] = rng.random(int(mask.sum())).astype(np.float32)
+    maps[:, :, ::7, ::5] = np.float32(0.5)   # equal values: plateaus wherever two of them touch
+    got = hip_ctx.cpm2_nms(torch.from_numpy(maps).cuda(), parts=18, max_peaks=max_peaks, threshold=0.05).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], oracle.cpm2_nms(maps[i], 18, max_peaks, 0.05))
+    if h > 2 and density < 1:
+        assert got[:, :, 0, 0].max() > 0
+
+
+@pytest.mark.gpu
+def test_resize_nms_output_chain_recovers_planted_people(hip_ctx):
+    """Low-resolution maps with planted people -> resize x8 -> nms -> CPM2Output (limb scores on the GPU, assembly
+    on the host): everybody is found, and the chain equals the oracle's chain on the same low-resolution maps."""
+    import torch
+    H8, W8, people = 46, 82, 3
+    hm_lo, _, truth = synthetic_pose_maps(5, H8, W8, people, clutter=0, drop=0.0)
+    # joints become blobs in the part planes (the planted candidates of synthetic_pose_maps are not used)
+    hm_lo[:19] = 0
+    yy, xx = np.mgrid[0:H8, 0:W8]
+    for p in range(people):
+        for j in range(18):
+            hm_lo[j] += np.exp(-((xx - truth[p, j, 0]) ** 2 + (yy - truth[p, j, 1]) ** 2) / 1.5).astype(np.float32)
+    lo = torch.from_numpy(np.ascontiguousarray(hm_lo.transpose(1, 2, 0))[None]).cuda()
+    maps = hip_ctx.cpm2_resize_maps(lo, 8 * H8, 8 * W8)
+    joints = hip_ctx.cpm2_nms(maps, parts=18, max_peaks=64, threshold=0.05)
+    ref_maps = oracle.cpm2_resize_maps(hm_lo, 8 * H8, 8 * W8)
+    ref_joints = oracle.cpm2_nms(ref_maps, 18, 64, 0.05)
+    np.testing.assert_array_equal(maps[0].cpu().numpy(), ref_maps)
+    np.testing.assert_array_equal(joints[0].cpu().numpy(), ref_joints)
+    scores = hip_ctx.cpm2_limb_scores(maps, joints).cpu().numpy()
+    got = oracle.cpm2_connect_limbs_coco(ref_maps, ref_joints, 8 * H8, 8 * W8, scores=scores[0])
+    assert got.shape[0] == people
+    for p in range(people):
+        d = np.abs(got[:, 1, :2] - (truth[p, 1] * 8 + 3.5)).sum(axis=1)
+        person = got[int(d.argmin())]
+        assert np.abs(person[:, :2] - (truth[p] * 8 + 3.5)).max() < 8.0 and (person[:, 2] > 0).all()

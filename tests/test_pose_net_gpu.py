@@ -106,3 +106,64 @@ def test_pose_network_end_to_end(hip_ctx):
     assert scale > 1e-3
     assert float((got - ref).abs().max()) <= 1e-3 * scale, (float((got - ref).abs().max()), scale)
     assert pose_net.flops(368, 656) > 4e11 and len(pose_net.all_layers()) == 92
+
+
+def test_whole_pose_pipeline_through_the_engine(hip_ctx):
+    """frames -> CPM2Input -> CPM2 (network + resize + nms, random weights) -> CPM2Output -> poses, as one graph
+    (the op chain of the reference's pose pipeline: cpm2_input_kernel_gpu.cpp:184, cpm2_kernel.cpp:46-52,
+    cpm2_output_kernel_cpu.cpp:805-810).  Checked link by link: the op's two columns equal the oracle's `resize`
+    and `nms` restatements applied to the network's own output, and the poses equal the oracle's assembly of those
+    columns."""
+    import oracle
+    from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+    from util import random_frames
+    frames = random_frames(11, 3, 135, 240)
+    scale = 64 / 135.
+    sc = Client()
+    sc.ingest_frames("v", frames)
+    frame = sc.io.Input([NamedVideoStream(sc, "v")])
+    net_in = sc.ops.CPM2Input(frame=frame, scale=scale, device=DeviceType.GPU, batch=2)
+    maps_col, joints_col = sc.ops.CPM2(cpm2_input=net_in, seed=4, batch=2)
+    poses = sc.ops.CPM2Output(cpm2_resized_map=maps_col, cpm2_joints=joints_col, original_frame_info=sc.ops.InfoFromFrame(frame=frame),
+                              scale=scale, device=DeviceType.GPU, batch=2)
+    out = NamedStream(sc, "poses")
+    sc.run(sc.io.Output(poses, [out]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    got = list(out.load())
+    assert len(got) == 3
+
+    net = pose_net.PoseNet(hip_ctx, seed=4)
+    x = torch.from_numpy(np.stack([oracle.cpm2_input(f, scale) for f in frames])).cuda()
+    low = net.forward(x).cpu().numpy()                       # (n, h/8, w/8, 57)
+    maps, joints = net.detect(x)
+    H, W = x.shape[2], x.shape[3]
+    for i in range(3):
+        ref_maps = oracle.cpm2_resize_maps(np.ascontiguousarray(low[i].transpose(2, 0, 1)), H, W)
+        np.testing.assert_array_equal(maps[i].cpu().numpy(), ref_maps)
+        ref_joints = oracle.cpm2_nms(ref_maps, 18, 64, 0.05)
+        np.testing.assert_array_equal(joints[i].cpu().numpy(), ref_joints)
+        np.testing.assert_array_equal(got[i], oracle.cpm2_connect_limbs_coco(ref_maps, ref_joints, 135, 240))
+    assert float(joints[:, :, 0, 0].max()) > 0   # the random network does produce candidates
+
+
+def test_pose_net_loads_a_caffemodel(hip_ctx, tmp_path):
+    """PoseNet(caffemodel=...) == PoseNet with the same weights set directly: a complete 92-layer file written with
+    the wire-format helpers (tiny spatial check, the weights are what is being tested)."""
+    from scannertools_amd import _proto
+    a = pose_net.PoseNet(hip_ctx, seed=6)
+
+    def blob(arr):
+        return _proto.message(7, _proto.message(1, b"".join(_proto._varint(d) for d in arr.shape))) + _proto.message(5, arr.astype("<f4").tobytes())
+
+    buf = bytearray(_proto.message(1, b"pose"))
+    for (name, *_), cname in zip(pose_net.all_layers(), pose_net.caffe_layer_names()):
+        wt, b = a.weights[name]
+        buf += _proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
+                              _proto.message(7, blob(wt.numpy())) + _proto.message(7, blob(b.numpy())))
+    path = tmp_path / "pose.caffemodel"
+    path.write_bytes(bytes(buf))
+    b_net = pose_net.PoseNet(hip_ctx, caffemodel=str(path))
+    x = (torch.rand((1, 3, 16, 24), generator=torch.Generator().manual_seed(1)) - 0.5).cuda()
+    assert torch.equal(a.forward(x), b_net.forward(x))
+    path.write_bytes(bytes(buf[:len(buf) // 2]))
+    with pytest.raises(ValueError):
+        pose_net.PoseNet(hip_ctx, caffemodel=str(path))
