@@ -210,8 +210,15 @@ struct EngineKernel {
 
 struct EngineOutputs {
   DeviceHandle device;
-  Elements elements;  // one per input row
+  Elements elements;            // first output column: one element per input row
+  std::vector<Elements> extra;  // further output columns of ops that declare several (CPM2)
 };
+
+Element* output_at(EngineOutputs* o, int col, int i) {
+  if (!o || col < 0 || i < 0) return nullptr;
+  Elements* e = col == 0 ? &o->elements : (col - 1 < (int)o->extra.size() ? &o->extra[col - 1] : nullptr);
+  return e && i < (int)e->size() ? &(*e)[i] : nullptr;
+}
 
 double g_last_execute_seconds = 0.0;  // wall time spent inside execute() by the last stshim_run_frames
 
@@ -333,7 +340,9 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
   for (int r0 = 0; r0 < n; r0 += batch) {
     const auto t_begin = std::chrono::steady_clock::now();
     const int nb = std::min(batch, n - r0);
-    BatchedElements out_cols(1);
+    const size_t n_out = ek->op && ek->op->outputs.size() > 1 ? ek->op->outputs.size() : 1;
+    BatchedElements out_cols(n_out);
+    outs->extra.resize(n_out - 1);
     switch (ek->reg.kind) {
       case KernelKind::Batched: {
         BatchedElements in(1);
@@ -367,13 +376,15 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
       }
     }
     g_last_execute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    if ((int)out_cols[0].size() != nb) {
-      set_err(err, err_len, "kernel produced " + std::to_string(out_cols[0].size()) + " outputs for " + std::to_string(nb) + " rows");
-      for (auto& e : out_cols[0]) outs->elements.push_back(e);
-      // fall through to cleanup by the caller
-      return outs;
-    }
     for (auto& e : out_cols[0]) outs->elements.push_back(e);
+    for (size_t c = 1; c < n_out; ++c)
+      for (auto& e : out_cols[c]) outs->extra[c - 1].push_back(e);
+    for (size_t c = 0; c < n_out; ++c)
+      if ((int)out_cols[c].size() != nb) {
+        set_err(err, err_len, "kernel produced " + std::to_string(out_cols[c].size()) + " outputs in column " + std::to_string(c) + " for " +
+                                  std::to_string(nb) + " rows");
+        return outs;  // the caller frees what was produced
+      }
   }
   return outs;
 }
@@ -435,10 +446,12 @@ SHIM_EXPORT void* stshim_run_columns(void* k, int n_cols, int n, const void* con
 
 SHIM_EXPORT int stshim_outputs_count(void* o) { return o ? (int)((EngineOutputs*)o)->elements.size() : 0; }
 
-SHIM_EXPORT int stshim_output_get(void* o, int i, const void** data, size_t* size, int* is_frame, int* shape3, int* type) {
-  auto* outs = (EngineOutputs*)o;
-  if (!outs || i < 0 || i >= (int)outs->elements.size()) return 1;
-  Element& e = outs->elements[i];
+SHIM_EXPORT int stshim_outputs_columns(void* o) { return o ? 1 + (int)((EngineOutputs*)o)->extra.size() : 0; }
+
+SHIM_EXPORT int stshim_output_get_col(void* o, int col, int i, const void** data, size_t* size, int* is_frame, int* shape3, int* type) {
+  Element* ep = output_at((EngineOutputs*)o, col, i);
+  if (!ep) return 1;
+  Element& e = *ep;
   if (e.is_frame) {
     Frame* f = e.as_frame();
     if (data) *data = f->data;
@@ -453,22 +466,32 @@ SHIM_EXPORT int stshim_output_get(void* o, int i, const void** data, size_t* siz
   return 0;
 }
 
-SHIM_EXPORT int stshim_output_copy(void* o, int i, void* dst_host, size_t n) {
+SHIM_EXPORT int stshim_output_get(void* o, int i, const void** data, size_t* size, int* is_frame, int* shape3, int* type) {
+  return stshim_output_get_col(o, 0, i, data, size, is_frame, shape3, type);
+}
+
+SHIM_EXPORT int stshim_output_copy_col(void* o, int col, int i, void* dst_host, size_t n) {
   auto* outs = (EngineOutputs*)o;
   const void* p = nullptr;
   size_t sz = 0;
-  if (stshim_output_get(o, i, &p, &sz, nullptr, nullptr, nullptr) || n > sz) return 1;
+  if (stshim_output_get_col(o, col, i, &p, &sz, nullptr, nullptr, nullptr) || n > sz) return 1;
   memcpy_buffer((u8*)dst_host, CPU_DEVICE, (const u8*)p, outs->device, n);
   return 0;
 }
 
+SHIM_EXPORT int stshim_output_copy(void* o, int i, void* dst_host, size_t n) { return stshim_output_copy_col(o, 0, i, dst_host, n); }
+
 SHIM_EXPORT void stshim_outputs_free(void* o) {
   auto* outs = (EngineOutputs*)o;
   if (!outs) return;
-  for (auto& e : outs->elements) {
-    if (e.is_frame) delete_frame(outs->device, e.as_frame());
-    else if (e.buffer) delete_buffer(outs->device, e.buffer);
-  }
+  auto drop = [&](Elements& col) {
+    for (auto& e : col) {
+      if (e.is_frame) delete_frame(outs->device, e.as_frame());
+      else if (e.buffer) delete_buffer(outs->device, e.buffer);
+    }
+  };
+  drop(outs->elements);
+  for (auto& col : outs->extra) drop(col);
   delete outs;
 }
 

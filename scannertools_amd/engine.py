@@ -89,6 +89,9 @@ def _load_op_library(path):
         L.stshim_output_get.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ci),
                                         ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.stshim_output_copy.argtypes = [vp, ci, vp, sz]
+        L.stshim_outputs_columns.argtypes = [vp]
+        L.stshim_output_get_col.argtypes = [vp, ci] + list(L.stshim_output_get.argtypes[1:])
+        L.stshim_output_copy_col.argtypes = [vp, ci, ci, vp, sz]
         L.stshim_outputs_free.argtypes = [vp]
         L.stshim_live_buffers.restype = sz
         L.stshim_last_execute_seconds.restype = ctypes.c_double
@@ -245,8 +248,10 @@ class _CppOpNode(_Node):
                         L.stshim_outputs_free(res)
                     raise RuntimeError("op %s failed: %s" % (self.name, err.value.decode()))
                 try:
+                    ncols = L.stshim_outputs_columns(res)
                     for r in range(a, b + 1):
-                        out[r] = self._fetch(L, res, r - lo)
+                        # ops with several output columns (CPM2) yield a tuple per row; _CppOpColumn picks one
+                        out[r] = self._fetch(L, res, r - lo) if ncols == 1 else tuple(self._fetch(L, res, r - lo, c) for c in range(ncols))
                 finally:
                     L.stshim_outputs_free(res)
         finally:
@@ -254,22 +259,43 @@ class _CppOpNode(_Node):
         return [out[r] for r in idx]
 
     @staticmethod
-    def _fetch(L, res, i):
+    def _fetch(L, res, i, col=0):
         data, size = ctypes.c_void_p(), ctypes.c_size_t()
         isf, typ = ctypes.c_int(), ctypes.c_int()
         shape = (ctypes.c_int * 3)()
-        if L.stshim_output_get(res, i, ctypes.byref(data), ctypes.byref(size), ctypes.byref(isf), shape, ctypes.byref(typ)):
-            raise RuntimeError("missing output row %d" % i)
+        if L.stshim_output_get_col(res, col, i, ctypes.byref(data), ctypes.byref(size), ctypes.byref(isf), shape, ctypes.byref(typ)):
+            raise RuntimeError("missing output row %d of column %d" % (i, col))
         if isf.value:
             arr = np.empty((shape[0], shape[1], shape[2]), dtype=_FRAME_DTYPES[typ.value])
             assert arr.nbytes == size.value
-            if L.stshim_output_copy(res, i, arr.ctypes.data_as(ctypes.c_void_p), size.value):
+            if L.stshim_output_copy_col(res, col, i, arr.ctypes.data_as(ctypes.c_void_p), size.value):
                 raise RuntimeError("copying output row %d failed" % i)
             return arr
         buf = ctypes.create_string_buffer(size.value)
-        if L.stshim_output_copy(res, i, buf, size.value):
+        if L.stshim_output_copy_col(res, col, i, buf, size.value):
             raise RuntimeError("copying output row %d failed" % i)
         return buf.raw
+
+
+class _CppOpColumn(_Node):
+    """One output column of a C++ op that declares several (the rows of the op are tuples)."""
+
+    def __init__(self, node, col):
+        self.node, self.col = node, col
+        self._cache = (None, None)
+
+    def length(self):
+        return self.node.length()
+
+    def rows(self, idx):
+        if not idx:
+            return []
+        shared = self.node.__dict__.setdefault("_rows_cache", {})
+        key = tuple(idx)
+        if key not in shared:
+            shared.clear()
+            shared[key] = self.node.rows(list(idx))
+        return [r[self.col] for r in shared[key]]
 
 
 class _FrameInfoNode(_Node):
@@ -593,9 +619,16 @@ class _Ops:
         from . import _proto
         return _CppOpNode(self.sc, "CPM2Input", frame, device, batch, None, _proto.encode([(2, "float", float(scale))]))
 
-    def CPM2(self, cpm2_input, weights=None, seed=0, batch=8, max_peaks=64, nms_threshold=0.05):
+    def CPM2(self, cpm2_input, weights=None, seed=0, batch=8, max_peaks=64, nms_threshold=0.05, device=None):
         """sc.ops.CPM2(cpm2_input=...) (cpm2_kernel.cpp:46-52): returns the columns (cpm2_resized_map, cpm2_joints).
-        `weights`: path of the model's caffemodel; None = random weights (architecture only)."""
+        `weights`: path of the model's caffemodel -> the registered C++ kernel class (CPM2KernelHIP, the drop-in; args
+        CPM2Args{caffe_args{net_descriptor{model_weights_path}}}); None -> the same layer sequence driven from Python
+        (PoseNet) with random weights from `seed`, for exercising the architecture without a model file."""
+        if weights is not None:
+            from . import _proto
+            args = _proto.message(1, _proto.message(1, _proto.encode([(2, "string", str(weights))])))
+            node = _CppOpNode(self.sc, "CPM2", cpm2_input, device, batch, None, args)
+            return _CppOpColumn(node, 0), _CppOpColumn(node, 1)
         op = _PoseNetOp(self.sc, cpm2_input, weights, seed, batch, max_peaks, nms_threshold)
         return _PoseNetColumn(op, 0), _PoseNetColumn(op, 1)
 

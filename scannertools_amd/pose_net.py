@@ -222,7 +222,6 @@ class PoseNet:
         self.ctx._bind()
         self.ctx._check(self.ctx._L.st_planar_to_nhwc_f32(self.ctx._h, ctypes.c_void_p(net_input.contiguous().data_ptr()), n, 3, H, W,
                                                           ctypes.c_void_p(x.data_ptr()), 16))
-        cur_c = 3
         cat = [torch.zeros((n, H // 8, W // 8, CAT_PAD), dtype=torch.float32, device=self.device) for _ in range(2)]
         for l in TRUNK:
             if l == "pool":
@@ -230,15 +229,16 @@ class PoseNet:
                 continue
             name, ci, co, k, relu = l
             if name == "conv4_4_CPM":
-                y, yoff = cat[0], OFF_FEAT               # the features go straight into the stage-input buffer
-            else:
-                y, yoff = torch.zeros((x.shape[0], x.shape[1], x.shape[2], _pad16(co)), dtype=torch.float32, device=self.device), 0
-            self._conv(name, x, x.shape[3], 0, y, co, yoff, k, relu)
-            x, cur_c = y, co
-        cat[1][..., OFF_FEAT:OFF_FEAT + N_FEAT] = cat[0][..., OFF_FEAT:OFF_FEAT + N_FEAT]
+                # the features go straight into BOTH stage-input buffers (stage s reads buffer (s - 1) & 1)
+                for t in range(2):
+                    self._conv(name, x, x.shape[3], 0, cat[t], co, OFF_FEAT, k, relu)
+                break
+            y = torch.empty((x.shape[0], x.shape[1], x.shape[2], _pad16(co)), dtype=torch.float32, device=self.device)
+            self._conv(name, x, x.shape[3], 0, y, co, 0, k, relu)
+            x = y
         h8, w8 = H // 8, W // 8
-        tmp = [torch.zeros((n, h8, w8, 128), dtype=torch.float32, device=self.device) for _ in range(2)]
-        wide = torch.zeros((n, h8, w8, 512), dtype=torch.float32, device=self.device)
+        tmp = [torch.empty((n, h8, w8, 128), dtype=torch.float32, device=self.device) for _ in range(2)]
+        wide = torch.empty((n, h8, w8, 512), dtype=torch.float32, device=self.device)
         for st in range(1, 7):
             src, dst = cat[(st - 1) & 1], cat[st & 1]
             for br, nout, boff in (("L1", N_PAF, OFF_PAF), ("L2", N_HEAT, OFF_HEAT)):

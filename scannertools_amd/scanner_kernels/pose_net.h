@@ -1,0 +1,277 @@
+// The CPM2 op's network (OpenPose COCO body model) as a sequence of C-ABI layer calls: what the Caffe forward pass
+// behind CaffeKernel::execute computes for /root/reference/scannertools_caffe/scannertools_caffe_cpp/cpm2_kernel.cpp:8-52.
+// C++ twin of scannertools_amd/pose_net.py (same layer list, same buffer layout, same call order, hence the same bits):
+//   trunk   conv1_1 .. conv4_2 (VGG-19 head), conv4_3_CPM, conv4_4_CPM -> 128 feature channels at 1/8 resolution
+//   stage 1 two branches (L1: 38 part-affinity planes, L2: 19 heat maps): 3 x (3x3, 128) + 1x1 512 + 1x1 out
+//   stage 2..6 on concat(L1, L2, features) = 185 channels: 5 x (7x7, 128) + 1x1 128 + 1x1 out
+// The layer list is the published pose_deploy_linevec.prototxt ([EXT]: the reference downloads prototxt and
+// caffemodel at run time, openpose_kernel.cpp:35-78; neither is in its tree); weights come from the caffemodel the
+// op's arguments name (CPM2Args.caffe_args.net_descriptor.model_weights_path).
+// Layout: activations NHWC float32; the stage input lives in ONE 192-channel buffer [features 128 | L1 38 | L2 19 |
+// 7 zero] the branches write their slices of (no concat pass); the first layer of stages 2..6 has its input
+// channels permuted accordingly.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "proto_lite.h"
+#include "scannertools_hip.h"
+
+namespace scanner {
+namespace pose {
+
+constexpr int kPaf = 38, kHeat = 19, kFeat = 128, kCat = kPaf + kHeat + kFeat, kCatPad = 192;
+constexpr int kOffFeat = 0, kOffPaf = kFeat, kOffHeat = kFeat + kPaf;
+
+struct LayerSpec {
+  std::string name;  // name in the prototxt / caffemodel
+  int cin, cout, k, relu;
+};
+
+inline std::vector<LayerSpec> trunk_layers() {
+  return {{"conv1_1", 3, 64, 3, 1},   {"conv1_2", 64, 64, 3, 1},      {"conv2_1", 64, 128, 3, 1},     {"conv2_2", 128, 128, 3, 1},
+          {"conv3_1", 128, 256, 3, 1}, {"conv3_2", 256, 256, 3, 1},    {"conv3_3", 256, 256, 3, 1},    {"conv3_4", 256, 256, 3, 1},
+          {"conv4_1", 256, 512, 3, 1}, {"conv4_2", 512, 512, 3, 1},    {"conv4_3_CPM", 512, 256, 3, 1}, {"conv4_4_CPM", 256, 128, 3, 1}};
+}
+// pooling follows these trunk layers (index into trunk_layers())
+inline bool pool_after(int i) { return i == 1 || i == 3 || i == 7; }
+
+inline std::vector<LayerSpec> branch_layers(int stage, int branch /*1 | 2*/) {
+  const int out = branch == 1 ? kPaf : kHeat;
+  std::vector<LayerSpec> l;
+  char buf[64];
+  if (stage == 1) {
+    const int ci[5] = {128, 128, 128, 128, 512}, co[5] = {128, 128, 128, 512, out}, k[5] = {3, 3, 3, 1, 1};
+    for (int i = 0; i < 5; ++i) {
+      snprintf(buf, sizeof buf, "conv5_%d_CPM_L%d", i + 1, branch);
+      l.push_back({buf, ci[i], co[i], k[i], i < 4});
+    }
+  } else {
+    for (int i = 0; i < 7; ++i) {
+      snprintf(buf, sizeof buf, "Mconv%d_stage%d_L%d", i + 1, stage, branch);
+      l.push_back({buf, i == 0 ? kCat : 128, i == 6 ? out : 128, i < 5 ? 7 : 1, i < 6});
+    }
+  }
+  return l;
+}
+
+// ---- caffemodel ------------------------------------------------------------------------------------------
+// NetParameter wire format ([EXT] caffe.proto): layer = 100 (LayerParameter: name = 1, blobs = 7) or the V1
+// `layers` = 2 (name = 4, blobs = 6); BlobProto: data = 5 (packed float).  Only the float payloads are needed:
+// the shapes are the architecture's.
+struct Blobs {
+  std::vector<float> w, b;
+};
+
+inline bool read_file(const std::string& path, std::string* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n >= 0 && fread(&(*out)[0], 1, out->size(), f) == out->size();
+  fclose(f);
+  return ok;
+}
+
+inline bool blob_floats(const std::string& blob, std::vector<float>* out) {
+  std::vector<proto_lite::Field> fs;
+  if (!proto_lite::parse((const uint8_t*)blob.data(), blob.size(), &fs)) return false;
+  out->clear();
+  for (auto& f : fs) {
+    if (f.number != 5) continue;
+    if (f.wire == 2) {
+      const size_t n = f.bytes.size() / 4, at = out->size();
+      out->resize(at + n);
+      memcpy(out->data() + at, f.bytes.data(), n * 4);
+    } else if (f.wire == 5) {
+      out->push_back(proto_lite::as_float(f));
+    }
+  }
+  return true;
+}
+
+inline bool read_caffemodel(const std::string& path, std::map<std::string, Blobs>* out, std::string* err) {
+  std::string buf;
+  if (!read_file(path, &buf)) { *err = "cannot read " + path; return false; }
+  std::vector<proto_lite::Field> top;
+  if (!proto_lite::parse((const uint8_t*)buf.data(), buf.size(), &top)) { *err = path + " is not a serialized NetParameter"; return false; }
+  for (auto& f : top) {
+    if (f.wire != 2 || (f.number != 100 && f.number != 2)) continue;
+    const uint32_t name_field = f.number == 100 ? 1 : 4, blob_field = f.number == 100 ? 7 : 6;
+    std::vector<proto_lite::Field> lf;
+    if (!proto_lite::parse((const uint8_t*)f.bytes.data(), f.bytes.size(), &lf)) { *err = "malformed layer in " + path; return false; }
+    std::string name;
+    std::vector<const std::string*> blobs;
+    for (auto& g : lf) {
+      if (g.number == name_field && g.wire == 2) name = g.bytes;
+      else if (g.number == blob_field && g.wire == 2) blobs.push_back(&g.bytes);
+    }
+    if (name.empty() || blobs.size() < 2) continue;
+    Blobs bl;
+    if (!blob_floats(*blobs[0], &bl.w) || !blob_floats(*blobs[1], &bl.b)) { *err = "malformed blob in layer " + name; return false; }
+    (*out)[name] = std::move(bl);
+  }
+  return true;
+}
+
+// ---- the network on one GPU ---------------------------------------------------------------------------------
+class Net {
+ public:
+  ~Net() { release(); }
+
+  // Loads the weights, packs them as [cout_pad][k][k][cin_pad] and uploads them to the current device.
+  bool load(const std::string& caffemodel, std::string* err) {
+    std::map<std::string, Blobs> blobs;
+    if (!read_caffemodel(caffemodel, &blobs, err)) return false;
+    std::vector<LayerSpec> all = trunk_layers();
+    for (int st = 1; st <= 6; ++st)
+      for (int br = 1; br <= 2; ++br)
+        for (auto& l : branch_layers(st, br)) all.push_back(l);
+    for (auto& l : all) {
+      auto it = blobs.find(l.name);
+      if (it == blobs.end()) { *err = "caffemodel " + caffemodel + " has no weights for layer " + l.name; return false; }
+      const Blobs& bl = it->second;
+      if (bl.w.size() != (size_t)l.cout * l.cin * l.k * l.k || bl.b.size() != (size_t)l.cout) {
+        *err = "layer " + l.name + ": the file's blob sizes do not match the architecture";
+        return false;
+      }
+      const int cip = l.cin == kCat ? kCatPad : (l.cin + 15) / 16 * 16, cop = (l.cout + 63) / 64 * 64;
+      std::vector<float> wp((size_t)cop * l.k * l.k * cip, 0.f), bp(cop, 0.f);
+      for (int o = 0; o < l.cout; ++o) {
+        bp[o] = bl.b[o];
+        for (int c = 0; c < l.cin; ++c) {
+          // stage-input channel order of the prototxt is (L1 38, L2 19, features 128); the buffer holds the features first
+          const int cb = l.cin == kCat ? (c < kPaf + kHeat ? kFeat + c : c - (kPaf + kHeat)) : c;
+          for (int kk = 0; kk < l.k * l.k; ++kk)
+            wp[((size_t)o * l.k * l.k + kk) * cip + cb] = bl.w[((size_t)o * l.cin + c) * l.k * l.k + kk];
+        }
+      }
+      Packed p;
+      p.cin_pad = cip; p.cout_pad = cop;
+      if (hipMalloc(&p.w, wp.size() * 4) != hipSuccess || hipMalloc(&p.b, bp.size() * 4) != hipSuccess ||
+          hipMemcpy(p.w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(p.b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "out of device memory while uploading layer " + l.name;
+        return false;
+      }
+      packed_[l.name] = p;
+    }
+    return true;
+  }
+
+  // inputs: n device pointers to planar (3, H, W) float32 frames (CPM2Input's output); H, W multiples of 8.
+  // Returns the stage buffer (n, H/8, W/8, 192) holding stage 6's outputs at channels kOffPaf.. / kOffHeat.. (device
+  // memory owned by the net, valid until the next call), or nullptr with *err set.
+  const float* forward(st_ctx* ctx, const float* const* inputs, int n, int H, int W, std::string* err) {
+    if (n <= 0 || H % 8 || W % 8) { *err = "pose net: the network input must be a multiple of 8 in both dimensions"; return nullptr; }
+    if (!reserve(n, H, W, err)) return nullptr;
+    auto fail = [&](const char* what) { *err = std::string(what) + ": " + st_ctx_last_error(ctx); return (const float*)nullptr; };
+    for (int i = 0; i < n; ++i)
+      if (st_planar_to_nhwc_f32(ctx, inputs[i], 1, 3, H, W, a_ + (size_t)i * H * W * 16, 16) != ST_OK) return fail("st_planar_to_nhwc_f32");
+    float *x = a_, *y = b_;
+    int h = H, w = W, xc = 16;
+    const auto trunk = trunk_layers();
+    for (int i = 0; i < (int)trunk.size(); ++i) {
+      const LayerSpec& l = trunk[i];
+      const Packed& p = packed_[l.name];
+      if (i == (int)trunk.size() - 1) {
+        // conv4_4_CPM: the features go straight into BOTH stage buffers (stage s reads buffer (s-1)&1)
+        for (int t = 0; t < 2; ++t)
+          if (st_conv2d_nhwc_f32(ctx, x, n, h, w, xc, xc, 0, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, cat_[t], kCatPad, kOffFeat) != ST_OK)
+            return fail("st_conv2d_nhwc_f32");
+        break;
+      }
+      const int yc = (l.cout + 15) / 16 * 16;
+      if (st_conv2d_nhwc_f32(ctx, x, n, h, w, xc, xc, 0, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, yc, 0) != ST_OK) return fail("st_conv2d_nhwc_f32");
+      std::swap(x, y);
+      xc = yc;
+      if (pool_after(i)) {
+        if (st_maxpool2_nhwc_f32(ctx, x, n, h, w, xc, xc, y, xc) != ST_OK) return fail("st_maxpool2_nhwc_f32");
+        std::swap(x, y);
+        h /= 2; w /= 2;
+      }
+    }
+    for (int st = 1; st <= 6; ++st) {
+      const float* src = cat_[(st - 1) & 1];
+      float* dst = cat_[st & 1];
+      for (int br = 1; br <= 2; ++br) {
+        const auto layers = branch_layers(st, br);
+        const float* xin = src;
+        int xs = kCatPad, xcin = st == 1 ? kFeat : kCatPad, xoff = st == 1 ? kOffFeat : 0;
+        for (int i = 0; i < (int)layers.size(); ++i) {
+          const LayerSpec& l = layers[i];
+          const Packed& p = packed_[l.name];
+          float* yout;
+          int ys, yoff;
+          if (i == (int)layers.size() - 1) { yout = dst; ys = kCatPad; yoff = br == 1 ? kOffPaf : kOffHeat; }
+          else if (l.cout == 512) { yout = wide_; ys = 512; yoff = 0; }
+          else { yout = tmp_[i & 1]; ys = 128; yoff = 0; }
+          if (st_conv2d_nhwc_f32(ctx, xin, n, h, w, xcin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, yout, ys, yoff) != ST_OK)
+            return fail("st_conv2d_nhwc_f32");
+          xin = yout; xs = ys; xcin = ys; xoff = 0;
+        }
+      }
+    }
+    return cat_[6 & 1];
+  }
+
+ private:
+  struct Packed {
+    float* w = nullptr;
+    float* b = nullptr;
+    int cin_pad = 0, cout_pad = 0;
+  };
+
+  bool reserve(int n, int H, int W, std::string* err) {
+    const size_t big = (size_t)n * H * W * 64, small = (size_t)n * (H / 8) * (W / 8);
+    if (big <= cap_big_ && small <= cap_small_) return true;
+    free_buffers();
+    auto alloc = [&](float** p, size_t floats) { return hipMalloc(p, floats * 4) == hipSuccess; };
+    // the largest trunk activation is conv1's (64 channels at full resolution)
+    if (!alloc(&a_, big) || !alloc(&b_, big) || !alloc(&cat_[0], small * kCatPad) || !alloc(&cat_[1], small * kCatPad) ||
+        !alloc(&tmp_[0], small * 128) || !alloc(&tmp_[1], small * 128) || !alloc(&wide_, small * 512)) {
+      free_buffers();
+      *err = "pose net: out of device memory for a batch of " + std::to_string(n) + " frames";
+      return false;
+    }
+    // the 7 pad channels of the stage buffers are read (against zero weights) and never written: zero them once
+    if (hipMemset(cat_[0], 0, small * kCatPad * 4) != hipSuccess || hipMemset(cat_[1], 0, small * kCatPad * 4) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {  // the layer calls run on the context's own (non-blocking) stream
+      *err = "pose net: hipMemset failed";
+      return false;
+    }
+    cap_big_ = big; cap_small_ = small;
+    return true;
+  }
+  void free_buffers() {
+    float** all[] = {&a_, &b_, &cat_[0], &cat_[1], &tmp_[0], &tmp_[1], &wide_};
+    for (auto p : all) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    cap_big_ = cap_small_ = 0;
+  }
+  void release() {
+    free_buffers();
+    for (auto& kv : packed_) {
+      if (kv.second.w) (void)hipFree(kv.second.w);
+      if (kv.second.b) (void)hipFree(kv.second.b);
+    }
+    packed_.clear();
+  }
+
+  std::map<std::string, Packed> packed_;
+  float *a_ = nullptr, *b_ = nullptr, *cat_[2] = {nullptr, nullptr}, *tmp_[2] = {nullptr, nullptr}, *wide_ = nullptr;
+  size_t cap_big_ = 0, cap_small_ = 0;
+};
+
+}  // namespace pose
+}  // namespace scanner

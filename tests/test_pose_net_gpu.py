@@ -162,8 +162,38 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, tmp_path):
     path = tmp_path / "pose.caffemodel"
     path.write_bytes(bytes(buf))
     b_net = pose_net.PoseNet(hip_ctx, caffemodel=str(path))
-    x = (torch.rand((1, 3, 16, 24), generator=torch.Generator().manual_seed(1)) - 0.5).cuda()
+    x = (torch.rand((3, 3, 16, 24), generator=torch.Generator().manual_seed(1)) - 0.5).cuda()
     assert torch.equal(a.forward(x), b_net.forward(x))
+
+    # the registered kernel classes (CPM2KernelHIP on DeviceType::GPU, its staged twin on DeviceType::CPU) read the
+    # same file and produce the same two columns as PoseNet.detect, bit for bit
+    from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, PerfParams
+    maps, joints = a.detect(x)
+
+    class _Rows:
+        def __init__(self, rows):
+            self.rows_ = rows
+
+        def length(self):
+            return len(self.rows_)
+
+        def rows(self, idx):
+            return [self.rows_[i] for i in idx]
+
+    for device in (DeviceType.GPU, DeviceType.CPU):
+        sc = Client()
+        src = _Rows([f for f in (x if device == DeviceType.GPU else x.cpu().numpy())])
+        m_col, j_col = sc.ops.CPM2(cpm2_input=src, weights=str(path), device=device, batch=2)
+        om, oj = NamedStream(sc, "maps"), NamedStream(sc, "joints")
+        sc.run([sc.io.Output(m_col, [om]), sc.io.Output(j_col, [oj])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        for i, (m, j) in enumerate(zip(om.load(), oj.load())):
+            np.testing.assert_array_equal(m, maps[i].cpu().numpy())
+            np.testing.assert_array_equal(j, joints[i].cpu().numpy())
+
     path.write_bytes(bytes(buf[:len(buf) // 2]))
     with pytest.raises(ValueError):
         pose_net.PoseNet(hip_ctx, caffemodel=str(path))
+    with pytest.raises(RuntimeError, match="CPM2"):
+        sc = Client()
+        m_col, _ = sc.ops.CPM2(cpm2_input=_Rows([x[0]]), weights=str(path), device=DeviceType.GPU)
+        sc.run(sc.io.Output(m_col, [NamedStream(sc, "m")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
