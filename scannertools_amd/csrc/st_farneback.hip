@@ -1417,6 +1417,9 @@ __global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
 #ifndef ST_ABLATE
 #define ST_ABLATE 0
 #endif
+#ifndef ST_EXP_D
+#define ST_EXP_D 1  // gather queue depth of k_flow_iter3 (experiments)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // One full Farneback iteration without materialising M:
@@ -1701,7 +1704,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   for (int ybase = y0; ybase < y1; ybase += F3_RING) {
     // anchor rows 32 j > 0: the column sums restart from the fresh sum of the 15 window rows in row order
     // (at the top of a 16-row period slot s holds row ybase - 7 + s)
-    if (ybase > y0 && (ybase - y0) % F3_ANCHOR == 0) {
+    if (!(ST_ABLATE & 8) && ybase > y0 && (ybase - y0) % F3_ANCHOR == 0) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) vs[c] = 0;
 #pragma unroll
@@ -1742,9 +1745,9 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             Vs[bb * RB + r][c][vpos] = (float)vs[c];
-            const float d = m[c] - ring[t % F3_RING][c];
+            const float d = (ST_ABLATE & 8) ? m[c] * 0.5f : m[c] - ring[t % F3_RING][c];  // ablation 8: no ring
             vs[c] += d;
-            ring[(t + W) % F3_RING][c] = m[c];
+            if (!(ST_ABLATE & 8)) ring[(t + W) % F3_RING][c] = m[c];
           }
           fcur[q][r] = fnext[r];
           if (ST_ABLATE & 4) {  // ablation: no expansion loads
@@ -2195,10 +2198,10 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   dim3 grid(strips, (a.h + rows - 1) / rows, n_pairs);
   st_timed t(ctx, ST_K_BLUR_UPDATE);
   const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-  if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE2, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_FIELD, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_ZERO, 1>), grid, dim3(B2_T), 0, ctx->stream, a);
+  if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE2, ST_EXP_D>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_COARSE, ST_EXP_D>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_FIELD, ST_EXP_D>), grid, dim3(B2_T), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_flow_iter3<7, 2, FLOW_ZERO, ST_EXP_D>), grid, dim3(B2_T), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }
