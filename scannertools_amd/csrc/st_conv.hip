@@ -225,15 +225,23 @@ struct PlanarArgs {
   int n, c, h, wd, cs;
 };
 
-// planar (CPM2Input's output) -> NHWC with zero pad channels (the first layer's operand)
+// planar (CPM2Input's output) -> NHWC with zero pad channels (the first layer's operand); thread = (pixel, channel
+// quad), so that the lanes of a wave store consecutive 16-byte pieces
 __global__ __launch_bounds__(256) void k_planar_to_nhwc(PlanarArgs a) {
-  const long long total = (long long)a.n * a.h * a.wd;
+  const int qpp = a.cs / 4;
+  const long long hw = (long long)a.h * a.wd, total = (long long)a.n * hw * qpp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long hw = (long long)a.h * a.wd;
-    const int n = (int)(i / hw);
-    const long long p = i - (long long)n * hw;
-    float* __restrict__ d = a.y + (size_t)i * a.cs;
-    for (int c = 0; c < a.cs; ++c) d[c] = c < a.c ? a.x[((size_t)n * a.c + c) * hw + p] : 0.f;
+    const int q = (int)(i % qpp);
+    const long long px = i / qpp;
+    const int n = (int)(px / hw);
+    const long long p = px - (long long)n * hw;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * q + k;
+      v[k] = c < a.c ? a.x[((size_t)n * a.c + c) * hw + p] : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.y + (size_t)px * a.cs + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -270,8 +278,9 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
 ST_EXPORT int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int c, int x_stride, float* y_dev,
                                    int y_stride) {
   ST_TRY(st_enter(ctx));
-  if (!x_dev || !y_dev || n <= 0 || h < 2 || w < 2 || c <= 0 || c % 4 || x_stride % 4 || y_stride % 4 || c > x_stride || c > y_stride)
-    return st_set_error(ctx, ST_ERR_INVALID, "maxpool2: bad arguments");
+  if (!x_dev || !y_dev || n <= 0 || h < 2 || w < 2 || c <= 0 || c % 4 || x_stride % 4 || y_stride % 4 || c > x_stride || c > y_stride ||
+      ((uintptr_t)x_dev & 15) || ((uintptr_t)y_dev & 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "maxpool2: bad arguments (channel counts and strides in multiples of 4, 16-byte aligned buffers)");
   PoolArgs a;
   a.x = x_dev; a.y = y_dev; a.n = n; a.h = h; a.wd = w; a.c = c; a.xs = x_stride; a.ys = y_stride;
   const long long total = (long long)n * (h / 2) * (w / 2) * (c / 4);
@@ -285,12 +294,14 @@ ST_EXPORT int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h
 
 ST_EXPORT int st_planar_to_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int c, int h, int w, float* y_dev, int y_stride) {
   ST_TRY(st_enter(ctx));
-  if (!x_dev || !y_dev || n <= 0 || c <= 0 || h <= 0 || w <= 0 || y_stride < c) return st_set_error(ctx, ST_ERR_INVALID, "planar_to_nhwc: bad arguments");
+  if (!x_dev || !y_dev || n <= 0 || c <= 0 || h <= 0 || w <= 0 || y_stride < c || y_stride % 4 || ((uintptr_t)y_dev & 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "planar_to_nhwc: bad arguments (output channel count a multiple of 4 >= c, 16-byte aligned)");
   PlanarArgs a;
   a.x = x_dev; a.y = y_dev; a.n = n; a.c = c; a.h = h; a.wd = w; a.cs = y_stride;
-  const long long total = (long long)n * h * w;
+  const long long total = (long long)n * h * w * (y_stride / 4);
   long long bx = (total + 255) / 256;
   if (bx > 65536) bx = 65536;
+  st_timed t(ctx, ST_K_CONV);
   hipLaunchKernelGGL(k_planar_to_nhwc, dim3((unsigned)bx), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;

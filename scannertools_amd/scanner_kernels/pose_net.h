@@ -154,7 +154,7 @@ class Net {
             wp[((size_t)o * l.k * l.k + kk) * cip + cb] = bl.w[((size_t)o * l.cin + c) * l.k * l.k + kk];
         }
       }
-      Packed p;
+      Packed& p = packed_[l.name];  // registered first, so that release() frees whatever part of it was allocated
       p.cin_pad = cip; p.cout_pad = cop;
       if (hipMalloc(&p.w, wp.size() * 4) != hipSuccess || hipMalloc(&p.b, bp.size() * 4) != hipSuccess ||
           hipMemcpy(p.w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -162,7 +162,6 @@ class Net {
         *err = "out of device memory while uploading layer " + l.name;
         return false;
       }
-      packed_[l.name] = p;
     }
     return true;
   }

@@ -1,4 +1,4 @@
-"""Pose path, config 5: 1080p frames -> CPM2Input -> convolution stack (random weights), frames/s and TFLOP/s."""
+"""Pose path, config 5: 1080p frames -> CPM2Input -> CPM2 (network, resize, nms; random weights) -> limb scores; frames/s and TFLOP/s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,13 +13,13 @@ frames = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
 _, _, nh, nw = cpm2_geometry(h, w, scale)
 fl = pose_net.flops(nh, nw)
 for _ in range(2):
-    out = net.forward(ctx.cpm2_input(frames, scale))
+    maps, joints = net.detect(ctx.cpm2_input(frames, scale)); limb = ctx.cpm2_limb_scores(maps, joints)
 torch.cuda.synchronize()
 ctx.timing_enable([_native.K_CONV]); ctx.timing_reset()
 reps = 3
 t0 = time.perf_counter()
 for _ in range(reps):
-    out = net.forward(ctx.cpm2_input(frames, scale))
+    maps, joints = net.detect(ctx.cpm2_input(frames, scale)); limb = ctx.cpm2_limb_scores(maps, joints)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 nl, ms = ctx.timing_read(_native.K_CONV)
