@@ -1,4 +1,5 @@
-"""Long differential fuzz run (154 + 37 seeds of tests/test_fuzz_gpu.py); not part of the test-suite."""
+"""Long differential fuzz run of tests/test_fuzz_gpu.py's generators (integer ops, flows, pose ops); not part of the
+test-suite.  python scripts/big_fuzz.py [n_int] [n_flow] [n_pose]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -7,14 +8,20 @@ import test_fuzz_gpu as F
 from scannertools_amd.hip import HipContext
 ctx = HipContext(0)
 bad = 0
-for seed in range(6, 160):
+n_int, n_flow, n_pose = (int(v) for v in (sys.argv[1:4] + ['160', '40', '60'][len(sys.argv) - 1:]))
+for seed in range(6, n_int):
     try:
         F.test_fuzz_integer_ops(ctx, seed)
     except AssertionError as e:
         bad += 1; print("INT FAIL seed", seed, str(e)[:300])
-for seed in range(3, 40):
+for seed in range(3, n_flow):
     try:
         F.test_fuzz_optical_flow(ctx, seed)
     except AssertionError as e:
         bad += 1; print("FLOW FAIL seed", seed, str(e)[:300])
+for seed in range(4, n_pose):
+    try:
+        F.test_fuzz_pose_ops(ctx, seed)
+    except AssertionError as e:
+        bad += 1; print("POSE FAIL seed", seed, str(e)[:300])
 print("done, failures:", bad)

@@ -70,3 +70,40 @@ def test_fuzz_optical_flow(flow_ctx, seed):
             ref = oracle.optical_flow_rgb(frames[a], frames[b])
             assert np.abs(got[i] - ref).max() <= 5e-3, (h, w, a, b, np.abs(got[i] - ref).max())
             assert np.linalg.norm(got[i] - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-30) + 1e-6, (h, w, a, b)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_pose_ops(hip_ctx, seed):
+    """CPM2Input at random frame sizes and scales; the `resize` layer at random (also non-integer, also shrinking)
+    ratios with random channel maps; the `nms` layer on random peak populations; the limb scores on the result."""
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(6):
+        h, w, n = int(rng.integers(8, 200)), int(rng.integers(8, 260)), int(rng.integers(1, 4))
+        scale = float(rng.uniform(0.2, 1.6))
+        if int(h * np.float32(scale)) < 1 or int(w * np.float32(scale)) < 1:
+            continue
+        frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        got = hip_ctx.cpm2_input(_cu(frames), scale).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.cpm2_input(frames[i], scale), err_msg="cpm2_input %dx%d scale %r" % (h, w, scale))
+        sh, sw, C = int(rng.integers(1, 40)), int(rng.integers(1, 50)), int(rng.integers(1, 24))
+        th, tw = int(rng.integers(1, 180)), int(rng.integers(1, 300))
+        maps = rng.standard_normal((n, sh, sw, C)).astype(np.float32)
+        chan = [int(c) for c in rng.integers(0, C, int(rng.integers(1, 20)))] if rng.random() < 0.5 else None
+        got = hip_ctx.cpm2_resize_maps(_cu(maps), th, tw, chan_map=chan).cpu().numpy()
+        sel = chan if chan is not None else list(range(C))
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], oracle.cpm2_resize_maps(np.ascontiguousarray(maps[i].transpose(2, 0, 1)[sel]), th, tw),
+                                          err_msg="resize_maps %dx%d -> %dx%d" % (sh, sw, th, tw))
+        H, W, mp = int(rng.integers(1, 90)), int(rng.integers(1, 140)), int(rng.integers(1, 20))
+        hm = (rng.random((n, 57, H, W)) * 0.06).astype(np.float32)
+        mask = rng.random(hm.shape) < float(rng.choice([0.001, 0.02, 0.3]))
+        hm[mask] = rng.random(int(mask.sum())).astype(np.float32)
+        thr = float(rng.choice([0.05, 0.5]))
+        joints = hip_ctx.cpm2_nms(_cu(hm), parts=18, max_peaks=mp, threshold=thr)
+        jn = joints.cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(jn[i], oracle.cpm2_nms(hm[i], 18, mp, thr), err_msg="nms %dx%d max %d" % (H, W, mp))
+        sc = hip_ctx.cpm2_limb_scores(_cu(hm), joints).cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(sc[i], oracle.cpm2_limb_scores(hm[i], jn[i]), err_msg="limb scores %dx%d" % (H, W))
