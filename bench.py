@@ -292,7 +292,7 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
     # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
     try:
         from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
-        n = 128
+        n = 192
         host = batches[0][:n].cpu().pin_memory()
         # measured H2D rate of this host for the same bytes (pinned -> device)
         dst = torch.empty_like(batches[0][:n])
@@ -309,14 +309,19 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         fed = {"h2d_GBs_pinned_copy": h2d, "frames": n}
         for name, mk, nrep in (("Histogram", lambda: sc.ops.Histogram(frame=frame, device=DeviceType.CPU, batch=64, bins=bins), 3),
                                ("OpticalFlow", lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.CPU, batch=32), 2)):
-            best = None
+            best, steady = None, 0.0
             for _ in range(nrep):
                 o = NamedStream(sc, "hf_" + name)
-                sc.execute_seconds = 0.0
+                sc.execute_seconds, sc.steady_seconds, sc.steady_rows = 0.0, 0.0, 0
                 sc.run(sc.io.Output(mk(), [o]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
                 best = sc.execute_seconds if best is None else min(best, sc.execute_seconds)
+                if sc.steady_rows:
+                    steady = max(steady, sc.steady_rows / sc.steady_seconds)
+            # frames_per_s: a fresh kernel instance over the whole stream (its first execute() allocates the device scratch);
+            # steady_frames_per_s: the execute() calls after the first, i.e. an instance that lives for a whole job
             fed[name] = {"frames_per_s": n / best, "input_GBs": n * 3 * h * w / best / 1e9,
-                         "frac_of_h2d": n * 3 * h * w / best / 1e9 / h2d}
+                         "frac_of_h2d": n * 3 * h * w / best / 1e9 / h2d, "steady_frames_per_s": steady,
+                         "steady_frac_of_h2d": steady * 3 * h * w / 1e9 / h2d}
         # the same Histogram graph fed from PAGEABLE host memory (the kernel bounces it through its
         # page-locked ring)
         sc.ingest_frames("vp", np.array(host.numpy(), copy=True))

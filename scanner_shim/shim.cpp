@@ -221,6 +221,10 @@ Element* output_at(EngineOutputs* o, int col, int i) {
 }
 
 double g_last_execute_seconds = 0.0;  // wall time spent inside execute() by the last stshim_run_frames
+// the same without the run's first execute() call (a fresh kernel instance allocates its device scratch there), and
+// the rows those later calls covered: the steady state of a kernel instance that lives for a whole job
+double g_last_steady_seconds = 0.0;
+int g_last_steady_rows = 0;
 
 void set_err(char* err, size_t n, const std::string& s) {
   if (err && n) { strncpy(err, s.c_str(), n - 1); err[n - 1] = 0; }
@@ -337,6 +341,8 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
   auto* outs = new EngineOutputs();
   outs->device = ek->device;
   g_last_execute_seconds = 0.0;
+  g_last_steady_seconds = 0.0;
+  g_last_steady_rows = 0;
   for (int r0 = 0; r0 < n; r0 += batch) {
     const auto t_begin = std::chrono::steady_clock::now();
     const int nb = std::min(batch, n - r0);
@@ -375,7 +381,11 @@ SHIM_EXPORT void* stshim_run_frames(void* k, const void* const* frames, int n, i
         break;
       }
     }
-    g_last_execute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      g_last_execute_seconds += dt;
+      if (r0 > 0) { g_last_steady_seconds += dt; g_last_steady_rows += nb; }
+    }
     for (auto& e : out_cols[0]) outs->elements.push_back(e);
     for (size_t c = 1; c < n_out; ++c)
       for (auto& e : out_cols[c]) outs->extra[c - 1].push_back(e);
@@ -419,6 +429,8 @@ SHIM_EXPORT void* stshim_run_columns(void* k, int n_cols, int n, const void* con
   auto* outs = new EngineOutputs();
   outs->device = ek->device;
   g_last_execute_seconds = 0.0;
+  g_last_steady_seconds = 0.0;
+  g_last_steady_rows = 0;
   for (int r0 = 0; r0 < n; r0 += batch) {
     const auto t_begin = std::chrono::steady_clock::now();
     const int nb = std::min(batch, n - r0);
@@ -434,7 +446,11 @@ SHIM_EXPORT void* stshim_run_columns(void* k, int n_cols, int n, const void* con
       static_cast<Kernel*>(ek->kernel.get())->execute(in, o);
       out_cols[0] = o;
     }
-    g_last_execute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      g_last_execute_seconds += dt;
+      if (r0 > 0) { g_last_steady_seconds += dt; g_last_steady_rows += nb; }
+    }
     for (auto& e : out_cols[0]) outs->elements.push_back(e);
     if ((int)out_cols[0].size() != nb) {
       set_err(err, err_len, "kernel produced " + std::to_string(out_cols[0].size()) + " outputs for " + std::to_string(nb) + " rows");
@@ -496,5 +512,9 @@ SHIM_EXPORT void stshim_outputs_free(void* o) {
 }
 
 SHIM_EXPORT double stshim_last_execute_seconds() { return g_last_execute_seconds; }
+SHIM_EXPORT double stshim_last_steady_seconds(int* rows) {
+  if (rows) *rows = g_last_steady_rows;
+  return g_last_steady_seconds;
+}
 
 SHIM_EXPORT size_t stshim_live_buffers(int device_type) { return shim_live_buffers((DeviceType)device_type); }

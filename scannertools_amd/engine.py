@@ -95,6 +95,8 @@ def _load_op_library(path):
         L.stshim_outputs_free.argtypes = [vp]
         L.stshim_live_buffers.restype = sz
         L.stshim_last_execute_seconds.restype = ctypes.c_double
+        L.stshim_last_steady_seconds.restype = ctypes.c_double
+        L.stshim_last_steady_seconds.argtypes = [ctypes.POINTER(ci)]
         L.stshim_live_buffers.argtypes = [ci]
         _LIBS[path] = L
     return _LIBS[path]
@@ -243,6 +245,9 @@ class _CppOpNode(_Node):
                     torch.cuda.synchronize(dev_id)  # kernel contexts run on their own streams
                 res = L.stshim_run_frames(k, tab, len(ptrs), h, w, c, ftype, self.batch, st, len(self.stencil), err, 512)
                 self.client.execute_seconds += L.stshim_last_execute_seconds()
+                srows = ctypes.c_int()
+                self.client.steady_seconds += L.stshim_last_steady_seconds(ctypes.byref(srows))
+                self.client.steady_rows += srows.value
                 if not res or err.value:
                     if res:
                         L.stshim_outputs_free(res)
@@ -653,6 +658,8 @@ class Client:
         self.device_id = device_id
         self._videos, self._tables = {}, {}
         self.execute_seconds = 0.0  # wall time spent inside kernel execute() calls (excludes Python copies)
+        # the same without each run's first execute() call (scratch allocation of a fresh kernel instance) + rows covered
+        self.steady_seconds, self.steady_rows = 0.0, 0
         self.io, self.ops, self.streams = _IO(self), _Ops(self), _Streams()
 
     def ingest_frames(self, name, frames):
