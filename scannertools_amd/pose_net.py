@@ -136,6 +136,20 @@ def read_caffemodel(path):
     return out
 
 
+def check_caffemodel(path):
+    """Number of layers of the architecture whose weights the file holds with the right sizes (92 = usable), through the
+    op library's own reader (scannertools_caffe_check_model; no GPU needed).  Raises ValueError with the reader's message."""
+    from . import engine
+    L = engine._caffe()
+    L.scannertools_caffe_check_model.restype = ctypes.c_int
+    L.scannertools_caffe_check_model.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    err = ctypes.create_string_buffer(512)
+    n = L.scannertools_caffe_check_model(str(path).encode(), err, 512)
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return n
+
+
 def _pad16(c):
     return (c + 15) // 16 * 16
 

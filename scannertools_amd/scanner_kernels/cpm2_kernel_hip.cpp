@@ -148,6 +148,20 @@ class CPM2KernelHIPImpl : public BatchedKernel, public VideoKernel {
   std::vector<float*> map_ptr_, joint_ptr_;
 };
 
+}  // namespace scanner
+
+// Model-file check without a GPU: number of layers whose weights were found with the architecture's sizes (92 = all),
+// or -1 with the reason in `err`.
+extern "C" __attribute__((visibility("default"))) int scannertools_caffe_check_model(const char* caffemodel, char* err, size_t err_len) {
+  std::string msg;
+  int matched = 0;
+  const bool ok = caffemodel && scanner::pose::check_caffemodel(caffemodel, &matched, &msg);
+  if (!caffemodel) msg = "null path";
+  if (err && err_len) { strncpy(err, msg.c_str(), err_len - 1); err[err_len - 1] = 0; }
+  return ok ? matched : -1;
+}
+
+namespace scanner {
 using CPM2KernelHIP = CPM2KernelHIPImpl<false>;
 using CPM2KernelHIPStaged = CPM2KernelHIPImpl<true>;
 

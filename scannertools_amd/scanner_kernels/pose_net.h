@@ -122,6 +122,32 @@ inline bool read_caffemodel(const std::string& path, std::map<std::string, Blobs
   return true;
 }
 
+inline std::vector<LayerSpec> all_layers() {
+  std::vector<LayerSpec> all = trunk_layers();
+  for (int st = 1; st <= 6; ++st)
+    for (int br = 1; br <= 2; ++br)
+      for (auto& l : branch_layers(st, br)) all.push_back(l);
+  return all;
+}
+
+// Does the file hold weights of the right sizes for every layer of the architecture?  (No GPU involved: what
+// CPM2's validate() reports for a wrong or damaged model file, and a check a deployment can run up front.)
+inline bool check_caffemodel(const std::string& path, int* matched, std::string* err) {
+  std::map<std::string, Blobs> blobs;
+  if (matched) *matched = 0;
+  if (!read_caffemodel(path, &blobs, err)) return false;
+  for (auto& l : all_layers()) {
+    auto it = blobs.find(l.name);
+    if (it == blobs.end()) { *err = "caffemodel " + path + " has no weights for layer " + l.name; return false; }
+    if (it->second.w.size() != (size_t)l.cout * l.cin * l.k * l.k || it->second.b.size() != (size_t)l.cout) {
+      *err = "layer " + l.name + ": the file's blob sizes do not match the architecture";
+      return false;
+    }
+    if (matched) ++*matched;
+  }
+  return true;
+}
+
 // ---- the network on one GPU ---------------------------------------------------------------------------------
 class Net {
  public:
@@ -131,11 +157,7 @@ class Net {
   bool load(const std::string& caffemodel, std::string* err) {
     std::map<std::string, Blobs> blobs;
     if (!read_caffemodel(caffemodel, &blobs, err)) return false;
-    std::vector<LayerSpec> all = trunk_layers();
-    for (int st = 1; st <= 6; ++st)
-      for (int br = 1; br <= 2; ++br)
-        for (auto& l : branch_layers(st, br)) all.push_back(l);
-    for (auto& l : all) {
+    for (auto& l : all_layers()) {
       auto it = blobs.find(l.name);
       if (it == blobs.end()) { *err = "caffemodel " + caffemodel + " has no weights for layer " + l.name; return false; }
       const Blobs& bl = it->second;

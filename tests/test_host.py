@@ -293,8 +293,23 @@ for mk in (lambda: sc.ops.Histogram(frame=frame), lambda: sc.ops.Blur(frame=fram
         errors.append(str(e))
 assert len(errors) == 7, errors
 assert any("Could not parse BlurArgs" in e for e in errors)
+# the caffemodel reader of the CPM2 kernel class on well-formed, truncated and random bytes
+import ctypes, os, tempfile
+from scannertools_amd import _proto
+L = ctypes.CDLL(%r)
+L.scannertools_caffe_check_model.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+err = ctypes.create_string_buffer(256)
+layer = _proto.message(100, _proto.message(1, b"conv1_1") + _proto.message(7, _proto.message(5, np.zeros(64 * 27, "<f4").tobytes())) +
+                       _proto.message(7, _proto.message(5, np.zeros(64, "<f4").tobytes())))
+rng = np.random.default_rng(1)
+for blob in (layer, layer[:len(layer) // 2], layer[:7], b"", rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(), layer * 3 + b"\xff"):
+    with tempfile.NamedTemporaryFile(delete=False) as fh:
+        fh.write(blob)
+    assert L.scannertools_caffe_check_model(fh.name.encode(), err, 256) == -1 and err.value
+    os.unlink(fh.name)
+assert L.scannertools_caffe_check_model(None, err, 256) == -1
 print("sanitized run ok")
-''' % (ROOT, str(lib))
+''' % (ROOT, str(lib), str(lib))
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
     p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0 and "sanitized run ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])

@@ -242,6 +242,46 @@ def test_caffemodel_reader_round_trip(tmp_path):
     assert names[12] == "conv5_1_CPM_L1" and names[-1] == "Mconv7_stage6_L2" and names[22] == "Mconv1_stage2_L1"
 
 
+def _write_model(path, layers, corrupt=None):
+    """A caffemodel with zero weights of the architecture's sizes for the given (caffe name, cin, cout, k) layers."""
+    from scannertools_amd import _proto
+    with open(path, "wb") as fh:
+        fh.write(_proto.message(1, b"pose"))
+        for name, ci, co, k in layers:
+            wn = co * ci * k * k - (1 if corrupt == name else 0)
+            blobs = b"".join(_proto.message(7, _proto.message(5, np.zeros(n, "<f4").tobytes())) for n in (wn, co))
+            fh.write(_proto.message(100, _proto.message(1, name.encode()) + _proto.message(2, b"Convolution") + blobs))
+
+
+def test_op_library_checks_a_model_file(tmp_path):
+    """scannertools_caffe_check_model (the C++ reader CPM2KernelHIP uses, no GPU needed): a complete file passes with 92
+    layers; a missing layer, a wrong blob size, a truncated file and a file that is not a NetParameter are refused
+    with a message that says what is wrong."""
+    from scannertools_amd import pose_net
+    layers = [(cn, ci, co, k) for (_, ci, co, k, _), cn in zip(pose_net.all_layers(), pose_net.caffe_layer_names())]
+    good = tmp_path / "good.caffemodel"
+    _write_model(good, layers)
+    assert pose_net.check_caffemodel(good) == 92
+    missing = tmp_path / "missing.caffemodel"
+    _write_model(missing, [l for l in layers if l[0] != "Mconv3_stage4_L2"])
+    with pytest.raises(ValueError, match="Mconv3_stage4_L2"):
+        pose_net.check_caffemodel(missing)
+    wrong = tmp_path / "wrong.caffemodel"
+    _write_model(wrong, layers, corrupt="conv4_3_CPM")
+    with pytest.raises(ValueError, match="conv4_3_CPM"):
+        pose_net.check_caffemodel(wrong)
+    cut = tmp_path / "cut.caffemodel"
+    cut.write_bytes(good.read_bytes()[:1000003])
+    with pytest.raises(ValueError, match="NetParameter|no weights"):
+        pose_net.check_caffemodel(cut)
+    junk = tmp_path / "junk.caffemodel"
+    junk.write_bytes(np.random.default_rng(0).integers(0, 256, 4096, dtype=np.uint8).tobytes())
+    with pytest.raises(ValueError):
+        pose_net.check_caffemodel(junk)
+    with pytest.raises(ValueError, match="cannot read"):
+        pose_net.check_caffemodel(tmp_path / "absent.caffemodel")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,h,w,C,th,tw,chan", [(2, 6, 9, 57, 48, 72, None), (1, 46, 82, 192, 368, 656, "pose"), (3, 7, 5, 8, 23, 31, [7, 0, 3]),
                                                 (1, 5, 5, 4, 5, 5, None), (1, 12, 16, 3, 6, 8, None)])
