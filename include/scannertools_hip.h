@@ -297,6 +297,13 @@ int st_planar_to_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int c, int h, 
  * (host array; NULL = identity); bicubic (Catmull-Rom), one scale. */
 int st_cpm2_resize_maps(st_ctx* ctx, const float* src_dev, int n, int src_h, int src_w, int src_stride,
                         const int* chan_map, int nmaps, int dst_h, int dst_w, float* const* out_dev);
+/* Several network scales merged (OpenPoseArgs.pose_num_scales / pose_scale_gap, openpose_kernel.cpp:96-112; the `num`
+ * loop of the fork's resize kernel): source s = (n, src_h[s], src_w[s], src_stride) maps of which eff_h[s] x eff_w[s]
+ * source pixels (float) correspond to the whole output; per output pixel the bicubic interpolants of the scales are
+ * summed in order and divided by `scales` (<= 8).  One scale with eff = its map size is st_cpm2_resize_maps, bit for bit. */
+int st_cpm2_resize_merge_maps(st_ctx* ctx, const float* const* src_dev, const int* src_h, const int* src_w, const float* eff_h,
+                              const float* eff_w, int scales, int n, int src_stride, const int* chan_map, int nmaps, int dst_h,
+                              int dst_w, float* const* out_dev);
 /* st_cpm2_nms: peaks of the first `parts` planes of n (>= parts, h, w) maps: strict 8-neighbour maxima above
  * `threshold`, interior pixels only, raster order, at most max_peaks per part.  joints_dev: n device pointers to
  * (parts, max_peaks + 1, 3) float32: row 0 = [count, 0, 0], row i = (x, y, score) -- the layout

@@ -311,18 +311,20 @@ def _rm_cubic(v0, v1, v2, v3, d):
             + (f(-0.5) * v0 + f(0.5) * v2) * d + v1)
 
 
-def cpm2_resize_maps(maps, dst_h, dst_w):
+def cpm2_resize_maps(maps, dst_h, dst_w, eff=None):
     """The `resize` layer of the Caffe fork behind the reference's CPM2 op (ImResizeLayer with start scale 1 and one
     scale, configured at scannertools_caffe_cpp/cpm2_kernel.cpp:16-23).  The layer's source is not in the reference
     tree: restated from the published caffe_rtpose kernel ([EXT], PARITY UNPINNED).  maps: (C, h, w) float32 ->
     (C, dst_h, dst_w) float32, every operation in float32 in the layer's order (the 1e-5 nudge and the offset's
-    `- 0.5` in double, as the C expression evaluates them)."""
+    `- 0.5` in double, as the C expression evaluates them).  eff = (eff_h, eff_w): the source extent (float) that spans
+    the whole output, when it is not the map itself (a smaller network scale, cpm2_resize_merge_maps)."""
     maps = np.ascontiguousarray(maps, dtype=np.float32)
     C, h, w = maps.shape
     f = np.float32
-    off_x = f(np.float64(f(f(dst_w) / f(w)) / f(2)) - 0.5)
-    off_y = f(np.float64(f(f(dst_h) / f(h)) / f(2)) - 0.5)
-    rx, ry = f(w) / f(dst_w), f(h) / f(dst_h)
+    eh, ew = (f(h), f(w)) if eff is None else (f(eff[0]), f(eff[1]))
+    off_x = f(np.float64(f(f(dst_w) / ew) / f(2)) - 0.5)
+    off_y = f(np.float64(f(f(dst_h) / eh) / f(2)) - 0.5)
+    rx, ry = ew / f(dst_w), eh / f(dst_h)
     x_on = (np.arange(dst_w, dtype=np.float32) - off_x) * rx
     y_on = (np.arange(dst_h, dtype=np.float32) - off_y) * ry
     xn = _rm_taps(x_on, w)
@@ -334,6 +336,17 @@ def cpm2_resize_maps(maps, dst_h, dst_w):
         r = maps[:, yn[i], :]                                  # (C, dst_h, w)
         rows.append(_rm_cubic(r[:, :, xn[0]], r[:, :, xn[1]], r[:, :, xn[2]], r[:, :, xn[3]], dx))
     return _rm_cubic(rows[0], rows[1], rows[2], rows[3], dy).astype(np.float32)
+
+
+def cpm2_resize_merge_maps(maps_list, eff_sizes, dst_h, dst_w):
+    """Several network scales merged ([EXT]: the `num` loop of the fork's resize kernel / OpenPose's resizeAndMerge;
+    OpenPoseArgs.pose_num_scales, openpose_kernel.cpp:110-111): the scales' interpolants summed in order, divided by their
+    number, in float32."""
+    total = None
+    for m, e in zip(maps_list, eff_sizes):
+        v = cpm2_resize_maps(m, dst_h, dst_w, eff=e)
+        total = v if total is None else total + v
+    return (total / np.float32(len(maps_list))).astype(np.float32)
 
 
 def cpm2_nms(maps, parts=18, max_peaks=64, threshold=0.05):

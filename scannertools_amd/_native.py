@@ -87,6 +87,8 @@ SIGNATURES = {
     "st_maxpool2_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),
     "st_planar_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "st_cpm2_resize_maps": (_i, [_vp, _vp, _i, _i, _i, _i, _c.POINTER(_i), _i, _i, _i, _c.POINTER(_vp)]),
+    "st_cpm2_resize_merge_maps": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _i, _i,
+                                       _i, _c.POINTER(_i), _i, _i, _i, _c.POINTER(_vp)]),
     "st_cpm2_nms": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _c.c_float, _c.POINTER(_vp)]),
 }
 

@@ -229,6 +229,69 @@ __global__ __launch_bounds__(256) void k_cpm2_resize_maps(ResizeMapsArgs a) {
   }
 }
 
+// Several network scales merged into one set of maps (the `num` loop of the fork's resize kernel; OpenPose's
+// resizeAndMerge): source s is sampled with ITS ratio (eff_w / tw source pixels per output pixel, neighbours clamped
+// to its own extent), the interpolants are summed in scale order and divided by the number of scales.
+constexpr int RM_MAX_SCALES = 8;
+struct ResizeMergeArgs {
+  const float* src[RM_MAX_SCALES];  // (n, sh[s], sw[s], stride)
+  int sh[RM_MAX_SCALES], sw[RM_MAX_SCALES];
+  float off_x[RM_MAX_SCALES], off_y[RM_MAX_SCALES], rx[RM_MAX_SCALES], ry[RM_MAX_SCALES];
+  float* const* dst;
+  int stride, nmaps, th, tw, scales;
+  int chan[64];
+};
+
+__global__ __launch_bounds__(256) void k_cpm2_resize_merge(ResizeMergeArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.tw) return;
+  const int f = blockIdx.z;
+  float* __restrict__ dst = a.dst[f];
+  const int y0 = blockIdx.y * RM_ROWS, y1 = min(a.th, y0 + RM_ROWS);
+  int o[RM_MAX_SCALES][4];
+  float dx[RM_MAX_SCALES];
+#pragma unroll
+  for (int s = 0; s < RM_MAX_SCALES; ++s) {
+    if (s < a.scales) {
+      const float x_on = ((float)x - a.off_x[s]) * a.rx[s];
+      int xn[4];
+      rm_taps(x_on, a.sw[s], xn);
+      dx[s] = x_on - (float)xn[1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[s][k] = xn[k] * a.stride;
+    }
+  }
+  for (int c = 0; c < a.nmaps; ++c) {
+    int cached[RM_MAX_SCALES];
+    float t[RM_MAX_SCALES][4];
+#pragma unroll
+    for (int s = 0; s < RM_MAX_SCALES; ++s) cached[s] = -1;
+    for (int y = y0; y < y1; ++y) {
+      float sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < RM_MAX_SCALES; ++s) {
+        if (s < a.scales) {
+          const float y_on = ((float)y - a.off_y[s]) * a.ry[s];
+          int yn[4];
+          rm_taps(y_on, a.sh[s], yn);
+          if (yn[1] != cached[s]) {
+            cached[s] = yn[1];
+            const float* __restrict__ sc = a.src[s] + (size_t)f * a.sh[s] * a.sw[s] * a.stride + a.chan[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float* r = sc + (size_t)yn[k] * a.sw[s] * a.stride;
+              t[s][k] = rm_cubic(r[o[s][0]], r[o[s][1]], r[o[s][2]], r[o[s][3]], dx[s]);
+            }
+          }
+          const float v = rm_cubic(t[s][0], t[s][1], t[s][2], t[s][3], y_on - (float)yn[1]);
+          sum = s == 0 ? v : sum + v;  // starts from the first interpolant itself: one scale reproduces st_cpm2_resize_maps' bits
+        }
+      }
+      dst[((size_t)c * a.th + y) * a.tw + x] = sum / (float)a.scales;
+    }
+  }
+}
+
 struct NmsArgs {
   const float* const* maps;  // n x (>= parts, h, w)
   float* const* joints;      // n x (parts, max_peaks + 1, 3)
@@ -405,6 +468,44 @@ ST_EXPORT int st_cpm2_resize_maps(st_ctx* ctx, const float* src_dev, int n, int 
   a.ry = (float)src_h / (float)dst_h;
   st_timed t(ctx, ST_K_CPM2_RESIZE);
   hipLaunchKernelGGL(k_cpm2_resize_maps, dim3((dst_w + 255) / 256, (dst_h + RM_ROWS - 1) / RM_ROWS, n), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+ST_EXPORT int st_cpm2_resize_merge_maps(st_ctx* ctx, const float* const* src_dev, const int* src_h, const int* src_w, const float* eff_h,
+                                        const float* eff_w, int scales, int n, int src_stride, const int* chan_map, int nmaps, int dst_h,
+                                        int dst_w, float* const* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (scales < 1 || scales > RM_MAX_SCALES || n < 0 || src_stride <= 0 || nmaps <= 0 || nmaps > 64 || dst_h <= 0 || dst_w <= 0 ||
+      (long long)dst_h * dst_w > 35000000LL || n > 65535 || !src_h || !src_w || !eff_h || !eff_w)
+    return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_merge_maps: bad arguments (%d scales, n=%d -> %dx%d, %d maps)", scales, n, dst_h, dst_w, nmaps);
+  if (n == 0) return ST_OK;
+  if (!src_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_merge_maps: null argument");
+  ResizeMergeArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int c = 0; c < nmaps; ++c) {
+    a.chan[c] = chan_map ? chan_map[c] : c;
+    if (a.chan[c] < 0 || a.chan[c] >= src_stride) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_merge_maps: channel %d outside the source pixel", a.chan[c]);
+  }
+  for (int s = 0; s < scales; ++s) {
+    if (!src_dev[s] || src_h[s] <= 0 || src_w[s] <= 0 || !(eff_h[s] > 0.f) || !(eff_w[s] > 0.f))
+      return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_merge_maps: scale %d has no maps or an empty extent", s);
+    a.src[s] = src_dev[s]; a.sh[s] = src_h[s]; a.sw[s] = src_w[s];
+    // st_cpm2_resize_maps' arithmetic with the scale's effective extent in place of the map size
+    a.off_x[s] = (float)((double)((float)dst_w / eff_w[s] / 2) - 0.5);
+    a.off_y[s] = (float)((double)((float)dst_h / eff_h[s] / 2) - 0.5);
+    a.rx[s] = eff_w[s] / (float)dst_w;
+    a.ry[s] = eff_h[s] / (float)dst_h;
+  }
+  for (int i = 0; i < n; ++i)
+    if (!out_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "cpm2_resize_merge_maps: row %d is null", i);
+  const size_t tb = st_align_up(sizeof(void*) * (size_t)n);
+  ST_TRY(st_ws_reserve(ctx, tb));
+  float** d_dst = (float**)st_ws_alloc(ctx, tb);
+  ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  a.dst = d_dst; a.stride = src_stride; a.nmaps = nmaps; a.th = dst_h; a.tw = dst_w; a.scales = scales;
+  st_timed t(ctx, ST_K_CPM2_RESIZE);
+  hipLaunchKernelGGL(k_cpm2_resize_merge, dim3((dst_w + 255) / 256, (dst_h + RM_ROWS - 1) / RM_ROWS, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }

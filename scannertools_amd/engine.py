@@ -637,6 +637,19 @@ class _Ops:
         op = _PoseNetOp(self.sc, cpm2_input, weights, seed, batch, max_peaks, nms_threshold)
         return _PoseNetColumn(op, 0), _PoseNetColumn(op, 1)
 
+    def OpenPose(self, frame, model_directory="", pose_num_scales=1, pose_scale_gap=0.3, compute_hands=False, hand_num_scales=1,
+                 hand_scale_gap=0.4, compute_face=False, device=None, batch=None):
+        """sc.ops.OpenPose(frame=..., pose_num_scales=..., pose_scale_gap=..., compute_hands=..., compute_face=..., device=...,
+        batch=...) (scannertools_caffe/tests/test_all.py:12-22; OpenPoseArgs, scannertools_caffe.proto:50-61); rows read with
+        scannertools_amd.pose_detection.pose_list."""
+        from . import _proto, pose_detection
+        args = _proto.encode([(1, "string", model_directory), (2, "int32", pose_num_scales), (3, "float", pose_scale_gap),
+                              (4, "bool", compute_hands), (5, "int32", hand_num_scales), (6, "float", hand_scale_gap),
+                              (7, "bool", compute_face)])
+        node = _CppOpNode(self.sc, "OpenPose", frame, device, batch, None, args)
+        node.reader = pose_detection.pose_list
+        return node
+
     def CPM2Output(self, cpm2_resized_map, cpm2_joints, original_frame_info, scale, device=None, batch=None):
         """sc.ops.CPM2Output(cpm2_resized_map=..., cpm2_joints=..., original_frame_info=...)
         (cpm2_output_kernel_cpu.cpp:805-810); rows read with scannertools_amd.types.poses."""

@@ -327,6 +327,33 @@ class HipContext:
         self._check(self._L.st_cpm2_resize_maps(self._h, ctypes.c_void_p(maps.data_ptr()), n, h, w, C, cm, nmaps, int(dst_h), int(dst_w), to))
         return out
 
+    def cpm2_resize_merge_maps(self, maps_list, eff_sizes, dst_h, dst_w, chan_map=None, nmaps=None):
+        """Maps of several network scales merged (st_cpm2_resize_merge_maps): maps_list[s] (n,h_s,w_s,C) float32 channel-last,
+        eff_sizes[s] = (eff_h, eff_w) source pixels of scale s that span the whole output -> (n,nmaps,dst_h,dst_w)."""
+        self._bind()
+        S = len(maps_list)
+        for m in maps_list:
+            _require_cuda(m, torch.float32, "maps", self.device)
+        n, _, _, C = maps_list[0].shape
+        if any(m.dim() != 4 or m.shape[0] != n or m.shape[3] != C for m in maps_list) or len(eff_sizes) != S:
+            raise ValueError("every scale needs (n,h,w,C) maps with the same n and C, and one (eff_h, eff_w) pair")
+        if chan_map is not None:
+            nmaps = len(chan_map)
+        elif nmaps is None:
+            nmaps = C
+        out = torch.empty((n, nmaps, int(dst_h), int(dst_w)), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        cm = (ctypes.c_int * nmaps)(*[int(v) for v in chan_map]) if chan_map is not None else None
+        src = (ctypes.c_void_p * S)(*[m.data_ptr() for m in maps_list])
+        sh = (ctypes.c_int * S)(*[m.shape[1] for m in maps_list])
+        sw = (ctypes.c_int * S)(*[m.shape[2] for m in maps_list])
+        eh = (ctypes.c_float * S)(*[float(e[0]) for e in eff_sizes])
+        ew = (ctypes.c_float * S)(*[float(e[1]) for e in eff_sizes])
+        to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+        self._check(self._L.st_cpm2_resize_merge_maps(self._h, src, sh, sw, eh, ew, S, n, C, cm, nmaps, int(dst_h), int(dst_w), to))
+        return out
+
     def cpm2_nms(self, maps, parts=18, max_peaks=64, threshold=0.05, out=None):
         """The CPM2 network's `nms` layer ([EXT] Caffe fork): maps (n,>=parts,H,W) float32 -> joints
         (n,parts,max_peaks+1,3) float32, row 0 = [count,0,0], rows 1.. = (x, y, score) in raster order."""

@@ -191,9 +191,12 @@ class Net {
   // inputs: n device pointers to planar (3, H, W) float32 frames (CPM2Input's output); H, W multiples of 8.
   // Returns the stage buffer (n, H/8, W/8, 192) holding stage 6's outputs at channels kOffPaf.. / kOffHeat.. (device
   // memory owned by the net, valid until the next call), or nullptr with *err set.
-  const float* forward(st_ctx* ctx, const float* const* inputs, int n, int H, int W, std::string* err) {
-    if (n <= 0 || H % 8 || W % 8) { *err = "pose net: the network input must be a multiple of 8 in both dimensions"; return nullptr; }
-    if (!reserve(n, H, W, err)) return nullptr;
+  // slot: which pair of stage buffers receives the result -- a caller that runs several network scales per batch
+  // (OpenPose's pose_num_scales) keeps every scale's output alive by giving each its own slot.
+  const float* forward(st_ctx* ctx, const float* const* inputs, int n, int H, int W, std::string* err, int slot = 0) {
+    if (n <= 0 || H % 8 || W % 8 || slot < 0 || slot >= kMaxSlots) { *err = "pose net: the network input must be a multiple of 8 in both dimensions"; return nullptr; }
+    if (!reserve(n, H, W, slot, err)) return nullptr;
+    float* const* cat_ = slots_[slot].cat;
     auto fail = [&](const char* what) { *err = std::string(what) + ": " + st_ctx_last_error(ctx); return (const float*)nullptr; };
     for (int i = 0; i < n; ++i)
       if (st_planar_to_nhwc_f32(ctx, inputs[i], 1, 3, H, W, a_ + (size_t)i * H * W * 16, 16) != ST_OK) return fail("st_planar_to_nhwc_f32");
@@ -251,32 +254,47 @@ class Net {
     int cin_pad = 0, cout_pad = 0;
   };
 
-  bool reserve(int n, int H, int W, std::string* err) {
+  bool reserve(int n, int H, int W, int slot, std::string* err) {
     const size_t big = (size_t)n * H * W * 64, small = (size_t)n * (H / 8) * (W / 8);
-    if (big <= cap_big_ && small <= cap_small_) return true;
-    free_buffers();
-    auto alloc = [&](float** p, size_t floats) { return hipMalloc(p, floats * 4) == hipSuccess; };
-    // the largest trunk activation is conv1's (64 channels at full resolution)
-    if (!alloc(&a_, big) || !alloc(&b_, big) || !alloc(&cat_[0], small * kCatPad) || !alloc(&cat_[1], small * kCatPad) ||
-        !alloc(&tmp_[0], small * 128) || !alloc(&tmp_[1], small * 128) || !alloc(&wide_, small * 512)) {
-      free_buffers();
+    auto alloc = [&](float** p, size_t floats) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+      return hipMalloc(p, floats * 4) == hipSuccess;
+    };
+    bool ok = true;
+    // the largest trunk activation is conv1's (64 channels at full resolution); grow-only, shared by all slots
+    if (big > cap_big_) { ok = ok && alloc(&a_, big) && alloc(&b_, big); cap_big_ = ok ? big : 0; }
+    if (ok && small > cap_small_) {
+      ok = alloc(&tmp_[0], small * 128) && alloc(&tmp_[1], small * 128) && alloc(&wide_, small * 512);
+      cap_small_ = ok ? small : 0;
+    }
+    Slot& sl = slots_[slot];
+    if (ok && small > sl.cap) {
+      ok = alloc(&sl.cat[0], small * kCatPad) && alloc(&sl.cat[1], small * kCatPad);
+      // the 7 pad channels of the stage buffers are read (against zero weights) and never written: zero them once
+      ok = ok && hipMemset(sl.cat[0], 0, small * kCatPad * 4) == hipSuccess && hipMemset(sl.cat[1], 0, small * kCatPad * 4) == hipSuccess &&
+           hipDeviceSynchronize() == hipSuccess;  // the layer calls run on the context's own (non-blocking) stream
+      sl.cap = ok ? small : 0;
+    }
+    if (!ok) {
       *err = "pose net: out of device memory for a batch of " + std::to_string(n) + " frames";
+      free_buffers();
       return false;
     }
-    // the 7 pad channels of the stage buffers are read (against zero weights) and never written: zero them once
-    if (hipMemset(cat_[0], 0, small * kCatPad * 4) != hipSuccess || hipMemset(cat_[1], 0, small * kCatPad * 4) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {  // the layer calls run on the context's own (non-blocking) stream
-      *err = "pose net: hipMemset failed";
-      return false;
-    }
-    cap_big_ = big; cap_small_ = small;
     return true;
   }
   void free_buffers() {
-    float** all[] = {&a_, &b_, &cat_[0], &cat_[1], &tmp_[0], &tmp_[1], &wide_};
+    float** all[] = {&a_, &b_, &tmp_[0], &tmp_[1], &wide_};
     for (auto p : all) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
+    }
+    for (auto& sl : slots_) {
+      for (auto& c : sl.cat) {
+        if (c) (void)hipFree(c);
+        c = nullptr;
+      }
+      sl.cap = 0;
     }
     cap_big_ = cap_small_ = 0;
   }
@@ -290,7 +308,13 @@ class Net {
   }
 
   std::map<std::string, Packed> packed_;
-  float *a_ = nullptr, *b_ = nullptr, *cat_[2] = {nullptr, nullptr}, *tmp_[2] = {nullptr, nullptr}, *wide_ = nullptr;
+  static constexpr int kMaxSlots = 8;
+  struct Slot {
+    float* cat[2] = {nullptr, nullptr};
+    size_t cap = 0;
+  };
+  Slot slots_[kMaxSlots];
+  float *a_ = nullptr, *b_ = nullptr, *tmp_[2] = {nullptr, nullptr}, *wide_ = nullptr;
   size_t cap_big_ = 0, cap_small_ = 0;
 };
 

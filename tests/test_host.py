@@ -286,12 +286,15 @@ for mk in (lambda: sc.ops.Histogram(frame=frame), lambda: sc.ops.Blur(frame=fram
            lambda: sc.ops.Resize(frame=frame, width=4, height=4, interpolation="INTER_AREA"),
            lambda: sc.ops.ConvertColor(frame=frame, conversion="COLOR_RGB2GRAY"),
            lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.GPU), lambda: sc.ops.FlowHistogram(flow=frame),
-           lambda: sc.ops.Blur(frame=frame, kernel_size=0)):
+           lambda: sc.ops.Blur(frame=frame, kernel_size=0),
+           lambda: sc.ops.OpenPose(frame=frame, model_directory="/nonexistent", compute_hands=True),
+           lambda: sc.ops.OpenPose(frame=frame, model_directory="/nonexistent", pose_num_scales=3, pose_scale_gap=0.2)):
     try:
         sc.run(sc.io.Output(mk(), [NamedStream(sc, "o")]), PerfParams.estimate())
     except RuntimeError as e:
         errors.append(str(e))
-assert len(errors) == 7, errors
+assert len(errors) == 9, errors
+assert any("hand and face networks" in e for e in errors)
 assert any("Could not parse BlurArgs" in e for e in errors)
 # the caffemodel reader of the CPM2 kernel class on well-formed, truncated and random bytes
 import ctypes, os, tempfile

@@ -145,23 +145,34 @@ def test_whole_pose_pipeline_through_the_engine(hip_ctx):
     assert float(joints[:, :, 0, 0].max()) > 0   # the random network does produce candidates
 
 
-def test_pose_net_loads_a_caffemodel(hip_ctx, tmp_path):
-    """PoseNet(caffemodel=...) == PoseNet with the same weights set directly: a complete 92-layer file written with
-    the wire-format helpers (tiny spatial check, the weights are what is being tested)."""
+@pytest.fixture(scope="module")
+def model_dir(hip_ctx, tmp_path_factory):
+    """An OpenPose model directory (<dir>/pose/coco/pose_iter_440000.caffemodel, openpose_kernel.cpp:47-52) holding the
+    weights of PoseNet(seed=6), written with the wire-format helpers: (directory, caffemodel path, the network)."""
     from scannertools_amd import _proto
     a = pose_net.PoseNet(hip_ctx, seed=6)
 
     def blob(arr):
         return _proto.message(7, _proto.message(1, b"".join(_proto._varint(d) for d in arr.shape))) + _proto.message(5, arr.astype("<f4").tobytes())
 
-    buf = bytearray(_proto.message(1, b"pose"))
-    for (name, *_), cname in zip(pose_net.all_layers(), pose_net.caffe_layer_names()):
-        wt, b = a.weights[name]
-        buf += _proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
-                              _proto.message(7, blob(wt.numpy())) + _proto.message(7, blob(b.numpy())))
-    path = tmp_path / "pose.caffemodel"
-    path.write_bytes(bytes(buf))
-    b_net = pose_net.PoseNet(hip_ctx, caffemodel=str(path))
+    root = tmp_path_factory.mktemp("openpose_models")
+    path = root / "pose" / "coco" / "pose_iter_440000.caffemodel"
+    path.parent.mkdir(parents=True)
+    with open(path, "wb") as fh:
+        fh.write(_proto.message(1, b"pose"))
+        for (name, *_), cname in zip(pose_net.all_layers(), pose_net.caffe_layer_names()):
+            wt, b = a.weights[name]
+            fh.write(_proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
+                                    _proto.message(7, blob(wt.numpy())) + _proto.message(7, blob(b.numpy()))))
+    return str(root), str(path), a
+
+
+def test_pose_net_loads_a_caffemodel(hip_ctx, model_dir, tmp_path):
+    """PoseNet(caffemodel=...) == PoseNet with the same weights set directly (a complete 92-layer file; tiny spatial
+    check, the weights are what is being tested), and so do the registered kernel classes."""
+    _, path, a = model_dir
+    assert pose_net.check_caffemodel(path) == 92
+    b_net = pose_net.PoseNet(hip_ctx, caffemodel=path)
     x = (torch.rand((3, 3, 16, 24), generator=torch.Generator().manual_seed(1)) - 0.5).cuda()
     assert torch.equal(a.forward(x), b_net.forward(x))
 
@@ -183,17 +194,107 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, tmp_path):
     for device in (DeviceType.GPU, DeviceType.CPU):
         sc = Client()
         src = _Rows([f for f in (x if device == DeviceType.GPU else x.cpu().numpy())])
-        m_col, j_col = sc.ops.CPM2(cpm2_input=src, weights=str(path), device=device, batch=2)
+        m_col, j_col = sc.ops.CPM2(cpm2_input=src, weights=path, device=device, batch=2)
         om, oj = NamedStream(sc, "maps"), NamedStream(sc, "joints")
         sc.run([sc.io.Output(m_col, [om]), sc.io.Output(j_col, [oj])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
         for i, (m, j) in enumerate(zip(om.load(), oj.load())):
             np.testing.assert_array_equal(m, maps[i].cpu().numpy())
             np.testing.assert_array_equal(j, joints[i].cpu().numpy())
 
-    path.write_bytes(bytes(buf[:len(buf) // 2]))
+    cut = tmp_path / "cut.caffemodel"
+    with open(path, "rb") as fh:
+        cut.write_bytes(fh.read(100 * 1000 * 1000))
     with pytest.raises(ValueError):
-        pose_net.PoseNet(hip_ctx, caffemodel=str(path))
+        pose_net.PoseNet(hip_ctx, caffemodel=str(cut))
     with pytest.raises(RuntimeError, match="CPM2"):
         sc = Client()
-        m_col, _ = sc.ops.CPM2(cpm2_input=_Rows([x[0]]), weights=str(path), device=DeviceType.GPU)
+        m_col, _ = sc.ops.CPM2(cpm2_input=_Rows([x[0]]), weights=str(cut), device=DeviceType.GPU)
         sc.run(sc.io.Output(m_col, [NamedStream(sc, "m")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_resize_merge_maps_bit_exact(hip_ctx, S):
+    """The scales' maps merged on the GPU == the oracle's sum of per-scale interpolants / S; one scale == the single-scale
+    kernel bit for bit (both with identity and with the pose channel map)."""
+    import oracle
+    rng = np.random.default_rng(40 + S)
+    dims = [(46, 82), (40, 70), (33, 58)][:S]
+    maps = [rng.standard_normal((2, h, w, 192)).astype(np.float32) for h, w in dims]
+    eff = [(46.0, 82.0), (46 * 0.85, 82 * 0.853), (46 * 0.7, 82 * 0.71)][:S]
+    chan = [pose_net.OFF_HEAT + i for i in range(19)] + [pose_net.OFF_PAF + i for i in range(38)]
+    cu = [torch.from_numpy(m).cuda() for m in maps]
+    got = hip_ctx.cpm2_resize_merge_maps(cu, eff, 368, 656, chan_map=chan).cpu().numpy()
+    for i in range(2):
+        ref = oracle.cpm2_resize_merge_maps([np.ascontiguousarray(m[i].transpose(2, 0, 1)[chan]) for m in maps], eff, 368, 656)
+        np.testing.assert_array_equal(got[i], ref)
+    if S == 1:
+        single = hip_ctx.cpm2_resize_maps(cu[0], 368, 656, chan_map=chan)
+        assert torch.equal(single, torch.from_numpy(got).cuda())
+        assert np.array_equal(np.signbit(single.cpu().numpy()), np.signbit(got))
+
+
+@pytest.mark.parametrize("scales,gap,device", [(1, 0.0, "gpu"), (3, 0.15, "gpu"), (2, 0.25, "cpu")])
+def test_openpose_op(hip_ctx, model_dir, scales, gap, device):
+    """sc.ops.OpenPose through the registered kernel classes == the same chain assembled from the Python-visible pieces
+    (CPM2Input per scale -> network -> merge -> nms -> limb scores -> the oracle's assembly -> the element layout of
+    openpose_kernel.cpp:175-212), byte for byte; hands / faces and a missing model are refused."""
+    import oracle
+    from scannertools_amd import pose_detection
+    from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+    from scannertools_amd.hip import cpm2_geometry
+    from util import random_frames
+    root, _, net = model_dir
+    frames = random_frames(17, 3, 96, 160)
+    H, W = 96, 160
+    sc = Client()
+    sc.ingest_frames("v", frames)
+    frame = sc.io.Input([NamedVideoStream(sc, "v")])
+    dev = DeviceType.GPU if device == "gpu" else DeviceType.CPU
+    out = NamedStream(sc, "pose")
+    sc.run(sc.io.Output(sc.ops.OpenPose(frame=frame, model_directory=root, pose_num_scales=scales, pose_scale_gap=gap, device=dev, batch=2),
+                        [out]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    raw = sc._tables["pose"][0]
+    people = list(out.load())
+
+    fr = torch.from_numpy(frames).cuda()
+    geo, raws = [], []
+    for i in range(scales):
+        s = float(np.float32(368) / np.float32(H) * (np.float32(1) - np.float32(i) * np.float32(gap)))
+        geo.append(cpm2_geometry(H, W, s))
+        raws.append(net.forward_raw(hip_ctx.cpm2_input(fr, s)))
+    (rh0, rw0, nh0, nw0) = geo[0]
+    f32 = np.float32
+    eff = [(float(nh0 // 8), float(nw0 // 8))] + [(float(f32(nh0 // 8) * (f32(g[0]) / f32(rh0))), float(f32(nw0 // 8) * (f32(g[1]) / f32(rw0)))) for g in geo[1:]]
+    chan = [pose_net.OFF_HEAT + i for i in range(19)] + [pose_net.OFF_PAF + i for i in range(38)]
+    maps = hip_ctx.cpm2_resize_merge_maps(raws, eff, nh0, nw0, chan_map=chan)
+    joints = hip_ctx.cpm2_nms(maps, parts=18, max_peaks=64, threshold=0.05)
+    scores = hip_ctx.cpm2_limb_scores(maps, joints).cpu().numpy()
+    total = 0
+    for i in range(3):
+        # joints of the oracle's assembly in network-input pixels (frame = network input), then ZeroToOne
+        pj = oracle.cpm2_connect_limbs_coco(maps[i].cpu().numpy(), joints[i].cpu().numpy(), nh0, nw0, scores=scores[i])
+        if len(pj) == 0:
+            assert raw[i] == b"\0\0\0\0" and people[i] == []
+            continue
+        total += len(pj)
+        rec = np.zeros((len(pj), pose_detection.Pose.kp_size()), np.float32)
+        kp = pj.copy()
+        kp[:, :, 0] = kp[:, :, 0] / f32(rw0)
+        kp[:, :, 1] = kp[:, :, 1] / f32(rh0)
+        acc = np.zeros(len(pj), np.float32)
+        for j in range(18):
+            acc = acc + kp[:, j, 2]
+        rec[:, 0] = acc / f32(18)
+        rec[:, 1:1 + 54] = kp.reshape(len(pj), 54)
+        assert raw[i] == rec.tobytes()
+        assert len(people[i]) == len(pj) and people[i][0].pose_keypoints().shape == (18, 3)
+        assert float(np.abs(people[i][0].face_keypoints()).max()) == 0.0
+    print("people assembled from the random network:", total)
+
+    if scales == 1 and device == "gpu":
+        for kw, msg in ((dict(compute_hands=True), "hand"), (dict(compute_face=True), "face"), (dict(model_directory=""), "model_directory"),
+                        (dict(model_directory=root + "/nowhere"), "cannot read"), (dict(pose_num_scales=4, pose_scale_gap=0.4), "pose_num_scales")):
+            args = dict(frame=frame, model_directory=root, device=dev)
+            args.update(kw)
+            with pytest.raises(RuntimeError, match=msg):
+                sc.run(sc.io.Output(sc.ops.OpenPose(**args), [NamedStream(sc, "bad")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
