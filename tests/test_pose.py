@@ -344,3 +344,36 @@ def test_resize_nms_output_chain_recovers_planted_people(hip_ctx):
         d = np.abs(got[:, 1, :2] - (truth[p, 1] * 8 + 3.5)).sum(axis=1)
         person = got[int(d.argmin())]
         assert np.abs(person[:, :2] - (truth[p] * 8 + 3.5)).max() < 8.0 and (person[:, 2] > 0).all()
+
+
+def test_resize_merge_oracle_and_pose_type():
+    """CPU: merging scales in the oracle (one scale = the plain resize; constants stay constant; a smaller scale sampled
+    with its effective extent shows the same picture), and the Pose element type / PoseList reader."""
+    from scannertools_amd import pose_detection as pd
+    rng = np.random.default_rng(2)
+    m = rng.random((2, 6, 9), dtype=np.float32)
+    np.testing.assert_array_equal(oracle.cpm2_resize_merge_maps([m], [(6, 9)], 48, 72), oracle.cpm2_resize_maps(m, 48, 72))
+    c0, c1 = np.full((1, 6, 9), 0.25, np.float32), np.full((1, 5, 7), 0.75, np.float32)
+    np.testing.assert_allclose(oracle.cpm2_resize_merge_maps([c0, c1], [(6, 9), (4.2, 6.3)], 48, 72), 0.5, atol=1e-6)
+    yy, xx = np.mgrid[0:12, 0:16].astype(np.float32)
+    big = (0.1 * xx + 0.05 * yy)[None]
+    # the same ramp seen at 3/4 of the resolution: pixel i of the small map sits at (i + 0.5) / 0.75 - 0.5 of the big one
+    small = (0.1 * ((xx[:9, :12] + 0.5) / 0.75 - 0.5) + 0.05 * ((yy[:9, :12] + 0.5) / 0.75 - 0.5))[None].astype(np.float32)
+    a = oracle.cpm2_resize_maps(big, 96, 128)
+    b = oracle.cpm2_resize_maps(small, 96, 128, eff=(9.0, 12.0))
+    np.testing.assert_allclose(a[:, 16:60, 16:80], b[:, 16:60, 16:80], atol=2e-5)
+
+    kp = rng.random((pd.Pose.total_keypoints(), 3)).astype(np.float32)
+    p = pd.Pose(0.7, kp)
+    q = pd.Pose.deserialize(p.serialize())
+    assert abs(q.score() - 0.7) < 1e-6 and np.array_equal(q.pose_keypoints(), kp[:18]) and q.face_keypoints().shape == (70, 3)
+    assert [h.shape for h in q.hand_keypoints()] == [(21, 3), (21, 3)]
+    assert pd.Pose.kp_size() == 1 + (18 + 70 + 42) * 3 and (pd.Pose.Nose, pd.Pose.Neck, pd.Pose.LEar, pd.Pose.Background) == (0, 1, 17, 18)
+    assert pd.pose_list(b"\0\0\0\0") == [] and len(pd.pose_list(p.serialize() * 3)) == 3 and pd.pose_list(None) == []
+    (x0, y0), (x1, y1), s = p.body_bbox()
+    assert x0 <= x1 and y0 <= y1 and 0 < s < 1
+    assert p.distance_to(q) == 0.0 and p.face_bbox()[2] > 0
+    img = np.zeros((64, 96, 3), np.uint8)
+    assert p.draw(img, thickness=3).any()
+    far = pd.Pose(0.1, np.zeros_like(kp))
+    assert p.distance_to(far) == float("inf") and far.face_bbox() == [(0, 0), (0, 0), 0]
