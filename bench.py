@@ -285,6 +285,31 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
             "resize_maps_GBs": nb5 * 57 * nh5 * nw5 * 4 / (kms5[_native.K_CPM2_RESIZE][1] / 2 * 1e-3) / 1e9,
             "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
                        "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())}}
+        # the same work through the reference's user-facing op: sc.ops.OpenPose on device frames (kernel class: transform,
+        # network, merge, nms, limb scores, assembly of people on the host, element formatting), one scale, batch 32;
+        # the model file holds the same random weights
+        try:
+            import shutil
+            import tempfile
+            from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+            mdir = tempfile.mkdtemp(prefix="st_openpose_")
+            os.makedirs(os.path.join(mdir, "pose", "coco"))
+            pose_net.write_caffemodel(os.path.join(mdir, "pose", "coco", "pose_iter_440000.caffemodel"), net.weights)
+            sc5c = Client(device_id=device.index)
+            sc5c.ingest_frames("v5", batches[0][:2 * nb5])
+            node5 = sc5c.ops.OpenPose(frame=sc5c.io.Input([NamedVideoStream(sc5c, "v5")]), model_directory=mdir, device=DeviceType.GPU, batch=nb5)
+            sc5c.execute_seconds, sc5c.steady_seconds, sc5c.steady_rows = 0.0, 0.0, 0
+            o5 = NamedStream(sc5c, "pose5")
+            sc5c.run(sc5c.io.Output(node5, [o5]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+            out["config5_pose_conv_stack"]["openpose_op"] = {
+                "what": "sc.ops.OpenPose(frame, pose_num_scales=1, device=GPU, batch=%d) on %d device frames: time inside the second "
+                        "execute() call (the first one allocates the instance's device buffers); the random network fills every "
+                        "frame with the maximum of candidate joints and people, the worst case for the host-side assembly" % (nb5, 2 * nb5),
+                "frames_per_s": sc5c.steady_rows / sc5c.steady_seconds, "first_call_frames_per_s": nb5 / (sc5c.execute_seconds - sc5c.steady_seconds),
+                "people_in_first_frame": len(list(o5.load())[0])}
+            shutil.rmtree(mdir, ignore_errors=True)
+        except Exception as e:  # auxiliary record
+            out["config5_pose_conv_stack"]["openpose_op"] = {"error": repr(e)}
         del net, maps, joints, limb
         torch.cuda.empty_cache()
 

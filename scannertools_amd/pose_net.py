@@ -136,6 +136,26 @@ def read_caffemodel(path):
     return out
 
 
+def write_caffemodel(path, weights):
+    """Writes {architecture layer name: (weight (cout, cin, k, k), bias)} (PoseNet.weights) as a caffemodel file with the
+    published layer names: NetParameter{name, layer{name, type, blobs{shape, data}}}.  Used by tests and the benchmark
+    to hand the kernel classes a model file when only random weights exist."""
+    from . import _proto
+
+    def blob(arr):
+        arr = np.ascontiguousarray(arr, dtype="<f4")
+        return _proto.message(7, _proto.message(1, b"".join(_proto._varint(d) for d in arr.shape))) + _proto.message(5, arr.tobytes())
+
+    with open(path, "wb") as fh:
+        fh.write(_proto.message(1, b"pose"))
+        for (name, *_), cname in zip(all_layers(), caffe_layer_names()):
+            wt, b = weights[name]
+            wt = wt.numpy() if hasattr(wt, "numpy") else wt
+            b = b.numpy() if hasattr(b, "numpy") else b
+            fh.write(_proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
+                                    _proto.message(7, blob(wt)) + _proto.message(7, blob(b))))
+
+
 def check_caffemodel(path):
     """Number of layers of the architecture whose weights the file holds with the right sizes (92 = usable), through the
     op library's own reader (scannertools_caffe_check_model; no GPU needed).  Raises ValueError with the reader's message."""

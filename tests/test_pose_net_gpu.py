@@ -149,21 +149,11 @@ def test_whole_pose_pipeline_through_the_engine(hip_ctx):
 def model_dir(hip_ctx, tmp_path_factory):
     """An OpenPose model directory (<dir>/pose/coco/pose_iter_440000.caffemodel, openpose_kernel.cpp:47-52) holding the
     weights of PoseNet(seed=6), written with the wire-format helpers: (directory, caffemodel path, the network)."""
-    from scannertools_amd import _proto
     a = pose_net.PoseNet(hip_ctx, seed=6)
-
-    def blob(arr):
-        return _proto.message(7, _proto.message(1, b"".join(_proto._varint(d) for d in arr.shape))) + _proto.message(5, arr.astype("<f4").tobytes())
-
     root = tmp_path_factory.mktemp("openpose_models")
     path = root / "pose" / "coco" / "pose_iter_440000.caffemodel"
     path.parent.mkdir(parents=True)
-    with open(path, "wb") as fh:
-        fh.write(_proto.message(1, b"pose"))
-        for (name, *_), cname in zip(pose_net.all_layers(), pose_net.caffe_layer_names()):
-            wt, b = a.weights[name]
-            fh.write(_proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
-                                    _proto.message(7, blob(wt.numpy())) + _proto.message(7, blob(b.numpy()))))
+    pose_net.write_caffemodel(str(path), a.weights)
     return str(root), str(path), a
 
 
