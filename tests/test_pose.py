@@ -377,3 +377,59 @@ def test_resize_merge_oracle_and_pose_type():
     assert p.draw(img, thickness=3).any()
     far = pd.Pose(0.1, np.zeros_like(kp))
     assert p.distance_to(far) == float("inf") and far.face_bbox() == [(0, 0), (0, 0), 0]
+
+
+@pytest.mark.gpu
+def test_pose_entry_points_reject_bad_arguments_and_accept_empty_batches(hip_ctx):
+    """Error behaviour of the pose entry points of the C ABI: empty batches are no-ops, malformed requests return
+    ST_ERR_INVALID / ST_ERR_UNSUPPORTED with a message and leave the context usable."""
+    import ctypes
+    import torch
+    from scannertools_amd import _native
+    from scannertools_amd._native import StError
+    L, h = hip_ctx._L, hip_ctx._h
+    hip_ctx._bind()
+    f32 = torch.float32
+    # empty batches
+    assert tuple(hip_ctx.cpm2_resize_maps(torch.empty((0, 4, 4, 8), dtype=f32, device="cuda"), 8, 8).shape) == (0, 8, 8, 8)
+    assert tuple(hip_ctx.cpm2_nms(torch.empty((0, 18, 8, 8), dtype=f32, device="cuda")).shape) == (0, 18, 65, 3)
+    assert tuple(hip_ctx.cpm2_limb_scores(torch.empty((0, 57, 8, 8), dtype=f32, device="cuda"), torch.empty((0, 18, 65, 3), dtype=f32, device="cuda")).shape) == (0, 19, 64, 64)
+    assert tuple(hip_ctx.cpm2_input(torch.empty((0, 16, 16, 3), dtype=torch.uint8, device="cuda"), 1.0).shape)[0] == 0
+    maps = torch.zeros((1, 4, 4, 8), dtype=f32, device="cuda")
+    # resize: channel outside the pixel, more than 64 maps, no scales, too many scales
+    with pytest.raises(StError, match="channel"):
+        hip_ctx.cpm2_resize_maps(maps, 8, 8, chan_map=[0, 9])
+    with pytest.raises(StError):
+        hip_ctx.cpm2_resize_maps(torch.zeros((1, 2, 2, 80), dtype=f32, device="cuda"), 4, 4)
+    with pytest.raises(StError):
+        hip_ctx.cpm2_resize_merge_maps([maps] * 9, [(4, 4)] * 9, 8, 8)
+    with pytest.raises(StError, match="empty extent"):
+        hip_ctx.cpm2_resize_merge_maps([maps], [(0.0, 4.0)], 8, 8)
+    # nms: max_peaks out of range
+    with pytest.raises(StError):
+        hip_ctx.cpm2_nms(torch.zeros((1, 18, 8, 8), dtype=f32, device="cuda"), max_peaks=0)
+    with pytest.raises(StError):
+        hip_ctx.cpm2_nms(torch.zeros((1, 18, 8, 8), dtype=f32, device="cuda"), max_peaks=5000)
+    # conv: channel count not a multiple of 16, even kernel, slice beyond the buffer, misaligned channel offset
+    x = torch.zeros((1, 4, 4, 32), dtype=f32, device="cuda")
+    w = torch.zeros((64, 3, 3, 32), dtype=f32, device="cuda")
+    b = torch.zeros((64,), dtype=f32, device="cuda")
+    y = torch.zeros((1, 4, 4, 64), dtype=f32, device="cuda")
+    vp = ctypes.c_void_p
+
+    def conv(cin=32, xs=32, xoff=0, k=3, cout=64, cop=64, ys=64, yoff=0):
+        return L.st_conv2d_nhwc_f32(h, vp(x.data_ptr()), 1, 4, 4, cin, xs, xoff, vp(w.data_ptr()), vp(b.data_ptr()), k, k, cout, cop, 1, vp(y.data_ptr()), ys, yoff)
+
+    assert conv() == 0
+    assert conv(cin=24) == _native.ST_ERR_INVALID and b"multiple of 16" in L.st_ctx_last_error(h)
+    assert conv(k=4) == _native.ST_ERR_UNSUPPORTED and conv(k=9) == _native.ST_ERR_UNSUPPORTED
+    assert conv(xoff=16) != 0            # 16 + 32 channels > 32
+    assert conv(cin=16, xoff=2) != 0     # offset not a multiple of 4
+    assert conv(cop=96) != 0 and conv(cout=80) != 0 and conv(yoff=8) != 0
+    assert L.st_maxpool2_nhwc_f32(h, vp(x.data_ptr()), 1, 1, 4, 32, 32, vp(y.data_ptr()), 32) != 0
+    assert L.st_maxpool2_nhwc_f32(h, vp(x.data_ptr() + 4), 1, 4, 4, 32, 32, vp(y.data_ptr()), 32) != 0
+    assert L.st_planar_to_nhwc_f32(h, vp(x.data_ptr()), 1, 3, 4, 4, vp(y.data_ptr()), 2) != 0
+    assert b"planar_to_nhwc" in L.st_ctx_last_error(h)
+    # the context still works
+    got = hip_ctx.cpm2_resize_maps(torch.ones((1, 4, 4, 8), dtype=f32, device="cuda"), 8, 8)
+    assert float((got - 1).abs().max()) < 1e-6
