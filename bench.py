@@ -461,7 +461,7 @@ def run_rank(args):
     del rnd
     rnd_gbs = hist_bytes * hist_steps / (rnd_ms * 1e-3) / 1e9 if rnd_ms > 0 else 0.0
 
-    # HBM bytes per k_flow_iter launch from the PMC counters of the committed profile of this same
+    # HBM bytes per k_flow_iter3 launch from the PMC counters of the committed profile of this same
     # command (scripts/profile_round.sh -> scripts/pmc_traffic.py -> profiles/traffic.json):
     # 128-B read requests + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes.  None when the
     # profile is missing or was taken at another batch size / resolution.
