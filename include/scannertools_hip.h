@@ -228,6 +228,16 @@ int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int
  * selects the luma table width as in st_fb_params (15: OpenCV 4.x, 14: <= 3.4.2).
  * st_cvt_color_out_channels() gives the channel count of the output frame (-1: unsupported). */
 enum st_color_code {
+  /* channel layout family: codes 0..3, 5, 9..31 (alpha channel added / dropped / swapped, 16-bit BGR565 / BGR555
+   * pixels as 2-channel frames, gray from / to them) */
+  ST_COLOR_BGR2BGRA = 0, ST_COLOR_BGRA2BGR = 1, ST_COLOR_BGR2RGBA = 2, ST_COLOR_RGBA2BGR = 3, ST_COLOR_BGRA2RGBA = 5,
+  ST_COLOR_GRAY2BGRA = 9, ST_COLOR_BGRA2GRAY = 10, ST_COLOR_RGBA2GRAY = 11,
+  ST_COLOR_BGR2BGR565 = 12, ST_COLOR_RGB2BGR565 = 13, ST_COLOR_BGR5652BGR = 14, ST_COLOR_BGR5652RGB = 15,
+  ST_COLOR_BGRA2BGR565 = 16, ST_COLOR_RGBA2BGR565 = 17, ST_COLOR_BGR5652BGRA = 18, ST_COLOR_BGR5652RGBA = 19,
+  ST_COLOR_GRAY2BGR565 = 20, ST_COLOR_BGR5652GRAY = 21,
+  ST_COLOR_BGR2BGR555 = 22, ST_COLOR_RGB2BGR555 = 23, ST_COLOR_BGR5552BGR = 24, ST_COLOR_BGR5552RGB = 25,
+  ST_COLOR_BGRA2BGR555 = 26, ST_COLOR_RGBA2BGR555 = 27, ST_COLOR_BGR5552BGRA = 28, ST_COLOR_BGR5552RGBA = 29,
+  ST_COLOR_GRAY2BGR555 = 30, ST_COLOR_BGR5552GRAY = 31,
   ST_COLOR_BGR2RGB = 4, ST_COLOR_RGB2BGR = 4,
   ST_COLOR_BGR2GRAY = 6, ST_COLOR_RGB2GRAY = 7,
   ST_COLOR_GRAY2BGR = 8, ST_COLOR_GRAY2RGB = 8,

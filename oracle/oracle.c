@@ -1087,7 +1087,54 @@ ORC_API int orc_cvt_out_channels(int code, int in_channels) {
     case ORC_RGB2HSV: case ORC_HSV2BGR: case ORC_HSV2RGB: case ORC_BGR2HSV_FULL: case ORC_RGB2HSV_FULL:
     case ORC_HSV2BGR_FULL: case ORC_HSV2RGB_FULL: case ORC_BGR2YUV: case ORC_RGB2YUV: case ORC_YUV2BGR: case ORC_YUV2RGB:
       return in_channels == 3 ? 3 : -1;
+    /* channel layout family (cv::cvtColor codes 0..3, 5, 9..31) */
+    case 0: case 2: return in_channels == 3 ? 4 : -1;          /* BGR2BGRA, BGR2RGBA */
+    case 1: case 3: return in_channels == 4 ? 3 : -1;          /* BGRA2BGR, RGBA2BGR */
+    case 5: return in_channels == 4 ? 4 : -1;                  /* BGRA2RGBA */
+    case 9: return in_channels == 1 ? 4 : -1;                  /* GRAY2BGRA */
+    case 10: case 11: return in_channels == 4 ? 1 : -1;        /* BGRA2GRAY, RGBA2GRAY */
+    case 12: case 13: case 22: case 23: return in_channels == 3 ? 2 : -1;   /* BGR / RGB -> BGR565 / BGR555 */
+    case 14: case 15: case 24: case 25: return in_channels == 2 ? 3 : -1;   /* BGR565 / BGR555 -> BGR / RGB */
+    case 16: case 17: case 26: case 27: return in_channels == 4 ? 2 : -1;   /* BGRA / RGBA -> packed */
+    case 18: case 19: case 28: case 29: return in_channels == 2 ? 4 : -1;   /* packed -> BGRA / RGBA */
+    case 20: case 30: return in_channels == 1 ? 2 : -1;                     /* GRAY -> packed */
+    case 21: case 31: return in_channels == 2 ? 1 : -1;                     /* packed -> GRAY */
     default: return -1;
+  }
+}
+
+/* The functors of OpenCV's color_rgb (restated per functor, with their (srccn, dstcn, blueIdx, greenBits) parameters):
+ * RGB2RGB<uchar>: copies / swaps the colour channels, alpha = src alpha or 255.
+ * RGB2RGB5x5: ushort = (b >> 3) | ((g & ~3) << 3) | ((r & ~7) << 8) for 6 green bits,
+ *             (b >> 3) | ((g & ~7) << 2) | ((r & ~7) << 7) | (srccn == 4 && alpha ? 0x8000 : 0) for 5.
+ * RGB5x52RGB: b = t << 3, g = (t >> 3) & ~3, r = (t >> 8) & ~7 (alpha 255) for 6 green bits,
+ *             b = t << 3, g = (t >> 2) & ~7, r = (t >> 7) & ~7 (alpha = t & 0x8000 ? 255 : 0) for 5, each as uchar.
+ * Gray2RGB5x5: t |-> the same packing with b = g = r = t.   RGB5x52Gray: CV_DESCALE(b * 1868 + g * 9617 + r * 4899, 14). */
+static void orc_rgb2rgb(const uint8_t* src, size_t n, int scn, int dcn, int bidx, uint8_t* dst) {
+  for (size_t i = 0; i < n; ++i, src += scn, dst += dcn) {
+    const uint8_t t0 = src[bidx], t1 = src[1], t2 = src[bidx ^ 2];
+    dst[0] = t0; dst[1] = t1; dst[2] = t2;
+    if (dcn == 4) dst[3] = scn == 4 ? src[3] : 255;
+  }
+}
+static void orc_rgb2rgb5x5(const uint8_t* src, size_t n, int scn, int bidx, int green_bits, uint8_t* dst) {
+  for (size_t i = 0; i < n; ++i, src += scn) {
+    unsigned t;
+    if (green_bits == 6) t = (unsigned)(src[bidx] >> 3) | ((unsigned)(src[1] & ~3) << 3) | ((unsigned)(src[bidx ^ 2] & ~7) << 8);
+    else t = (unsigned)(src[bidx] >> 3) | ((unsigned)(src[1] & ~7) << 2) | ((unsigned)(src[bidx ^ 2] & ~7) << 7) | (scn == 4 && src[3] ? 0x8000u : 0u);
+    dst[2 * i] = (uint8_t)t; dst[2 * i + 1] = (uint8_t)(t >> 8);
+  }
+}
+static void orc_rgb5x52rgb(const uint8_t* src, size_t n, int dcn, int bidx, int green_bits, uint8_t* dst) {
+  for (size_t i = 0; i < n; ++i, dst += dcn) {
+    const unsigned t = src[2 * i] | ((unsigned)src[2 * i + 1] << 8);
+    if (green_bits == 6) {
+      dst[bidx] = (uint8_t)(t << 3); dst[1] = (uint8_t)((t >> 3) & ~3u); dst[bidx ^ 2] = (uint8_t)((t >> 8) & ~7u);
+      if (dcn == 4) dst[3] = 255;
+    } else {
+      dst[bidx] = (uint8_t)(t << 3); dst[1] = (uint8_t)((t >> 2) & ~7u); dst[bidx ^ 2] = (uint8_t)((t >> 7) & ~7u);
+      if (dcn == 4) dst[3] = (t & 0x8000u) ? 255 : 0;
+    }
   }
 }
 
@@ -1113,7 +1160,36 @@ static void orc_hsv2rgb_native(float h, float s, float v, float hscale, float* b
 ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code, int gray_bits, uint8_t* dst) {
   if (orc_cvt_out_channels(code, cn) < 0) return 1;
   const size_t n = (size_t)h * w;
-  if (code == ORC_BGR2RGB) {
+  if (code <= 3 || code == 5) {        /* RGB2RGB<uchar>(scn, dcn, blueIdx): blueIdx 2 swaps */
+    orc_rgb2rgb(src, n, cn, (code == 0 || code == 2) ? 4 : (code == 5 ? 4 : 3), (code == 2 || code == 3 || code == 5) ? 2 : 0, dst);
+  } else if (code == 9) {              /* Gray2RGB<uchar>(4) */
+    for (size_t i = 0; i < n; ++i) { dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = src[i]; dst[4 * i + 3] = 255; }
+  } else if (code == 10 || code == 11) {  /* RGB2Gray<uchar>(4, blueIdx) */
+    int cb, cg, cr, bits = gray_bits;
+    if (bits == 14) { cb = 1868; cg = 9617; cr = 4899; } else { bits = 15; cb = 3735; cg = 19235; cr = 9798; }
+    const int bi = code == 10 ? 0 : 2;
+    for (size_t i = 0; i < n; ++i)
+      dst[i] = (uint8_t)((src[4 * i + bi] * cb + src[4 * i + 1] * cg + src[4 * i + (bi ^ 2)] * cr + (1 << (bits - 1))) >> bits);
+  } else if (code >= 12 && code <= 31) {
+    const int gb = code >= 22 ? 5 : 6, c = code >= 22 ? code - 22 : code - 12;
+    if (c == 0 || c == 1 || c == 4 || c == 5) orc_rgb2rgb5x5(src, n, cn, (c & 1) ? 2 : 0, gb, dst);
+    else if (c == 2 || c == 3 || c == 6 || c == 7) orc_rgb5x52rgb(src, n, c >= 6 ? 4 : 3, (c & 1) ? 2 : 0, gb, dst);
+    else if (c == 8) {                 /* Gray2RGB5x5 */
+      for (size_t i = 0; i < n; ++i) {
+        unsigned t = src[i];
+        if (gb == 6) t = (t >> 3) | ((t & ~3u) << 3) | ((t & ~7u) << 8);
+        else { t >>= 3; t = t | (t << 5) | (t << 10); }
+        dst[2 * i] = (uint8_t)t; dst[2 * i + 1] = (uint8_t)(t >> 8);
+      }
+    } else {                           /* RGB5x52Gray */
+      for (size_t i = 0; i < n; ++i) {
+        const unsigned t = src[2 * i] | ((unsigned)src[2 * i + 1] << 8);
+        const int v = gb == 6 ? (int)((t << 3) & 0xf8) * 1868 + (int)((t >> 3) & 0xfc) * 9617 + (int)((t >> 8) & 0xf8) * 4899
+                              : (int)((t << 3) & 0xf8) * 1868 + (int)((t >> 2) & 0xf8) * 9617 + (int)((t >> 7) & 0xf8) * 4899;
+        dst[i] = (uint8_t)((v + (1 << 13)) >> 14);
+      }
+    }
+  } else if (code == ORC_BGR2RGB) {
     for (size_t i = 0; i < n; ++i) { dst[3 * i] = src[3 * i + 2]; dst[3 * i + 1] = src[3 * i + 1]; dst[3 * i + 2] = src[3 * i]; }
   } else if (code == ORC_BGR2GRAY || code == ORC_RGB2GRAY) {
     int cb, cg, cr, bits = gray_bits;

@@ -20,7 +20,16 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_YCrCb2BGR": 38, "COLOR_YCrCb2RGB": 39, "COLOR_BGR2HSV": 40, "COLOR_RGB2HSV": 41,
                "COLOR_HSV2BGR": 54, "COLOR_HSV2RGB": 55, "COLOR_BGR2HSV_FULL": 66, "COLOR_RGB2HSV_FULL": 67,
                "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
-               "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85}
+               "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85,
+               # channel layout family (alpha channel, 16-bit packed pixels)
+               "COLOR_BGR2BGRA": 0, "COLOR_RGB2RGBA": 0, "COLOR_BGRA2BGR": 1, "COLOR_RGBA2RGB": 1, "COLOR_BGR2RGBA": 2,
+               "COLOR_RGB2BGRA": 2, "COLOR_RGBA2BGR": 3, "COLOR_BGRA2RGB": 3, "COLOR_BGRA2RGBA": 5, "COLOR_RGBA2BGRA": 5,
+               "COLOR_GRAY2BGRA": 9, "COLOR_GRAY2RGBA": 9, "COLOR_BGRA2GRAY": 10, "COLOR_RGBA2GRAY": 11,
+               "COLOR_BGR2BGR565": 12, "COLOR_RGB2BGR565": 13, "COLOR_BGR5652BGR": 14, "COLOR_BGR5652RGB": 15,
+               "COLOR_BGRA2BGR565": 16, "COLOR_RGBA2BGR565": 17, "COLOR_BGR5652BGRA": 18, "COLOR_BGR5652RGBA": 19,
+               "COLOR_GRAY2BGR565": 20, "COLOR_BGR5652GRAY": 21, "COLOR_BGR2BGR555": 22, "COLOR_RGB2BGR555": 23,
+               "COLOR_BGR5552BGR": 24, "COLOR_BGR5552RGB": 25, "COLOR_BGRA2BGR555": 26, "COLOR_RGBA2BGR555": 27,
+               "COLOR_BGR5552BGRA": 28, "COLOR_BGR5552RGBA": 29, "COLOR_GRAY2BGR555": 30, "COLOR_BGR5552GRAY": 31}
 K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_CPM2_INPUT, K_CPM2_LIMBS, K_CONV, K_CPM2_RESIZE, K_CPM2_NMS, K_COUNT = range(17)
 KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color", "cpm2_input", "cpm2_limbs", "conv"]
 

@@ -361,7 +361,46 @@ struct CvtArgsK {
   long long npix;
   int code;                // cv::ColorConversionCodes value
   int cb, cg, cr, rnd, shift, bi;  // gray weights (bi = byte holding blue)
+  // layout family (alpha channel, 16-bit packed pixels): source / destination kind and the byte that holds blue
+  int layout, sk, sbi, dk, dbi;
 };
+
+// pixel kinds of the layout family
+enum { PK_C3 = 0, PK_C4 = 1, PK_GRAY = 2, PK_565 = 3, PK_555 = 4 };
+
+// cv::cvtColor codes 0..3, 5, 9..31: the conversions that only move, drop, add or pack channels
+// (RGB2RGB<uchar>, Gray2RGB, RGB2Gray on 4 channels, RGB2RGB5x5, RGB5x52RGB, Gray2RGB5x5, RGB5x52Gray)
+struct CvtLayout { int sk, sbi, dk, dbi; };
+__host__ __device__ inline bool cvt_layout_of(int code, CvtLayout* l) {
+  switch (code) {
+    case 0: *l = {PK_C3, 0, PK_C4, 0}; return true;   // BGR2BGRA = RGB2RGBA
+    case 1: *l = {PK_C4, 0, PK_C3, 0}; return true;   // BGRA2BGR = RGBA2RGB
+    case 2: *l = {PK_C3, 0, PK_C4, 2}; return true;   // BGR2RGBA = RGB2BGRA
+    case 3: *l = {PK_C4, 0, PK_C3, 2}; return true;   // RGBA2BGR = BGRA2RGB
+    case 5: *l = {PK_C4, 0, PK_C4, 2}; return true;   // BGRA2RGBA = RGBA2BGRA
+    case 9: *l = {PK_GRAY, 0, PK_C4, 0}; return true;  // GRAY2BGRA = GRAY2RGBA
+    case 10: *l = {PK_C4, 0, PK_GRAY, 0}; return true;  // BGRA2GRAY
+    case 11: *l = {PK_C4, 2, PK_GRAY, 0}; return true;  // RGBA2GRAY
+    default: break;
+  }
+  if (code >= 12 && code <= 31) {
+    const int k = code >= 22 ? PK_555 : PK_565, c = code >= 22 ? code - 22 : code - 12;
+    switch (c) {
+      case 0: *l = {PK_C3, 0, k, 0}; return true;      // BGR2BGR5x5
+      case 1: *l = {PK_C3, 2, k, 0}; return true;      // RGB2BGR5x5
+      case 2: *l = {k, 0, PK_C3, 0}; return true;      // BGR5x52BGR
+      case 3: *l = {k, 0, PK_C3, 2}; return true;      // BGR5x52RGB
+      case 4: *l = {PK_C4, 0, k, 0}; return true;      // BGRA2BGR5x5
+      case 5: *l = {PK_C4, 2, k, 0}; return true;      // RGBA2BGR5x5
+      case 6: *l = {k, 0, PK_C4, 0}; return true;      // BGR5x52BGRA
+      case 7: *l = {k, 0, PK_C4, 2}; return true;      // BGR5x52RGBA
+      case 8: *l = {PK_GRAY, 0, k, 0}; return true;    // GRAY2BGR5x5
+      case 9: *l = {k, 0, PK_GRAY, 0}; return true;    // BGR5x52GRAY
+    }
+  }
+  return false;
+}
+__host__ __device__ inline int cvt_kind_channels(int k) { return k == PK_C3 ? 3 : (k == PK_C4 ? 4 : (k == PK_GRAY ? 1 : 2)); }
 
 __device__ __forceinline__ bool cvt_is_to_hsv(int code) {
   return code == ST_COLOR_BGR2HSV || code == ST_COLOR_RGB2HSV || code == ST_COLOR_BGR2HSV_FULL || code == ST_COLOR_RGB2HSV_FULL;
@@ -380,7 +419,37 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
   const uint8_t* __restrict__ src = a.src[blockIdx.y];
   uint8_t* __restrict__ dst = a.dst[blockIdx.y];
   for (long long i = (long long)blockIdx.x * 256 + t; i < a.npix; i += (long long)gridDim.x * 256) {
-    if (a.code == ST_COLOR_BGR2RGB) {
+    if (a.layout) {
+      // decode to (b, g, r, alpha), encode in the destination kind
+      int b, g, r, al = 255;
+      bool packed_src = false;
+      if (a.sk == PK_C3) {
+        b = src[3 * i + a.sbi]; g = src[3 * i + 1]; r = src[3 * i + (a.sbi ^ 2)];
+      } else if (a.sk == PK_C4) {
+        b = src[4 * i + a.sbi]; g = src[4 * i + 1]; r = src[4 * i + (a.sbi ^ 2)]; al = src[4 * i + 3];
+      } else if (a.sk == PK_GRAY) {
+        b = g = r = src[i];
+      } else {
+        const unsigned tt = src[2 * i] | ((unsigned)src[2 * i + 1] << 8);
+        packed_src = true;
+        if (a.sk == PK_565) { b = (tt << 3) & 0xff; g = (tt >> 3) & 0xfc; r = (tt >> 8) & 0xf8; }
+        else { b = (tt << 3) & 0xf8; g = (tt >> 2) & 0xf8; r = (tt >> 7) & 0xf8; al = (tt & 0x8000) ? 255 : 0; }
+      }
+      if (a.dk == PK_C3) {
+        dst[3 * i + a.dbi] = (uint8_t)b; dst[3 * i + 1] = (uint8_t)g; dst[3 * i + (a.dbi ^ 2)] = (uint8_t)r;
+      } else if (a.dk == PK_C4) {
+        dst[4 * i + a.dbi] = (uint8_t)b; dst[4 * i + 1] = (uint8_t)g; dst[4 * i + (a.dbi ^ 2)] = (uint8_t)r; dst[4 * i + 3] = (uint8_t)al;
+      } else if (a.dk == PK_GRAY) {
+        // from 4 channels: RGB2Gray<uchar> (the op's gray table); from packed pixels: RGB5x52Gray, 14-bit weights
+        dst[i] = packed_src ? (uint8_t)((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14)
+                            : (uint8_t)((b * a.cb + g * a.cg + r * a.cr + a.rnd) >> a.shift);
+      } else {
+        unsigned tt;
+        if (a.dk == PK_565) tt = (unsigned)(b >> 3) | ((unsigned)(g & ~3) << 3) | ((unsigned)(r & ~7) << 8);
+        else tt = (unsigned)(b >> 3) | ((unsigned)(g & ~7) << 2) | ((unsigned)(r & ~7) << 7) | ((a.sk == PK_C4 && al) ? 0x8000u : 0u);
+        dst[2 * i] = (uint8_t)(tt & 0xff); dst[2 * i + 1] = (uint8_t)(tt >> 8);
+      }
+    } else if (a.code == ST_COLOR_BGR2RGB) {
       const uint8_t c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
       dst[3 * i] = c2; dst[3 * i + 1] = c1; dst[3 * i + 2] = c0;
     } else if (a.code == ST_COLOR_BGR2GRAY || a.code == ST_COLOR_RGB2GRAY) {
@@ -638,8 +707,11 @@ ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
       return in_channels == 3 ? 3 : -1;
     case ST_COLOR_BGR2GRAY: case ST_COLOR_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ST_COLOR_GRAY2BGR: return in_channels == 1 ? 3 : -1;
-    default: return -1;
+    default: break;
   }
+  CvtLayout l;
+  if (cvt_layout_of(code, &l)) return in_channels == cvt_kind_channels(l.sk) ? cvt_kind_channels(l.dk) : -1;
+  return -1;
 }
 
 ST_EXPORT int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
@@ -665,6 +737,9 @@ ST_EXPORT int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_de
   if (gray_bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }
   a.shift = gray_bits; a.rnd = 1 << (gray_bits - 1);
   a.bi = code == ST_COLOR_RGB2GRAY ? 2 : 0;
+  CvtLayout lay;
+  a.layout = cvt_layout_of(code, &lay) ? 1 : 0;
+  if (a.layout) { a.sk = lay.sk; a.sbi = lay.sbi; a.dk = lay.dk; a.dbi = lay.dbi; } else { a.sk = a.sbi = a.dk = a.dbi = 0; }
   long long bx = (a.npix + 255) / 256;
   if (bx > 4096) bx = 4096;
   for (int f0 = 0; f0 < n; f0 += 65535) {

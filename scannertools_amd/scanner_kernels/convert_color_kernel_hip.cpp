@@ -8,7 +8,8 @@
 // cv::cvtColor / cvc::cvtColor calls are replaced by ONE st_cvt_color_u8_batch() call per execute().
 // Implemented names: COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR,
 // COLOR_GRAY2RGB, COLOR_BGR/RGB2YCrCb, COLOR_YCrCb2BGR/RGB, COLOR_BGR/RGB2YUV, COLOR_YUV2BGR/RGB,
-// COLOR_BGR/RGB2HSV, COLOR_HSV2BGR/RGB and the four _FULL hue-range variants; an unknown name invalidates the stream as in the reference
+// COLOR_BGR/RGB2HSV, COLOR_HSV2BGR/RGB and the four _FULL hue-range variants, and the channel layout family (codes 0..3, 5,
+// 9..31: BGRA / RGBA, BGR565, BGR555, gray from / to them); an unknown name invalidates the stream as in the reference
 // (:231-236), a name of the reference's table that is not implemented here is reported the same way
 // instead of being run on the CPU.  SCANNERTOOLS_GRAY_BITS (15 default, 14) selects the luma table
 // width of the OpenCV build being replaced.
@@ -37,6 +38,19 @@ const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
     {u8"COLOR_HSV2BGR_FULL", ST_COLOR_HSV2BGR_FULL}, {u8"COLOR_HSV2RGB_FULL", ST_COLOR_HSV2RGB_FULL},
     {u8"COLOR_BGR2YUV", ST_COLOR_BGR2YUV},   {u8"COLOR_RGB2YUV", ST_COLOR_RGB2YUV},
     {u8"COLOR_YUV2BGR", ST_COLOR_YUV2BGR},   {u8"COLOR_YUV2RGB", ST_COLOR_YUV2RGB},
+    // channel layout family: alpha channel added / dropped / swapped, 16-bit packed pixels (2-channel frames)
+    {u8"COLOR_BGR2BGRA", ST_COLOR_BGR2BGRA}, {u8"COLOR_RGB2RGBA", ST_COLOR_BGR2BGRA}, {u8"COLOR_BGRA2BGR", ST_COLOR_BGRA2BGR},
+    {u8"COLOR_RGBA2RGB", ST_COLOR_BGRA2BGR}, {u8"COLOR_BGR2RGBA", ST_COLOR_BGR2RGBA}, {u8"COLOR_RGB2BGRA", ST_COLOR_BGR2RGBA},
+    {u8"COLOR_RGBA2BGR", ST_COLOR_RGBA2BGR}, {u8"COLOR_BGRA2RGB", ST_COLOR_RGBA2BGR}, {u8"COLOR_BGRA2RGBA", ST_COLOR_BGRA2RGBA},
+    {u8"COLOR_RGBA2BGRA", ST_COLOR_BGRA2RGBA}, {u8"COLOR_GRAY2BGRA", ST_COLOR_GRAY2BGRA}, {u8"COLOR_GRAY2RGBA", ST_COLOR_GRAY2BGRA},
+    {u8"COLOR_BGRA2GRAY", ST_COLOR_BGRA2GRAY}, {u8"COLOR_RGBA2GRAY", ST_COLOR_RGBA2GRAY},
+    {u8"COLOR_BGR2BGR565", ST_COLOR_BGR2BGR565}, {u8"COLOR_RGB2BGR565", ST_COLOR_RGB2BGR565}, {u8"COLOR_BGR5652BGR", ST_COLOR_BGR5652BGR},
+    {u8"COLOR_BGR5652RGB", ST_COLOR_BGR5652RGB}, {u8"COLOR_BGRA2BGR565", ST_COLOR_BGRA2BGR565}, {u8"COLOR_RGBA2BGR565", ST_COLOR_RGBA2BGR565},
+    {u8"COLOR_BGR5652BGRA", ST_COLOR_BGR5652BGRA}, {u8"COLOR_BGR5652RGBA", ST_COLOR_BGR5652RGBA}, {u8"COLOR_GRAY2BGR565", ST_COLOR_GRAY2BGR565},
+    {u8"COLOR_BGR5652GRAY", ST_COLOR_BGR5652GRAY}, {u8"COLOR_BGR2BGR555", ST_COLOR_BGR2BGR555}, {u8"COLOR_RGB2BGR555", ST_COLOR_RGB2BGR555},
+    {u8"COLOR_BGR5552BGR", ST_COLOR_BGR5552BGR}, {u8"COLOR_BGR5552RGB", ST_COLOR_BGR5552RGB}, {u8"COLOR_BGRA2BGR555", ST_COLOR_BGRA2BGR555},
+    {u8"COLOR_RGBA2BGR555", ST_COLOR_RGBA2BGR555}, {u8"COLOR_BGR5552BGRA", ST_COLOR_BGR5552BGRA}, {u8"COLOR_BGR5552RGBA", ST_COLOR_BGR5552RGBA},
+    {u8"COLOR_GRAY2BGR555", ST_COLOR_GRAY2BGR555}, {u8"COLOR_BGR5552GRAY", ST_COLOR_BGR5552GRAY},
 };
 }
 

@@ -34,6 +34,22 @@ def test_histogram_and_color_against_opencv():
                  "COLOR_RGB2HSV", "COLOR_HSV2BGR", "COLOR_HSV2RGB", "COLOR_BGR2HSV_FULL", "COLOR_RGB2HSV_FULL",
                  "COLOR_HSV2BGR_FULL", "COLOR_HSV2RGB_FULL", "COLOR_BGR2YUV", "COLOR_RGB2YUV", "COLOR_YUV2BGR", "COLOR_YUV2RGB"):
         np.testing.assert_array_equal(oracle.cvt_color(f, getattr(oracle, name)), cv2.cvtColor(f, getattr(cv2, name)), err_msg=name)
+    # channel layout family (codes 0..3, 5, 9..31): every code on a source of the channel count it takes, the enum
+    # value itself checked against cv2's
+    from scannertools_amd._native import COLOR_CODES
+    rng = np.random.default_rng(5)
+    f4 = np.ascontiguousarray(np.concatenate([f, rng.integers(0, 256, f.shape[:2] + (1,), dtype=np.uint8)], axis=2))
+    f4[:5, :5, 3] = 0
+    f2 = rng.integers(0, 256, f.shape[:2] + (2,), dtype=np.uint8)
+    srcs = {1: np.ascontiguousarray(f[..., :1]), 2: f2, 3: f, 4: f4}
+    for name, code in COLOR_CODES.items():
+        if not (code <= 3 or code == 5 or 9 <= code <= 31):
+            continue
+        assert getattr(cv2, name) == code, name
+        cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(code, c) > 0)
+        ref = cv2.cvtColor(srcs[cin], code)
+        got = oracle.cvt_color(srcs[cin], code, gray_bits=bits if code in (10, 11) else 15)
+        np.testing.assert_array_equal(got.reshape(ref.shape) if got.shape[2] == 1 else got, ref, err_msg=name)
 
 
 def test_resize_against_opencv():

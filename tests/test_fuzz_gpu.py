@@ -39,7 +39,8 @@ def test_fuzz_integer_ops(hip_ctx, seed):
             np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh, interp),
                                           err_msg="resize %dx%d -> %dx%d interp %d" % (h, w, dh, dw, interp))
         name = list(COLOR_CODES)[int(rng.integers(0, len(COLOR_CODES)))]
-        src = frames[..., :1] if "GRAY2" in name else frames
+        cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(COLOR_CODES[name], c) > 0)
+        src = np.ascontiguousarray(np.concatenate([frames, frames[..., ::-1]], axis=3)[..., :cin])   # 1, 2, 3 or 4 input channels
         got = hip_ctx.cvt_color(_cu(src), name).cpu().numpy()
         for i in range(n):
             np.testing.assert_array_equal(got[i], oracle.cvt_color(src[i], COLOR_CODES[name]), err_msg=name)

@@ -221,6 +221,47 @@ def test_cvt_color_exhaustive_hsv_and_known_answers(hip_ctx):
         hip_ctx.cvt_color(torch.from_numpy(g).cuda(), "COLOR_BGR2HSV")             # needs 3 channels
 
 
+def test_cvt_color_layout_family_exhaustive(hip_ctx):
+    """cv::cvtColor codes 0..3, 5, 9..31 (alpha channel added / dropped / swapped, BGR565 / BGR555 packed pixels, gray from /
+    to them): every code on every value its input can take (all 65 536 packed pixels; the byte cube for 3- and 4-channel
+    sources), bit for bit against the oracle's per-functor restatement, plus the identities the packing implies."""
+    from scannertools_amd._native import COLOR_CODES
+    v = np.unique(np.concatenate([np.arange(0, 256, 5), [1, 2, 3, 4, 6, 7, 8, 248, 251, 252, 253, 254, 255]])).astype(np.uint8)
+    cube3 = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, len(v), -1, 3))
+    alpha = (np.arange(cube3.shape[1] * cube3.shape[2]).reshape(1, cube3.shape[1], -1, 1) * 37 % 256).astype(np.uint8)
+    alpha[0, 0, :7, 0] = 0                      # some fully transparent pixels (the 555 alpha bit)
+    cube4 = np.ascontiguousarray(np.concatenate([cube3, alpha], axis=3))
+    packed = np.arange(65536, dtype="<u2").view(np.uint8).reshape(1, 256, 256, 2)
+    gray = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1)
+    sources = {1: gray, 2: np.ascontiguousarray(packed), 3: cube3, 4: cube4}
+    names = [n for n, c in COLOR_CODES.items() if c <= 3 or c == 5 or 9 <= c <= 31]
+    assert len(names) == 34 and len({COLOR_CODES[n] for n in names}) == 28
+    for name in names:
+        code = COLOR_CODES[name]
+        cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(code, c) > 0)
+        src = sources[cin]
+        got = hip_ctx.cvt_color(torch.from_numpy(src).cuda(), name).cpu().numpy()
+        np.testing.assert_array_equal(got[0], oracle.cvt_color(src[0], code), err_msg=name)
+        for wrong in (1, 2, 3, 4):
+            if wrong != cin:
+                with pytest.raises(ValueError):
+                    hip_ctx.cvt_color(torch.from_numpy(sources[wrong]).cuda(), name)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    # identities: alpha added then dropped; swap twice; packing keeps the top 5 / 6 / 5 bits; 565 -> gray == gray of the unpacked pixel (14-bit table)
+    a4 = hip_ctx.cvt_color(cu(cube3), "COLOR_BGR2BGRA")
+    assert int(a4[..., 3].min()) == 255 and torch.equal(hip_ctx.cvt_color(a4, "COLOR_BGRA2BGR"), cu(cube3))
+    assert torch.equal(hip_ctx.cvt_color(hip_ctx.cvt_color(cu(cube4), "COLOR_BGRA2RGBA"), "COLOR_RGBA2BGRA"), cu(cube4))
+    p565 = hip_ctx.cvt_color(cu(cube3), "COLOR_BGR2BGR565")
+    assert torch.equal(hip_ctx.cvt_color(p565, "COLOR_BGR5652BGR"), cu(cube3 & np.array([0xF8, 0xFC, 0xF8], np.uint8)))
+    assert torch.equal(hip_ctx.cvt_color(p565, "COLOR_BGR5652RGB"), cu(np.ascontiguousarray((cube3 & np.array([0xF8, 0xFC, 0xF8], np.uint8))[..., ::-1])))
+    p555 = hip_ctx.cvt_color(cu(cube4), "COLOR_BGRA2BGR555")
+    back = hip_ctx.cvt_color(p555, "COLOR_BGR5552BGRA").cpu().numpy()
+    np.testing.assert_array_equal(back[..., :3], cube4[..., :3] & 0xF8)
+    np.testing.assert_array_equal(back[..., 3], np.where(cube4[..., 3] != 0, 255, 0))
+    g = hip_ctx.cvt_color(p565, "COLOR_BGR5652GRAY")
+    assert torch.equal(g, hip_ctx.cvt_color(hip_ctx.cvt_color(p565, "COLOR_BGR5652BGR"), "COLOR_BGR2GRAY", gray_bits=14))
+
+
 @pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
 def test_hsv_histogram_pipeline(device):
     """old/histograms.py:21-40 (compute_hsv_histograms): colour conversion -> Histogram, plus a
@@ -239,6 +280,29 @@ def test_hsv_histogram_pipeline(device):
         np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(oracle.cvt_color(frames[i], oracle.COLOR_RGB2HSV), 16))
         assert gg.shape == (60, 80, 1)
         np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))
+
+
+@pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
+def test_layout_conversions_through_the_kernel_classes(device):
+    """ConvertColor with output frames of 4 and 2 channels, chained (RGB -> RGBA -> BGR565 -> gray): the op's
+    output-shape probe (convert_color_kernel.cpp:252-277) follows the conversion."""
+    from scannertools_amd.engine import NamedStream
+    sc = Client()
+    frames = random_frames(12, 4, 33, 47)
+    sc.ingest_frames('v', frames)
+    frame = sc.io.Input([NamedVideoStream(sc, 'v')])
+    rgba = sc.ops.ConvertColor(frame=frame, conversion='COLOR_RGB2RGBA', device=device, batch=3)
+    packed = sc.ops.ConvertColor(frame=rgba, conversion='COLOR_RGBA2BGR565', device=device, batch=2)
+    gray = sc.ops.ConvertColor(frame=packed, conversion='COLOR_BGR5652GRAY', device=device)
+    o = [NamedStream(sc, n) for n in ('a', 'p', 'g')]
+    sc.run([sc.io.Output(rgba, [o[0]]), sc.io.Output(packed, [o[1]]), sc.io.Output(gray, [o[2]])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    for i, (a, p, g) in enumerate(zip(o[0].load(), o[1].load(), o[2].load())):
+        ra = oracle.cvt_color(frames[i], 0)
+        rp = oracle.cvt_color(ra, 17)
+        assert a.shape == (33, 47, 4) and p.shape == (33, 47, 2) and g.shape == (33, 47, 1)
+        np.testing.assert_array_equal(a, ra)
+        np.testing.assert_array_equal(p, rp)
+        np.testing.assert_array_equal(g, oracle.cvt_color(rp, 21))
 
 
 def test_empty_batches_and_bad_handles(hip_ctx):
