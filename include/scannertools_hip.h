@@ -241,6 +241,7 @@ enum st_color_code {
   ST_COLOR_BGR2RGB = 4, ST_COLOR_RGB2BGR = 4,
   ST_COLOR_BGR2GRAY = 6, ST_COLOR_RGB2GRAY = 7,
   ST_COLOR_GRAY2BGR = 8, ST_COLOR_GRAY2RGB = 8,
+  ST_COLOR_BGR2XYZ = 32, ST_COLOR_RGB2XYZ = 33, ST_COLOR_XYZ2BGR = 34, ST_COLOR_XYZ2RGB = 35,
   ST_COLOR_BGR2YCrCb = 36, ST_COLOR_RGB2YCrCb = 37, ST_COLOR_YCrCb2BGR = 38, ST_COLOR_YCrCb2RGB = 39,
   ST_COLOR_BGR2HSV = 40, ST_COLOR_RGB2HSV = 41, ST_COLOR_HSV2BGR = 54, ST_COLOR_HSV2RGB = 55,
   ST_COLOR_BGR2HSV_FULL = 66, ST_COLOR_RGB2HSV_FULL = 67, ST_COLOR_HSV2BGR_FULL = 70, ST_COLOR_HSV2RGB_FULL = 71,

@@ -1087,6 +1087,7 @@ ORC_API int orc_cvt_out_channels(int code, int in_channels) {
     case ORC_RGB2HSV: case ORC_HSV2BGR: case ORC_HSV2RGB: case ORC_BGR2HSV_FULL: case ORC_RGB2HSV_FULL:
     case ORC_HSV2BGR_FULL: case ORC_HSV2RGB_FULL: case ORC_BGR2YUV: case ORC_RGB2YUV: case ORC_YUV2BGR: case ORC_YUV2RGB:
       return in_channels == 3 ? 3 : -1;
+    case 32: case 33: case 34: case 35: return in_channels == 3 ? 3 : -1;   /* BGR2XYZ, RGB2XYZ, XYZ2BGR, XYZ2RGB */
     /* channel layout family (cv::cvtColor codes 0..3, 5, 9..31) */
     case 0: case 2: return in_channels == 3 ? 4 : -1;          /* BGR2BGRA, BGR2RGBA */
     case 1: case 3: return in_channels == 4 ? 3 : -1;          /* BGRA2BGR, RGBA2BGR */
@@ -1187,6 +1188,26 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
         const int v = gb == 6 ? (int)((t << 3) & 0xf8) * 1868 + (int)((t >> 3) & 0xfc) * 9617 + (int)((t >> 8) & 0xf8) * 4899
                               : (int)((t << 3) & 0xf8) * 1868 + (int)((t >> 2) & 0xf8) * 9617 + (int)((t >> 7) & 0xf8) * 4899;
         dst[i] = (uint8_t)((v + (1 << 13)) >> 14);
+      }
+    }
+  } else if (code >= 32 && code <= 35) {
+    /* RGB2XYZ_i<uchar> / XYZ2RGB_i<uchar> (color_lab.cpp): the D65 matrices sRGB2XYZ_D65 / XYZ2sRGB_D65 scaled by 1 << 12
+       and rounded -- recomputed here from the float matrices rather than typed in --, with the blue / red columns (rows)
+       exchanged for blueIdx 0; CV_DESCALE(.., 12), saturate_cast<uchar>. */
+    static const double fwd[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double inv[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    int C[9];
+    const int to_xyz = code <= 33, bidx = (code == 32 || code == 34) ? 0 : 2;
+    for (int k = 0; k < 9; ++k) C[k] = (int)lrint((to_xyz ? fwd[k] : inv[k]) * 4096.);
+    if (bidx == 0) {
+      if (to_xyz) { int t; t = C[0]; C[0] = C[2]; C[2] = t; t = C[3]; C[3] = C[5]; C[5] = t; t = C[6]; C[6] = C[8]; C[8] = t; }
+      else { int t; for (int k = 0; k < 3; ++k) { t = C[k]; C[k] = C[6 + k]; C[6 + k] = t; } }
+    }
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* p = src + 3 * i;
+      for (int k = 0; k < 3; ++k) {
+        const int v = (p[0] * C[3 * k] + p[1] * C[3 * k + 1] + p[2] * C[3 * k + 2] + (1 << 11)) >> 12;
+        dst[3 * i + k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
       }
     }
   } else if (code == ORC_BGR2RGB) {

@@ -21,6 +21,7 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_HSV2BGR": 54, "COLOR_HSV2RGB": 55, "COLOR_BGR2HSV_FULL": 66, "COLOR_RGB2HSV_FULL": 67,
                "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
                "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85,
+               "COLOR_BGR2XYZ": 32, "COLOR_RGB2XYZ": 33, "COLOR_XYZ2BGR": 34, "COLOR_XYZ2RGB": 35,
                # channel layout family (alpha channel, 16-bit packed pixels)
                "COLOR_BGR2BGRA": 0, "COLOR_RGB2RGBA": 0, "COLOR_BGRA2BGR": 1, "COLOR_RGBA2RGB": 1, "COLOR_BGR2RGBA": 2,
                "COLOR_RGB2BGRA": 2, "COLOR_RGBA2BGR": 3, "COLOR_BGRA2RGB": 3, "COLOR_BGRA2RGBA": 5, "COLOR_RGBA2BGRA": 5,

@@ -449,6 +449,22 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
         else tt = (unsigned)(b >> 3) | ((unsigned)(g & ~7) << 2) | ((unsigned)(r & ~7) << 7) | ((a.sk == PK_C4 && al) ? 0x8000u : 0u);
         dst[2 * i] = (uint8_t)(tt & 0xff); dst[2 * i + 1] = (uint8_t)(tt >> 8);
       }
+    } else if (a.code >= 32 && a.code <= 35) {
+      // RGB2XYZ_i<uchar> / XYZ2RGB_i<uchar>: sRGB <-> XYZ (D65) matrices in 12-bit fixed point, CV_DESCALE, saturate
+      const int p0 = src[3 * i], p1 = src[3 * i + 1], p2 = src[3 * i + 2];
+      if (a.code <= 33) {
+        const int b = a.code == 32 ? p0 : p2, g = p1, r = a.code == 32 ? p2 : p0;
+        const int X = (r * 1689 + g * 1465 + b * 739 + (1 << 11)) >> 12;
+        const int Y = (r * 871 + g * 2929 + b * 296 + (1 << 11)) >> 12;
+        const int Z = (r * 79 + g * 488 + b * 3892 + (1 << 11)) >> 12;
+        dst[3 * i] = (uint8_t)min(max(X, 0), 255); dst[3 * i + 1] = (uint8_t)min(max(Y, 0), 255); dst[3 * i + 2] = (uint8_t)min(max(Z, 0), 255);
+      } else {
+        const int r = (p0 * 13273 + p1 * -6296 + p2 * -2042 + (1 << 11)) >> 12;
+        const int g = (p0 * -3970 + p1 * 7684 + p2 * 170 + (1 << 11)) >> 12;
+        const int b = (p0 * 228 + p1 * -836 + p2 * 4331 + (1 << 11)) >> 12;
+        const int bidx = a.code == 34 ? 0 : 2;
+        dst[3 * i + bidx] = (uint8_t)min(max(b, 0), 255); dst[3 * i + 1] = (uint8_t)min(max(g, 0), 255); dst[3 * i + (bidx ^ 2)] = (uint8_t)min(max(r, 0), 255);
+      }
     } else if (a.code == ST_COLOR_BGR2RGB) {
       const uint8_t c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
       dst[3 * i] = c2; dst[3 * i + 1] = c1; dst[3 * i + 2] = c0;
@@ -704,6 +720,7 @@ ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
     case ST_COLOR_YCrCb2BGR: case ST_COLOR_YCrCb2RGB: case ST_COLOR_RGB2HSV: case ST_COLOR_HSV2BGR: case ST_COLOR_HSV2RGB:
     case ST_COLOR_BGR2HSV_FULL: case ST_COLOR_RGB2HSV_FULL: case ST_COLOR_HSV2BGR_FULL: case ST_COLOR_HSV2RGB_FULL:
     case ST_COLOR_BGR2YUV: case ST_COLOR_RGB2YUV: case ST_COLOR_YUV2BGR: case ST_COLOR_YUV2RGB:
+    case ST_COLOR_BGR2XYZ: case ST_COLOR_RGB2XYZ: case ST_COLOR_XYZ2BGR: case ST_COLOR_XYZ2RGB:
       return in_channels == 3 ? 3 : -1;
     case ST_COLOR_BGR2GRAY: case ST_COLOR_RGB2GRAY: return in_channels == 3 ? 1 : -1;
     case ST_COLOR_GRAY2BGR: return in_channels == 1 ? 3 : -1;

@@ -38,6 +38,8 @@ const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
     {u8"COLOR_HSV2BGR_FULL", ST_COLOR_HSV2BGR_FULL}, {u8"COLOR_HSV2RGB_FULL", ST_COLOR_HSV2RGB_FULL},
     {u8"COLOR_BGR2YUV", ST_COLOR_BGR2YUV},   {u8"COLOR_RGB2YUV", ST_COLOR_RGB2YUV},
     {u8"COLOR_YUV2BGR", ST_COLOR_YUV2BGR},   {u8"COLOR_YUV2RGB", ST_COLOR_YUV2RGB},
+    {u8"COLOR_BGR2XYZ", ST_COLOR_BGR2XYZ},   {u8"COLOR_RGB2XYZ", ST_COLOR_RGB2XYZ},
+    {u8"COLOR_XYZ2BGR", ST_COLOR_XYZ2BGR},   {u8"COLOR_XYZ2RGB", ST_COLOR_XYZ2RGB},
     // channel layout family: alpha channel added / dropped / swapped, 16-bit packed pixels (2-channel frames)
     {u8"COLOR_BGR2BGRA", ST_COLOR_BGR2BGRA}, {u8"COLOR_RGB2RGBA", ST_COLOR_BGR2BGRA}, {u8"COLOR_BGRA2BGR", ST_COLOR_BGRA2BGR},
     {u8"COLOR_RGBA2RGB", ST_COLOR_BGRA2BGR}, {u8"COLOR_BGR2RGBA", ST_COLOR_BGR2RGBA}, {u8"COLOR_RGB2BGRA", ST_COLOR_BGR2RGBA},

@@ -182,7 +182,8 @@ def test_resize_op_target_size_rules():
                                        ("COLOR_RGB2HSV", 41), ("COLOR_HSV2BGR", 54), ("COLOR_HSV2RGB", 55),
                                        ("COLOR_BGR2HSV_FULL", 66), ("COLOR_RGB2HSV_FULL", 67), ("COLOR_HSV2BGR_FULL", 70),
                                        ("COLOR_HSV2RGB_FULL", 71), ("COLOR_BGR2YUV", 82), ("COLOR_RGB2YUV", 83),
-                                       ("COLOR_YUV2BGR", 84), ("COLOR_YUV2RGB", 85)])
+                                       ("COLOR_YUV2BGR", 84), ("COLOR_YUV2RGB", 85), ("COLOR_BGR2XYZ", 32), ("COLOR_RGB2XYZ", 33),
+                                       ("COLOR_XYZ2BGR", 34), ("COLOR_XYZ2RGB", 35)])
 @pytest.mark.parametrize("h,w", [(1, 1), (37, 53), (480, 640)])
 def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
     frames = random_frames(h + w + code, 2, h, w)
@@ -212,11 +213,14 @@ def test_cvt_color_exhaustive_hsv_and_known_answers(hip_ctx):
     # arithmetic is not a plain integer table: HSV -> RGB runs in float on both sides
     v = np.unique(np.concatenate([np.arange(0, 256, 3), [254, 255]])).astype(np.uint8)
     cube = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, len(v), len(v) * len(v), 3))
-    for name in ("COLOR_HSV2BGR", "COLOR_HSV2RGB_FULL", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2YUV", "COLOR_YUV2BGR"):
+    for name in ("COLOR_HSV2BGR", "COLOR_HSV2RGB_FULL", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2YUV", "COLOR_YUV2BGR",
+                 "COLOR_BGR2XYZ", "COLOR_RGB2XYZ", "COLOR_XYZ2BGR", "COLOR_XYZ2RGB"):
         got = hip_ctx.cvt_color(torch.from_numpy(cube).cuda(), name).cpu().numpy()
         np.testing.assert_array_equal(got[0], oracle.cvt_color(cube[0], getattr(oracle, name)), err_msg=name)
+    xyz = hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2XYZ").cpu().numpy()[0, 0]
+    assert xyz[3].tolist() == [242, 255, 255] and xyz[4].tolist() == [0, 0, 0]      # white (Z saturates), black
     with pytest.raises(ValueError):
-        hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2XYZ")
+        hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2Lab")
     with pytest.raises(ValueError):
         hip_ctx.cvt_color(torch.from_numpy(g).cuda(), "COLOR_BGR2HSV")             # needs 3 channels
 

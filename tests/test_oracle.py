@@ -392,3 +392,33 @@ def test_farneback_oracle_against_independent_float64_derivation():
     assert np.abs(got - want).max() <= 2e-3
     inner = got[40:-40, 40:-40]
     assert abs(np.median(inner[..., 0]) - 3) < 0.05 and abs(np.median(inner[..., 1]) + 2) < 0.05
+
+
+def test_cvt_color_xyz_and_layout_family_known_answers():
+    """XYZ: the float definition (sRGB primaries, D65) within the 12-bit rounding, white -> (242, 255, saturated 255),
+    the inverse within rounding where nothing saturated; layout family: packing keeps the top 5 / 6 / 5 bits, the 555
+    alpha bit, gray of a packed pixel with the 14-bit table, alpha added = 255."""
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    want = np.clip(f[..., ::-1].astype(float) @ M.T, 0, 255)          # f is BGR: reverse to R, G, B
+    got = oracle.cvt_color(f, oracle.COLOR_BGR2XYZ).astype(float)
+    assert np.abs(got - want).max() <= 0.6
+    np.testing.assert_array_equal(oracle.cvt_color(f[..., ::-1].copy(), oracle.COLOR_RGB2XYZ), oracle.cvt_color(f, oracle.COLOR_BGR2XYZ))
+    white = np.full((1, 1, 3), 255, np.uint8)
+    assert oracle.cvt_color(white, oracle.COLOR_BGR2XYZ)[0, 0].tolist() == [242, 255, 255]
+    dim = (f // 2 + 20).astype(np.uint8)                              # nothing saturates
+    back = oracle.cvt_color(oracle.cvt_color(dim, oracle.COLOR_BGR2XYZ), oracle.COLOR_XYZ2BGR).astype(int)
+    assert np.abs(back - dim).max() <= 3
+    p565 = oracle.cvt_color(f, 12)
+    t = p565[..., 0].astype(int) | (p565[..., 1].astype(int) << 8)
+    np.testing.assert_array_equal(t, (f[..., 0] >> 3).astype(int) | ((f[..., 1] >> 2).astype(int) << 5) | ((f[..., 2] >> 3).astype(int) << 11))
+    f4 = np.concatenate([f, rng.integers(0, 2, f.shape[:2] + (1,), dtype=np.uint8) * 200], axis=2)
+    p555 = oracle.cvt_color(f4, 26)
+    t = p555[..., 0].astype(int) | (p555[..., 1].astype(int) << 8)
+    np.testing.assert_array_equal(t >> 15, (f4[..., 3] != 0).astype(int))
+    np.testing.assert_array_equal(oracle.cvt_color(p555, 28)[..., 3], np.where(f4[..., 3] != 0, 255, 0))
+    np.testing.assert_array_equal(oracle.cvt_color(p565, 21), oracle.cvt_color(oracle.cvt_color(p565, 14), oracle.COLOR_BGR2GRAY, gray_bits=14))
+    assert oracle.cvt_color(f, 0)[..., 3].min() == 255 and np.array_equal(oracle.cvt_color(f, 2)[..., :3], f[..., ::-1])
+    g = f[..., :1].copy()
+    np.testing.assert_array_equal(oracle.cvt_color(g, 30), oracle.cvt_color(np.repeat(g, 3, axis=2), 22))
