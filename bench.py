@@ -196,122 +196,131 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                                   "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / max(n, 1)}
     out["histogram_small_batches"] = small
 
-    # (i) config 4: OpticalFlow at 4K, batch 32 (BASELINE.json configs[3])
-    if not args.no_4k:
-        H4, W4, B4 = 2160, 3840, 32
-        fr4 = [make_stream(torch, device, B4 + 1, H4, W4, seed=4000 + b) for b in range(2)]
-        fo4 = torch.empty((B4, H4, W4, 2), dtype=torch.float32, device=device)
-        ho4 = torch.empty((B4, 3, bins), dtype=torch.int32, device=device)
-        dt, launches, ms = timed_flow_hist(torch, ctx, _native, fr4, B4, bins, 4, 1, sync, fo4, ho4)
-        it_bytes, frame_bytes = iter_model_bytes(H4, W4, B4)
-        gbs = it_bytes * 4 / (ms * 1e-3) / 1e9
-        out["config4_4k_batch32"] = {
-            "workload": "OpticalFlow + %d-bin Histogram, 3840x2160, 32 pairs per call (33 resident frames)" % bins,
-            "frames_per_s": B4 * 4 / dt, "ms_per_step": dt / 4 * 1e3, "steps": 4,
-            "roofline": {"kernel": "k_flow_iter3", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": ms / max(launches, 1)},
-            "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
-        del fr4, fo4, ho4
-        ctx.release_workspace()
-        torch.cuda.empty_cache()
+    try:
+        # (i) config 4: OpticalFlow at 4K, batch 32 (BASELINE.json configs[3])
+        if not args.no_4k:
+            H4, W4, B4 = 2160, 3840, 32
+            fr4 = [make_stream(torch, device, B4 + 1, H4, W4, seed=4000 + b) for b in range(2)]
+            fo4 = torch.empty((B4, H4, W4, 2), dtype=torch.float32, device=device)
+            ho4 = torch.empty((B4, 3, bins), dtype=torch.int32, device=device)
+            dt, launches, ms = timed_flow_hist(torch, ctx, _native, fr4, B4, bins, 4, 1, sync, fo4, ho4)
+            it_bytes, frame_bytes = iter_model_bytes(H4, W4, B4)
+            gbs = it_bytes * 4 / (ms * 1e-3) / 1e9
+            out["config4_4k_batch32"] = {
+                "workload": "OpticalFlow + %d-bin Histogram, 3840x2160, 32 pairs per call (33 resident frames)" % bins,
+                "frames_per_s": B4 * 4 / dt, "ms_per_step": dt / 4 * 1e3, "steps": 4,
+                "roofline": {"kernel": "k_flow_iter3", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": ms / max(launches, 1)},
+                "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
+            del fr4, fo4, ho4
+            ctx.release_workspace()
+            torch.cuda.empty_cache()
+    except Exception as e:  # an auxiliary record must not take the headline down
+        out['config4_4k_batch32'] = {"error": repr(e)}
 
-    # config 3 on this one GPU: Histogram (the reference's 16 bins) over a 10 000-frame 1080p stream with 8
-    # planted cuts, generated chunk by chunk on the device, then ShotBoundaries on the host
-    if not args.no_shots:
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("shot_pipeline", os.path.join(ROOT, "scripts", "shot_pipeline.py"))
-        sp = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(sp)
-        from scannertools_amd.shot_detection import shot_boundaries
-        n3 = 10000
-        cuts = sp.planted_cuts(n3, 8)
-        hist3, t_hist = sp.shard_histograms(torch, ctx, device, 0, n3, 1080, 1920, 16, 250, cuts)
-        t0 = time.perf_counter()
-        res = shot_boundaries(None, list(hist3.cpu().numpy()))
-        t_sb = time.perf_counter() - t0
-        out["config3_shot_detection_10k"] = {
-            "workload": "Histogram (16 bins) on 10 000 x 1080p frames in chunks of 250 + ShotBoundaries on the host; "
-                        "1 GPU holds the whole stream (8 GPUs: scripts/shot_pipeline.py --gpus 8)",
-            "histogram_frames_per_s": n3 / t_hist, "histogram_s": t_hist, "shot_boundaries_s": t_sb,
-            "planted_cuts": cuts, "planted_found": all(c in res[0] for c in cuts), "boundaries_reported": len(res[0])}
-        del hist3
-        torch.cuda.empty_cache()
+    try:
+        # config 3 on this one GPU: Histogram (the reference's 16 bins) over a 10 000-frame 1080p stream with 8
+        # planted cuts, generated chunk by chunk on the device, then ShotBoundaries on the host
+        if not args.no_shots:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("shot_pipeline", os.path.join(ROOT, "scripts", "shot_pipeline.py"))
+            sp = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(sp)
+            from scannertools_amd.shot_detection import shot_boundaries
+            n3 = 10000
+            cuts = sp.planted_cuts(n3, 8)
+            hist3, t_hist = sp.shard_histograms(torch, ctx, device, 0, n3, 1080, 1920, 16, 250, cuts)
+            t0 = time.perf_counter()
+            res = shot_boundaries(None, list(hist3.cpu().numpy()))
+            t_sb = time.perf_counter() - t0
+            out["config3_shot_detection_10k"] = {
+                "workload": "Histogram (16 bins) on 10 000 x 1080p frames in chunks of 250 + ShotBoundaries on the host; "
+                            "1 GPU holds the whole stream (8 GPUs: scripts/shot_pipeline.py --gpus 8)",
+                "histogram_frames_per_s": n3 / t_hist, "histogram_s": t_hist, "shot_boundaries_s": t_sb,
+                "planted_cuts": cuts, "planted_found": all(c in res[0] for c in cuts), "boundaries_reported": len(res[0])}
+            del hist3
+            torch.cuda.empty_cache()
+    except Exception as e:  # an auxiliary record must not take the headline down
+        out['config3_shot_detection_10k'] = {"error": repr(e)}
 
-    # config 5: 1080p frames -> CPM2Input -> the pose network's convolution stack (random weights, float32 like
-    # the reference's Caffe pass) on the matrix cores; roofline = the f32 MFMA peak
-    if not args.no_pose:
-        from scannertools_amd import pose_net
-        from scannertools_amd.hip import cpm2_geometry
-        nb5, sc5 = 32, 368 / 1080.
-        net = pose_net.PoseNet(ctx, seed=1)
-        fr5 = batches[0][:nb5]
-        _, _, nh5, nw5 = cpm2_geometry(h, w, sc5)
-        fl5 = pose_net.flops(nh5, nw5)
+    try:
+        # config 5: 1080p frames -> CPM2Input -> the pose network's convolution stack (random weights, float32 like
+        # the reference's Caffe pass) on the matrix cores; roofline = the f32 MFMA peak
+        if not args.no_pose:
+            from scannertools_amd import pose_net
+            from scannertools_amd.hip import cpm2_geometry
+            nb5, sc5 = 32, 368 / 1080.
+            net = pose_net.PoseNet(ctx, seed=1)
+            fr5 = batches[0][:nb5]
+            _, _, nh5, nw5 = cpm2_geometry(h, w, sc5)
+            fl5 = pose_net.flops(nh5, nw5)
 
-        def pose_step():
-            # CPM2Input -> CPM2 (network, `resize`, `nms`) -> the GPU half of CPM2Output (limb candidate scores)
-            maps, joints = net.detect(ctx.cpm2_input(fr5, sc5))
-            return maps, joints, ctx.cpm2_limb_scores(maps, joints)
+            def pose_step():
+                # CPM2Input -> CPM2 (network, `resize`, `nms`) -> the GPU half of CPM2Output (limb candidate scores)
+                maps, joints = net.detect(ctx.cpm2_input(fr5, sc5))
+                return maps, joints, ctx.cpm2_limb_scores(maps, joints)
 
-        pose_step()
-        sync()
-        ids5 = [_native.K_CONV, _native.K_CPM2_INPUT, _native.K_CPM2_RESIZE, _native.K_CPM2_NMS, _native.K_CPM2_LIMBS]
-        ctx.timing_enable(ids5)
-        ctx.timing_reset()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            maps, joints, limb = pose_step()
-        sync()
-        dt5 = (time.perf_counter() - t0) / 2
-        kms5 = {k: ctx.timing_read(k) for k in ids5}
-        nl5, ms5 = kms5[_native.K_CONV]
-        ctx.timing_enable([])
-        # parity of the same code on a small input against the float32 torch network (CPU)
-        g5 = torch.Generator().manual_seed(4)
-        xs5 = torch.rand((1, 3, 48, 80), generator=g5) - 0.5
-        got5 = net.forward(xs5.to(device)).permute(0, 3, 1, 2).cpu()
-        ref5 = net.reference_forward(xs5, device="cpu")
-        tf5 = nb5 * fl5 / (ms5 / 2 * 1e-3) / 1e12
-        out["config5_pose_conv_stack"] = {
-            "workload": "%d x %dx%d frames -> CPM2Input (scale %.4f -> %dx%d) -> CPM2 = OpenPose COCO body network (92 convolutions "
-                        "+ 3 poolings, random float32 weights) + x8 bicubic `resize` + `nms` -> CPM2Output's limb scores; the assembly "
-                        "of people on the host is not in this loop" % (nb5, w, h, sc5, nw5, nh5),
-            "dtype": "f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation)",
-            "frames_per_s": nb5 / dt5, "ms_per_batch": dt5 * 1e3, "gflop_per_frame": fl5 / 1e9,
-            "roofline": {"kernel": "k_conv_nhwc_f32", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": tf5 / 157.3, "launches": nl5, "kernel_ms_per_batch": ms5 / 2},
-            "other_kernels_ms_per_batch": {"cpm2_input": kms5[_native.K_CPM2_INPUT][1] / 2, "resize_maps": kms5[_native.K_CPM2_RESIZE][1] / 2,
-                                           "nms": kms5[_native.K_CPM2_NMS][1] / 2, "limb_scores": kms5[_native.K_CPM2_LIMBS][1] / 2},
-            "resize_maps_GBs": nb5 * 57 * nh5 * nw5 * 4 / (kms5[_native.K_CPM2_RESIZE][1] / 2 * 1e-3) / 1e9,
-            "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
-                       "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())}}
-        # the same work through the reference's user-facing op: sc.ops.OpenPose on device frames (kernel class: transform,
-        # network, merge, nms, limb scores, assembly of people on the host, element formatting), one scale, batch 32;
-        # the model file holds the same random weights
-        try:
-            import shutil
-            import tempfile
-            from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
-            mdir = tempfile.mkdtemp(prefix="st_openpose_")
-            os.makedirs(os.path.join(mdir, "pose", "coco"))
-            pose_net.write_caffemodel(os.path.join(mdir, "pose", "coco", "pose_iter_440000.caffemodel"), net.weights)
-            sc5c = Client(device_id=device.index)
-            sc5c.ingest_frames("v5", batches[0][:2 * nb5])
-            node5 = sc5c.ops.OpenPose(frame=sc5c.io.Input([NamedVideoStream(sc5c, "v5")]), model_directory=mdir, device=DeviceType.GPU, batch=nb5)
-            sc5c.execute_seconds, sc5c.steady_seconds, sc5c.steady_rows = 0.0, 0.0, 0
-            o5 = NamedStream(sc5c, "pose5")
-            sc5c.run(sc5c.io.Output(node5, [o5]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
-            out["config5_pose_conv_stack"]["openpose_op"] = {
-                "what": "sc.ops.OpenPose(frame, pose_num_scales=1, device=GPU, batch=%d) on %d device frames: time inside the second "
-                        "execute() call (the first one allocates the instance's device buffers); the random network fills every "
-                        "frame with the maximum of candidate joints and people, the worst case for the host-side assembly" % (nb5, 2 * nb5),
-                "frames_per_s": sc5c.steady_rows / sc5c.steady_seconds, "first_call_frames_per_s": nb5 / (sc5c.execute_seconds - sc5c.steady_seconds),
-                "people_in_first_frame": len(list(o5.load())[0])}
-            shutil.rmtree(mdir, ignore_errors=True)
-        except Exception as e:  # auxiliary record
-            out["config5_pose_conv_stack"]["openpose_op"] = {"error": repr(e)}
-        del net, maps, joints, limb
-        torch.cuda.empty_cache()
+            pose_step()
+            sync()
+            ids5 = [_native.K_CONV, _native.K_CPM2_INPUT, _native.K_CPM2_RESIZE, _native.K_CPM2_NMS, _native.K_CPM2_LIMBS]
+            ctx.timing_enable(ids5)
+            ctx.timing_reset()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                maps, joints, limb = pose_step()
+            sync()
+            dt5 = (time.perf_counter() - t0) / 2
+            kms5 = {k: ctx.timing_read(k) for k in ids5}
+            nl5, ms5 = kms5[_native.K_CONV]
+            ctx.timing_enable([])
+            # parity of the same code on a small input against the float32 torch network (CPU)
+            g5 = torch.Generator().manual_seed(4)
+            xs5 = torch.rand((1, 3, 48, 80), generator=g5) - 0.5
+            got5 = net.forward(xs5.to(device)).permute(0, 3, 1, 2).cpu()
+            ref5 = net.reference_forward(xs5, device="cpu")
+            tf5 = nb5 * fl5 / (ms5 / 2 * 1e-3) / 1e12
+            out["config5_pose_conv_stack"] = {
+                "workload": "%d x %dx%d frames -> CPM2Input (scale %.4f -> %dx%d) -> CPM2 = OpenPose COCO body network (92 convolutions "
+                            "+ 3 poolings, random float32 weights) + x8 bicubic `resize` + `nms` -> CPM2Output's limb scores; the assembly "
+                            "of people on the host is not in this loop" % (nb5, w, h, sc5, nw5, nh5),
+                "dtype": "f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation)",
+                "frames_per_s": nb5 / dt5, "ms_per_batch": dt5 * 1e3, "gflop_per_frame": fl5 / 1e9,
+                "roofline": {"kernel": "k_conv_nhwc_f32", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
+                             "frac": tf5 / 157.3, "launches": nl5, "kernel_ms_per_batch": ms5 / 2},
+                "other_kernels_ms_per_batch": {"cpm2_input": kms5[_native.K_CPM2_INPUT][1] / 2, "resize_maps": kms5[_native.K_CPM2_RESIZE][1] / 2,
+                                               "nms": kms5[_native.K_CPM2_NMS][1] / 2, "limb_scores": kms5[_native.K_CPM2_LIMBS][1] / 2},
+                "resize_maps_GBs": nb5 * 57 * nh5 * nw5 * 4 / (kms5[_native.K_CPM2_RESIZE][1] / 2 * 1e-3) / 1e9,
+                "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
+                           "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())}}
+            # the same work through the reference's user-facing op: sc.ops.OpenPose on device frames (kernel class: transform,
+            # network, merge, nms, limb scores, assembly of people on the host, element formatting), one scale, batch 32;
+            # the model file holds the same random weights
+            try:
+                import shutil
+                import tempfile
+                from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+                mdir = tempfile.mkdtemp(prefix="st_openpose_")
+                os.makedirs(os.path.join(mdir, "pose", "coco"))
+                pose_net.write_caffemodel(os.path.join(mdir, "pose", "coco", "pose_iter_440000.caffemodel"), net.weights)
+                sc5c = Client(device_id=device.index)
+                sc5c.ingest_frames("v5", batches[0][:2 * nb5])
+                node5 = sc5c.ops.OpenPose(frame=sc5c.io.Input([NamedVideoStream(sc5c, "v5")]), model_directory=mdir, device=DeviceType.GPU, batch=nb5)
+                sc5c.execute_seconds, sc5c.steady_seconds, sc5c.steady_rows = 0.0, 0.0, 0
+                o5 = NamedStream(sc5c, "pose5")
+                sc5c.run(sc5c.io.Output(node5, [o5]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+                out["config5_pose_conv_stack"]["openpose_op"] = {
+                    "what": "sc.ops.OpenPose(frame, pose_num_scales=1, device=GPU, batch=%d) on %d device frames: time inside the second "
+                            "execute() call (the first one allocates the instance's device buffers); the random network fills every "
+                            "frame with the maximum of candidate joints and people, the worst case for the host-side assembly" % (nb5, 2 * nb5),
+                    "frames_per_s": sc5c.steady_rows / sc5c.steady_seconds, "first_call_frames_per_s": nb5 / (sc5c.execute_seconds - sc5c.steady_seconds),
+                    "people_in_first_frame": len(list(o5.load())[0])}
+                shutil.rmtree(mdir, ignore_errors=True)
+            except Exception as e:  # auxiliary record
+                out["config5_pose_conv_stack"]["openpose_op"] = {"error": repr(e)}
+            del net, maps, joints, limb
+            torch.cuda.empty_cache()
+    except Exception as e:  # an auxiliary record must not take the headline down
+        out['config5_pose_conv_stack'] = {"error": repr(e)}
 
     # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the
     # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
