@@ -248,6 +248,12 @@ enum st_color_code {
   ST_COLOR_BGR2YUV = 82, ST_COLOR_RGB2YUV = 83, ST_COLOR_YUV2BGR = 84, ST_COLOR_YUV2RGB = 85
 };
 int st_cvt_color_out_channels(int code, int in_channels);
+/* Output shape of a conversion: most codes keep (h, w) and change the channel count (st_cvt_color_out_channels);
+ * the YUV 4:2:0 sources (cv::cvtColor codes 90..106: NV12, NV21, YV12, IYUV / I420 -- a (3H/2, W) single-channel frame, what a
+ * video decoder hands out) produce (H, W, 3 | 4 | 1); the packed 4:2:2 sources (107..124: UYVY, YUY2, YVYU; (H, W, 2))
+ * produce (H, W, 3 | 4 | 1).  Returns 0, or -1 when the code does not apply to such a frame.  The output-shape probe of
+ * ConvertColorKernel::execute (convert_color_kernel.cpp:252-277). */
+int st_cvt_color_out_shape(int code, int in_h, int in_w, int in_channels, int* out_h, int* out_w, int* out_channels);
 int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                           int code, int gray_bits, uint8_t* const* out_dev);
 

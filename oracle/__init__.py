@@ -260,13 +260,13 @@ COLOR_BGR2XYZ, COLOR_RGB2XYZ, COLOR_XYZ2BGR, COLOR_XYZ2RGB = 32, 33, 34, 35
 
 
 def cvt_color(frame, code, gray_bits=15):
-    """(h,w,c) uint8 -> (h,w,c') uint8: cv::cvtColor restated for the codes above."""
+    """(h,w,c) uint8 -> (h',w,c') uint8: cv::cvtColor restated for the codes above (h' = 2h/3 for the YUV 4:2:0 sources)."""
     frame = np.ascontiguousarray(frame, dtype=np.uint8)
     h, w, c = frame.shape
-    oc = lib().orc_cvt_out_channels(int(code), c)
-    if oc < 0:
-        raise ValueError("unsupported conversion %r for %d channels" % (code, c))
-    out = np.empty((h, w, oc), np.uint8)
+    oh, ow, oc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if lib().orc_cvt_color_out_shape(int(code), h, w, c, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(oc)) != 0:
+        raise ValueError("unsupported conversion %r for a %dx%d frame of %d channel(s)" % (code, w, h, c))
+    out = np.empty((oh.value, ow.value, oc.value), np.uint8)
     assert lib().orc_cvt_color_u8(_p(frame), h, w, c, int(code), gray_bits, _p(out)) == 0
     return out
 

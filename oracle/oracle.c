@@ -1158,7 +1158,89 @@ static void orc_hsv2rgb_native(float h, float s, float v, float hscale, float* b
   *r = tab[sector_data[sector][2]];
 }
 
+/* YUV 4:2:0 / 4:2:2 sources -> RGB (OpenCV color_yuv: YUV420sp2RGB888Invoker, YUV420p2RGB888Invoker, YUV422toRGB888Invoker and
+ * their 8888 twins).  Walks the frame the way those invokers do -- two rows and two columns at a time, one (u, v) pair
+ * per block -- with the BT.601 constants derived from their decimal values (1.164, 2.018, 0.391, 0.813, 1.596) x 2^20. */
+static int orc_yuv_layout(int code, int* kind, int* bidx, int* uidx, int* yidx, int* dcn) {
+  if (code >= 90 && code <= 97) { const int c = code - 90; *kind = 0; *bidx = (c & 1) ? 0 : 2; *uidx = (c >> 1) & 1; *yidx = 0; *dcn = c >= 4 ? 4 : 3; return 1; }
+  if (code >= 98 && code <= 105) { const int c = code - 98; *kind = 1; *bidx = (c & 1) ? 0 : 2; *uidx = ((c >> 1) & 1) ? 0 : 1; *yidx = 0; *dcn = c >= 4 ? 4 : 3; return 1; }
+  if (code == 106) { *kind = 3; *bidx = *uidx = *yidx = 0; *dcn = 1; return 1; }
+  static const int t[][5] = {{107, 2, 0, 1, 3}, {108, 0, 0, 1, 3}, {111, 2, 0, 1, 4}, {112, 0, 0, 1, 4}, {115, 2, 1, 0, 3}, {116, 0, 1, 0, 3},
+                             {117, 2, 3, 0, 3}, {118, 0, 3, 0, 3}, {119, 2, 1, 0, 4}, {120, 0, 1, 0, 4}, {121, 2, 3, 0, 4}, {122, 0, 3, 0, 4}};
+  for (unsigned i = 0; i < sizeof(t) / sizeof(t[0]); ++i)
+    if (t[i][0] == code) { *kind = 2; *bidx = t[i][1]; *uidx = t[i][2]; *yidx = t[i][3]; *dcn = t[i][4]; return 1; }
+  if (code == 123) { *kind = 4; *bidx = 0; *uidx = 0; *yidx = 1; *dcn = 1; return 1; }
+  if (code == 124) { *kind = 4; *bidx = 0; *uidx = 1; *yidx = 0; *dcn = 1; return 1; }
+  return 0;
+}
+
+ORC_API int orc_cvt_color_out_shape(int code, int in_h, int in_w, int in_channels, int* oh, int* ow, int* oc) {
+  int kind, bidx, uidx, yidx, dcn;
+  if (orc_yuv_layout(code, &kind, &bidx, &uidx, &yidx, &dcn)) {
+    if (kind == 2 || kind == 4) {
+      if (in_channels != 2 || in_w % 2 || in_h <= 0 || in_w <= 0) return -1;
+      *oh = in_h;
+    } else {
+      if (in_channels != 1 || in_w % 2 || in_h % 3 || in_h <= 0 || in_w <= 0) return -1;
+      *oh = in_h * 2 / 3;
+    }
+    *ow = in_w; *oc = dcn;
+    return 0;
+  }
+  const int c = orc_cvt_out_channels(code, in_channels);
+  if (c < 0) return -1;
+  *oh = in_h; *ow = in_w; *oc = c;
+  return 0;
+}
+
+static void orc_yuv_px(int Y, int u, int v, int bidx, int dcn, uint8_t* o) {
+  const int CY = (int)(1.164 * 1048576), CUB = (int)(2.018 * 1048576), CUG = -(int)(0.391 * 1048576), CVG = -(int)(0.813 * 1048576),
+            CVR = (int)(1.596 * 1048576);
+  const int y = (Y - 16 > 0 ? Y - 16 : 0) * CY;
+  const int ruv = (1 << 19) + CVR * v, guv = (1 << 19) + CVG * v + CUG * u, buv = (1 << 19) + CUB * u;
+  int r = (y + ruv) >> 20, g = (y + guv) >> 20, b = (y + buv) >> 20;
+  o[bidx] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+  o[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+  o[bidx ^ 2] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+  if (dcn == 4) o[3] = 255;
+}
+
+static int orc_cvt_yuv(const uint8_t* src, int h, int w, int cn, int code, uint8_t* dst) {
+  int kind, bidx, uidx, yidx, dcn, H, W, C;
+  if (!orc_yuv_layout(code, &kind, &bidx, &uidx, &yidx, &dcn) || orc_cvt_color_out_shape(code, h, w, cn, &H, &W, &C)) return 1;
+  if (kind == 3) { memcpy(dst, src, (size_t)H * W); return 0; }
+  if (kind == 4) { for (size_t i = 0; i < (size_t)H * W; ++i) dst[i] = src[2 * (i & ~(size_t)1) + yidx + 2 * (i & 1)]; return 0; }
+  if (kind == 2) {
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; x += 2) {
+        const uint8_t* g = src + ((size_t)y * W + x) * 2;
+        const int u = g[uidx] - 128, v = g[uidx ^ 2] - 128;
+        orc_yuv_px(g[yidx], u, v, bidx, dcn, dst + ((size_t)y * W + x) * dcn);
+        orc_yuv_px(g[yidx + 2], u, v, bidx, dcn, dst + ((size_t)y * W + x + 1) * dcn);
+      }
+    return 0;
+  }
+  const uint8_t* chroma = src + (size_t)H * W;
+  for (int y = 0; y < H; y += 2)
+    for (int x = 0; x < W; x += 2) {
+      int u, v;
+      if (kind == 0) {
+        const uint8_t* uv = chroma + (size_t)(y / 2) * W + x;
+        u = uv[uidx] - 128; v = uv[1 - uidx] - 128;
+      } else {
+        const size_t q = (size_t)(H / 2) * (W / 2), o = (size_t)(y / 2) * (W / 2) + x / 2;
+        u = (uidx == 0 ? chroma[o] : chroma[q + o]) - 128;
+        v = (uidx == 0 ? chroma[q + o] : chroma[o]) - 128;
+      }
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx)
+          orc_yuv_px(src[(size_t)(y + dy) * W + x + dx], u, v, bidx, dcn, dst + ((size_t)(y + dy) * W + x + dx) * dcn);
+    }
+  return 0;
+}
+
 ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code, int gray_bits, uint8_t* dst) {
+  if (code >= 90 && code <= 124) return orc_cvt_yuv(src, h, w, cn, code, dst);
   if (orc_cvt_out_channels(code, cn) < 0) return 1;
   const size_t n = (size_t)h * w;
   if (code <= 3 || code == 5) {        /* RGB2RGB<uchar>(scn, dcn, blueIdx): blueIdx 2 swaps */

@@ -22,6 +22,25 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
                "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85,
                "COLOR_BGR2XYZ": 32, "COLOR_RGB2XYZ": 33, "COLOR_XYZ2BGR": 34, "COLOR_XYZ2RGB": 35,
+               # YUV 4:2:0 sources ((3H/2, W, 1) frames) and packed 4:2:2 sources ((H, W, 2) frames) -> RGB / BGR / RGBA / BGRA / gray
+               "COLOR_YUV2RGB_NV12": 90, "COLOR_YUV2BGR_NV12": 91, "COLOR_YUV2RGB_NV21": 92, "COLOR_YUV2BGR_NV21": 93,
+               "COLOR_YUV420sp2RGB": 92, "COLOR_YUV420sp2BGR": 93, "COLOR_YUV2RGBA_NV12": 94, "COLOR_YUV2BGRA_NV12": 95,
+               "COLOR_YUV2RGBA_NV21": 96, "COLOR_YUV2BGRA_NV21": 97, "COLOR_YUV420sp2RGBA": 96, "COLOR_YUV420sp2BGRA": 97,
+               "COLOR_YUV2RGB_YV12": 98, "COLOR_YUV2BGR_YV12": 99, "COLOR_YUV2RGB_IYUV": 100, "COLOR_YUV2BGR_IYUV": 101,
+               "COLOR_YUV2RGB_I420": 100, "COLOR_YUV2BGR_I420": 101, "COLOR_YUV420p2RGB": 98, "COLOR_YUV420p2BGR": 99,
+               "COLOR_YUV2RGBA_YV12": 102, "COLOR_YUV2BGRA_YV12": 103, "COLOR_YUV2RGBA_IYUV": 104, "COLOR_YUV2BGRA_IYUV": 105,
+               "COLOR_YUV2RGBA_I420": 104, "COLOR_YUV2BGRA_I420": 105, "COLOR_YUV420p2RGBA": 102, "COLOR_YUV420p2BGRA": 103,
+               "COLOR_YUV2GRAY_420": 106, "COLOR_YUV2GRAY_NV21": 106, "COLOR_YUV2GRAY_NV12": 106, "COLOR_YUV2GRAY_YV12": 106,
+               "COLOR_YUV2GRAY_IYUV": 106, "COLOR_YUV2GRAY_I420": 106, "COLOR_YUV420sp2GRAY": 106, "COLOR_YUV420p2GRAY": 106,
+               "COLOR_YUV2RGB_UYVY": 107, "COLOR_YUV2BGR_UYVY": 108, "COLOR_YUV2RGB_Y422": 107, "COLOR_YUV2BGR_Y422": 108,
+               "COLOR_YUV2RGB_UYNV": 107, "COLOR_YUV2BGR_UYNV": 108, "COLOR_YUV2RGBA_UYVY": 111, "COLOR_YUV2BGRA_UYVY": 112,
+               "COLOR_YUV2RGBA_Y422": 111, "COLOR_YUV2BGRA_Y422": 112, "COLOR_YUV2RGBA_UYNV": 111, "COLOR_YUV2BGRA_UYNV": 112,
+               "COLOR_YUV2RGB_YUY2": 115, "COLOR_YUV2BGR_YUY2": 116, "COLOR_YUV2RGB_YVYU": 117, "COLOR_YUV2BGR_YVYU": 118,
+               "COLOR_YUV2RGB_YUYV": 115, "COLOR_YUV2BGR_YUYV": 116, "COLOR_YUV2RGB_YUNV": 115, "COLOR_YUV2BGR_YUNV": 116,
+               "COLOR_YUV2RGBA_YUY2": 119, "COLOR_YUV2BGRA_YUY2": 120, "COLOR_YUV2RGBA_YVYU": 121, "COLOR_YUV2BGRA_YVYU": 122,
+               "COLOR_YUV2RGBA_YUYV": 119, "COLOR_YUV2BGRA_YUYV": 120, "COLOR_YUV2RGBA_YUNV": 119, "COLOR_YUV2BGRA_YUNV": 120,
+               "COLOR_YUV2GRAY_UYVY": 123, "COLOR_YUV2GRAY_YUY2": 124, "COLOR_YUV2GRAY_Y422": 123, "COLOR_YUV2GRAY_UYNV": 123,
+               "COLOR_YUV2GRAY_YVYU": 124, "COLOR_YUV2GRAY_YUYV": 124, "COLOR_YUV2GRAY_YUNV": 124,
                # channel layout family (alpha channel, 16-bit packed pixels)
                "COLOR_BGR2BGRA": 0, "COLOR_RGB2RGBA": 0, "COLOR_BGRA2BGR": 1, "COLOR_RGBA2RGB": 1, "COLOR_BGR2RGBA": 2,
                "COLOR_RGB2BGRA": 2, "COLOR_RGBA2BGR": 3, "COLOR_BGRA2RGB": 3, "COLOR_BGRA2RGBA": 5, "COLOR_RGBA2BGRA": 5,
@@ -89,6 +108,7 @@ SIGNATURES = {
     "st_box_blur_u8c3_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _c.POINTER(_vp)]),
     "st_resize_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
     "st_cvt_color_out_channels": (_i, [_i, _i]),
+    "st_cvt_color_out_shape": (_i, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "st_cvt_color_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
     "st_cpm2_geometry": (_i, [_i, _i, _c.c_float, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "st_cpm2_input_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _c.c_float, _c.POINTER(_vp)]),

@@ -561,6 +561,99 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
   }
 }
 
+// ---- YUV 4:2:0 / 4:2:2 sources (what a video decoder hands out) -> RGB / BGR / RGBA / BGRA / gray ------------------------
+// cv::cvtColor codes 90..106 (NV12, NV21, YV12, IYUV = I420; a (3H/2, W) single-channel frame: Y plane, then the chroma
+// interleaved (NV12: U V, NV21: V U) or as two quarter planes (I420: U V, YV12: V U)) and 107..124 (UYVY, YUY2, YVYU: a
+// (H, W, 2) frame, two pixels per 4 bytes).  OpenCV's YUV420sp2RGB888Invoker / YUV420p2RGB888Invoker / YUV422toRGB888Invoker:
+// ITU-R BT.601 in 20-bit fixed point, chroma replicated over its 2x2 (2x1) pixels, no interpolation:
+//   y = max(0, Y - 16) * CY;  R = sat((y + (1<<19) + CVR v) >> 20), G = sat((y + (1<<19) + CVG v + CUG u) >> 20),
+//   B = sat((y + (1<<19) + CUB u) >> 20),  u = U - 128, v = V - 128,
+//   CY, CUB, CUG, CVG, CVR = 1220542, 2116026, -409993, -852492, 1673527 (1.164, 2.018, -0.391, -0.813, 1.596 x 2^20).
+struct YuvDesc {
+  int kind;   // 0: semi-planar 4:2:0, 1: planar 4:2:0, 2: packed 4:2:2, 3: gray from 4:2:0, 4: gray from 4:2:2
+  int bidx;   // byte of the output pixel that holds blue
+  int uidx;   // 4:2:0: 0 = U first; 4:2:2: byte of U inside the 4-byte group
+  int yidx;   // 4:2:2: byte of the first luma sample inside the group (0 or 1)
+  int dcn;    // output channels
+};
+__host__ __device__ inline bool cvt_yuv_of(int code, YuvDesc* d) {
+  if (code >= 90 && code <= 97) {   // RGB_NV12, BGR_NV12, RGB_NV21, BGR_NV21, RGBA_NV12, BGRA_NV12, RGBA_NV21, BGRA_NV21
+    const int c = code - 90;
+    *d = {0, (c & 1) ? 0 : 2, ((c >> 1) & 1), 0, c >= 4 ? 4 : 3};
+    return true;
+  }
+  if (code >= 98 && code <= 105) {  // RGB_YV12, BGR_YV12, RGB_IYUV, BGR_IYUV, RGBA_YV12, BGRA_YV12, RGBA_IYUV, BGRA_IYUV
+    const int c = code - 98;
+    *d = {1, (c & 1) ? 0 : 2, ((c >> 1) & 1) ? 0 : 1, 0, c >= 4 ? 4 : 3};
+    return true;
+  }
+  if (code == 106) { *d = {3, 0, 0, 0, 1}; return true; }  // GRAY_420 (= GRAY_NV21 / NV12 / YV12 / IYUV / I420)
+  switch (code) {
+    case 107: *d = {2, 2, 0, 1, 3}; return true;   // RGB_UYVY   (U Y0 V Y1)
+    case 108: *d = {2, 0, 0, 1, 3}; return true;   // BGR_UYVY
+    case 111: *d = {2, 2, 0, 1, 4}; return true;   // RGBA_UYVY
+    case 112: *d = {2, 0, 0, 1, 4}; return true;   // BGRA_UYVY
+    case 115: *d = {2, 2, 1, 0, 3}; return true;   // RGB_YUY2   (Y0 U Y1 V)
+    case 116: *d = {2, 0, 1, 0, 3}; return true;   // BGR_YUY2
+    case 117: *d = {2, 2, 3, 0, 3}; return true;   // RGB_YVYU   (Y0 V Y1 U)
+    case 118: *d = {2, 0, 3, 0, 3}; return true;   // BGR_YVYU
+    case 119: *d = {2, 2, 1, 0, 4}; return true;   // RGBA_YUY2
+    case 120: *d = {2, 0, 1, 0, 4}; return true;   // BGRA_YUY2
+    case 121: *d = {2, 2, 3, 0, 4}; return true;   // RGBA_YVYU
+    case 122: *d = {2, 0, 3, 0, 4}; return true;   // BGRA_YVYU
+    case 123: *d = {4, 0, 0, 1, 1}; return true;   // GRAY_UYVY
+    case 124: *d = {4, 0, 1, 0, 1}; return true;   // GRAY_YUY2 (= YVYU / YUYV / YUNV)
+    default: return false;
+  }
+}
+
+struct YuvArgsK {
+  const uint8_t* const* src;
+  uint8_t* const* dst;
+  int H, W;   // OUTPUT size
+  YuvDesc d;
+};
+
+__global__ __launch_bounds__(256) void k_cvt_yuv_u8(YuvArgsK a) {
+  const uint8_t* __restrict__ src = a.src[blockIdx.y];
+  uint8_t* __restrict__ dst = a.dst[blockIdx.y];
+  const long long npix = (long long)a.H * a.W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / a.W), x = (int)(i - (long long)y * a.W);
+    int Y, U = 128, V = 128;
+    if (a.d.kind == 0 || a.d.kind == 1 || a.d.kind == 3) {
+      Y = src[i];
+      if (a.d.kind == 0) {
+        const uint8_t* uv = src + npix + (size_t)(y >> 1) * a.W + 2 * (x >> 1);
+        U = uv[a.d.uidx]; V = uv[1 - a.d.uidx];
+      } else if (a.d.kind == 1) {
+        const size_t q = (size_t)(a.H >> 1) * (a.W >> 1), o = (size_t)(y >> 1) * (a.W >> 1) + (x >> 1);
+        const uint8_t* p0 = src + npix;  // first chroma plane
+        U = a.d.uidx == 0 ? p0[o] : p0[q + o];
+        V = a.d.uidx == 0 ? p0[q + o] : p0[o];
+      }
+    } else {
+      const uint8_t* g = src + ((size_t)y * a.W + (x & ~1)) * 2;
+      Y = g[a.d.yidx + 2 * (x & 1)];
+      U = g[a.d.uidx]; V = g[a.d.uidx ^ 2];
+    }
+    if (a.d.dcn == 1) {
+      dst[i] = (uint8_t)Y;
+      continue;
+    }
+    const int u = U - 128, v = V - 128;
+    const int yy = max(0, Y - 16) * 1220542;
+    const int r = (yy + (1 << 19) + 1673527 * v) >> 20;
+    const int g = (yy + (1 << 19) - 852492 * v - 409993 * u) >> 20;
+    const int b = (yy + (1 << 19) + 2116026 * u) >> 20;
+    uint8_t* o = dst + i * a.d.dcn;
+    o[a.d.bidx] = (uint8_t)min(max(b, 0), 255);
+    o[1] = (uint8_t)min(max(g, 0), 255);
+    o[a.d.bidx ^ 2] = (uint8_t)min(max(r, 0), 255);
+    if (a.d.dcn == 4) o[3] = 255;
+  }
+}
+
 }  // namespace
 
 ST_EXPORT int st_box_blur_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int kernel_size,
@@ -731,13 +824,36 @@ ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
   return -1;
 }
 
+ST_EXPORT int st_cvt_color_out_shape(int code, int in_h, int in_w, int in_channels, int* out_h, int* out_w, int* out_channels) {
+  YuvDesc d;
+  int oh = in_h, ow = in_w, oc;
+  if (cvt_yuv_of(code, &d)) {
+    if (d.kind == 0 || d.kind == 1 || d.kind == 3) {
+      // 4:2:0: a (3H/2, W) single-channel frame with even W and H
+      if (in_channels != 1 || in_h <= 0 || in_w <= 0 || in_h % 3 || in_w % 2 || (in_h / 3 * 2) % 2) return -1;
+      oh = in_h / 3 * 2;
+    } else {
+      if (in_channels != 2 || in_h <= 0 || in_w <= 0 || in_w % 2) return -1;
+    }
+    oc = d.dcn;
+  } else {
+    oc = st_cvt_color_out_channels(code, in_channels);
+    if (oc < 0) return -1;
+  }
+  if (out_h) *out_h = oh;
+  if (out_w) *out_w = ow;
+  if (out_channels) *out_channels = oc;
+  return 0;
+}
+
 ST_EXPORT int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, int channels,
                                     int code, int gray_bits, uint8_t* const* out_dev) {
   ST_TRY(st_enter(ctx));
   if (n < 0 || h <= 0 || w <= 0 || (long long)h * w > 200000000LL)
     return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: bad arguments (n=%d h=%d w=%d)", n, h, w);
-  if (st_cvt_color_out_channels(code, channels) < 0)
-    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "cvt_color: conversion code %d on %d-channel frames is not implemented", code, channels);
+  int oh = 0, ow = 0, oc = 0;
+  if (st_cvt_color_out_shape(code, h, w, channels, &oh, &ow, &oc) != 0)
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "cvt_color: conversion code %d on %dx%d frames of %d channel(s) is not implemented", code, w, h, channels);
   if (gray_bits != 14 && gray_bits != 15) return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: gray_bits must be 14 or 15");
   if (n == 0) return ST_OK;
   if (!frames_dev || !out_dev) return st_set_error(ctx, ST_ERR_INVALID, "cvt_color: null argument");
@@ -749,6 +865,21 @@ ST_EXPORT int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_de
   uint8_t** d_dst = (uint8_t**)st_ws_alloc(ctx, tb);
   ST_HIP(ctx, hipMemcpyAsync(d_src, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   ST_HIP(ctx, hipMemcpyAsync(d_dst, out_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  YuvDesc yd;
+  if (cvt_yuv_of(code, &yd)) {
+    YuvArgsK ya;
+    ya.H = oh; ya.W = ow; ya.d = yd;
+    long long by = ((long long)oh * ow + 255) / 256;
+    if (by > 4096) by = 4096;
+    for (int f0 = 0; f0 < n; f0 += 65535) {
+      const int nf = n - f0 < 65535 ? n - f0 : 65535;
+      ya.src = d_src + f0; ya.dst = d_dst + f0;
+      st_timed t(ctx, ST_K_CVT_COLOR);
+      hipLaunchKernelGGL(k_cvt_yuv_u8, dim3((unsigned)by, nf), dim3(256), 0, ctx->stream, ya);
+      ST_HIP(ctx, hipGetLastError());
+    }
+    return ST_OK;
+  }
   CvtArgsK a;
   a.npix = (long long)h * w; a.code = code;
   if (gray_bits == 14) { a.cb = 1868; a.cg = 9617; a.cr = 4899; } else { a.cb = 3735; a.cg = 19235; a.cr = 9798; }

@@ -253,11 +253,11 @@ class HipContext:
             _require_cuda(f, torch.uint8, "frame", self.device)
             if tuple(f.shape) != (h, w, c):
                 raise ValueError("all frames must have the same (h,w,c) shape")
-        oc = self._L.st_cvt_color_out_channels(int(code), c)
-        if oc < 0:
-            raise ValueError("conversion code %d on %d-channel frames is not implemented" % (code, c))
-        out = (torch.empty((n, h, w, oc), dtype=torch.uint8, device=self.device) if out is None
-               else _check_out(out, (n, h, w, oc), torch.uint8, self.device))
+        oh, ow, oc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if self._L.st_cvt_color_out_shape(int(code), h, w, c, ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(oc)) != 0:
+            raise ValueError("conversion code %d on %dx%d frames of %d channel(s) is not implemented" % (code, w, h, c))
+        shape = (n, oh.value, ow.value, oc.value)
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device) if out is None else _check_out(out, shape, torch.uint8, self.device)
         tf = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
         to = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
         self._check(self._L.st_cvt_color_u8_batch(self._h, tf, n, h, w, c, int(code), int(gray_bits), to))

@@ -40,6 +40,78 @@ const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
     {u8"COLOR_YUV2BGR", ST_COLOR_YUV2BGR},   {u8"COLOR_YUV2RGB", ST_COLOR_YUV2RGB},
     {u8"COLOR_BGR2XYZ", ST_COLOR_BGR2XYZ},   {u8"COLOR_RGB2XYZ", ST_COLOR_RGB2XYZ},
     {u8"COLOR_XYZ2BGR", ST_COLOR_XYZ2BGR},   {u8"COLOR_XYZ2RGB", ST_COLOR_XYZ2RGB},
+    // YUV 4:2:0 (single-channel (3H/2, W) frames) and packed 4:2:2 ((H, W, 2) frames) sources; cv::ColorConversionCodes values
+    {u8"COLOR_YUV2RGB_NV12", 90},
+    {u8"COLOR_YUV2BGR_NV12", 91},
+    {u8"COLOR_YUV2RGB_NV21", 92},
+    {u8"COLOR_YUV2BGR_NV21", 93},
+    {u8"COLOR_YUV420sp2RGB", 92},
+    {u8"COLOR_YUV420sp2BGR", 93},
+    {u8"COLOR_YUV2RGBA_NV12", 94},
+    {u8"COLOR_YUV2BGRA_NV12", 95},
+    {u8"COLOR_YUV2RGBA_NV21", 96},
+    {u8"COLOR_YUV2BGRA_NV21", 97},
+    {u8"COLOR_YUV420sp2RGBA", 96},
+    {u8"COLOR_YUV420sp2BGRA", 97},
+    {u8"COLOR_YUV2RGB_YV12", 98},
+    {u8"COLOR_YUV2BGR_YV12", 99},
+    {u8"COLOR_YUV2RGB_IYUV", 100},
+    {u8"COLOR_YUV2BGR_IYUV", 101},
+    {u8"COLOR_YUV2RGB_I420", 100},
+    {u8"COLOR_YUV2BGR_I420", 101},
+    {u8"COLOR_YUV420p2RGB", 98},
+    {u8"COLOR_YUV420p2BGR", 99},
+    {u8"COLOR_YUV2RGBA_YV12", 102},
+    {u8"COLOR_YUV2BGRA_YV12", 103},
+    {u8"COLOR_YUV2RGBA_IYUV", 104},
+    {u8"COLOR_YUV2BGRA_IYUV", 105},
+    {u8"COLOR_YUV2RGBA_I420", 104},
+    {u8"COLOR_YUV2BGRA_I420", 105},
+    {u8"COLOR_YUV420p2RGBA", 102},
+    {u8"COLOR_YUV420p2BGRA", 103},
+    {u8"COLOR_YUV2GRAY_420", 106},
+    {u8"COLOR_YUV2GRAY_NV21", 106},
+    {u8"COLOR_YUV2GRAY_NV12", 106},
+    {u8"COLOR_YUV2GRAY_YV12", 106},
+    {u8"COLOR_YUV2GRAY_IYUV", 106},
+    {u8"COLOR_YUV2GRAY_I420", 106},
+    {u8"COLOR_YUV420sp2GRAY", 106},
+    {u8"COLOR_YUV420p2GRAY", 106},
+    {u8"COLOR_YUV2RGB_UYVY", 107},
+    {u8"COLOR_YUV2BGR_UYVY", 108},
+    {u8"COLOR_YUV2RGB_Y422", 107},
+    {u8"COLOR_YUV2BGR_Y422", 108},
+    {u8"COLOR_YUV2RGB_UYNV", 107},
+    {u8"COLOR_YUV2BGR_UYNV", 108},
+    {u8"COLOR_YUV2RGBA_UYVY", 111},
+    {u8"COLOR_YUV2BGRA_UYVY", 112},
+    {u8"COLOR_YUV2RGBA_Y422", 111},
+    {u8"COLOR_YUV2BGRA_Y422", 112},
+    {u8"COLOR_YUV2RGBA_UYNV", 111},
+    {u8"COLOR_YUV2BGRA_UYNV", 112},
+    {u8"COLOR_YUV2RGB_YUY2", 115},
+    {u8"COLOR_YUV2BGR_YUY2", 116},
+    {u8"COLOR_YUV2RGB_YVYU", 117},
+    {u8"COLOR_YUV2BGR_YVYU", 118},
+    {u8"COLOR_YUV2RGB_YUYV", 115},
+    {u8"COLOR_YUV2BGR_YUYV", 116},
+    {u8"COLOR_YUV2RGB_YUNV", 115},
+    {u8"COLOR_YUV2BGR_YUNV", 116},
+    {u8"COLOR_YUV2RGBA_YUY2", 119},
+    {u8"COLOR_YUV2BGRA_YUY2", 120},
+    {u8"COLOR_YUV2RGBA_YVYU", 121},
+    {u8"COLOR_YUV2BGRA_YVYU", 122},
+    {u8"COLOR_YUV2RGBA_YUYV", 119},
+    {u8"COLOR_YUV2BGRA_YUYV", 120},
+    {u8"COLOR_YUV2RGBA_YUNV", 119},
+    {u8"COLOR_YUV2BGRA_YUNV", 120},
+    {u8"COLOR_YUV2GRAY_UYVY", 123},
+    {u8"COLOR_YUV2GRAY_YUY2", 124},
+    {u8"COLOR_YUV2GRAY_Y422", 123},
+    {u8"COLOR_YUV2GRAY_UYNV", 123},
+    {u8"COLOR_YUV2GRAY_YVYU", 124},
+    {u8"COLOR_YUV2GRAY_YUYV", 124},
+    {u8"COLOR_YUV2GRAY_YUNV", 124},
     // channel layout family: alpha channel added / dropped / swapped, 16-bit packed pixels (2-channel frames)
     {u8"COLOR_BGR2BGRA", ST_COLOR_BGR2BGRA}, {u8"COLOR_RGB2RGBA", ST_COLOR_BGR2BGRA}, {u8"COLOR_BGRA2BGR", ST_COLOR_BGRA2BGR},
     {u8"COLOR_RGBA2RGB", ST_COLOR_BGRA2BGR}, {u8"COLOR_BGR2RGBA", ST_COLOR_BGR2RGBA}, {u8"COLOR_RGB2BGRA", ST_COLOR_BGR2RGBA},
@@ -103,10 +175,11 @@ class ConvertColorKernelHIPImpl : public BatchedKernel {
     LOG_IF(FATAL, code_ < 0) << valid_.msg();
     const Frame* frame = frame_col[0].as_const_frame();
     LOG_IF(FATAL, frame->type != FrameType::U8) << "ConvertColor expects U8 frames";
-    const int out_channels = st_cvt_color_out_channels(code_, frame->channels());
-    LOG_IF(FATAL, out_channels < 0) << "ConvertColor: conversion " << code_ << " does not apply to "
-                                    << frame->channels() << "-channel frames";
-    FrameInfo info(frame->height(), frame->width(), out_channels, FrameType::U8);
+    int out_h = 0, out_w = 0, out_channels = 0;
+    LOG_IF(FATAL, st_cvt_color_out_shape(code_, frame->height(), frame->width(), frame->channels(), &out_h, &out_w, &out_channels) != 0)
+        << "ConvertColor: conversion " << code_ << " does not apply to " << frame->width() << "x" << frame->height() << " frames of "
+        << frame->channels() << " channel(s)";
+    FrameInfo info(out_h, out_w, out_channels, FrameType::U8);
     std::vector<Frame*> output_frames = new_frames(device_, info, input_count);
     src_.resize(input_count);
     dst_.resize(input_count);

@@ -43,6 +43,15 @@ def test_histogram_and_color_against_opencv():
     f4[:5, :5, 3] = 0
     f2 = rng.integers(0, 256, f.shape[:2] + (2,), dtype=np.uint8)
     srcs = {1: np.ascontiguousarray(f[..., :1]), 2: f2, 3: f, 4: f4}
+    from util import cvt_source
+    for name, code in COLOR_CODES.items():
+        if 90 <= code <= 124:   # YUV 4:2:0 / 4:2:2 sources
+            assert getattr(cv2, name) == code, name
+            for hh, ww in ((6, 10), (54, 98)):
+                src = cvt_source(rng, code, hh, ww)
+                ref = cv2.cvtColor(src[..., 0] if src.shape[2] == 1 else src, code)
+                got = oracle.cvt_color(src, code)
+                np.testing.assert_array_equal(got[..., 0] if ref.ndim == 2 else got, ref, err_msg=name)
     for name, code in COLOR_CODES.items():
         if not (code <= 3 or code == 5 or 9 <= code <= 31):
             continue

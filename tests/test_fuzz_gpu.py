@@ -7,7 +7,7 @@ import torch
 
 import oracle
 from scannertools_amd._native import COLOR_CODES
-from util import smooth_texture
+from util import cvt_source, smooth_texture
 
 pytestmark = pytest.mark.gpu
 
@@ -39,11 +39,10 @@ def test_fuzz_integer_ops(hip_ctx, seed):
             np.testing.assert_array_equal(got[i], oracle.resize_u8(frames[i], dw, dh, interp),
                                           err_msg="resize %dx%d -> %dx%d interp %d" % (h, w, dh, dw, interp))
         name = list(COLOR_CODES)[int(rng.integers(0, len(COLOR_CODES)))]
-        cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(COLOR_CODES[name], c) > 0)
-        src = np.ascontiguousarray(np.concatenate([frames, frames[..., ::-1]], axis=3)[..., :cin])   # 1, 2, 3 or 4 input channels
+        src = np.stack([cvt_source(rng, COLOR_CODES[name], h, w) for _ in range(n)])
         got = hip_ctx.cvt_color(_cu(src), name).cpu().numpy()
         for i in range(n):
-            np.testing.assert_array_equal(got[i], oracle.cvt_color(src[i], COLOR_CODES[name]), err_msg=name)
+            np.testing.assert_array_equal(got[i], oracle.cvt_color(src[i], COLOR_CODES[name]), err_msg="%s %dx%d" % (name, h, w))
         flows = (rng.standard_normal((n, h, w, 2)) * float(rng.choice([0.3, 3.0, 40.0]))).astype(np.float32)
         got = hip_ctx.flow_histogram(_cu(flows)).cpu().numpy()
         for i in range(n):

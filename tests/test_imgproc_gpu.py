@@ -286,6 +286,69 @@ def test_hsv_histogram_pipeline(device):
         np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))
 
 
+@pytest.mark.parametrize("H,W", [(2, 2), (6, 10), (54, 98), (270, 480)])
+def test_cvt_color_yuv_sources(hip_ctx, H, W):
+    """cv::cvtColor codes 90..124: NV12 / NV21 / YV12 / IYUV 4:2:0 frames ((3H/2, W, 1), heights that are and are not
+    multiples of 4) and UYVY / YUY2 / YVYU 4:2:2 frames ((H, W, 2)) to RGB / BGR / RGBA / BGRA / gray, every name, against the
+    oracle's block-wise restatement; BT.601 known answers; shapes that cannot be such frames are refused."""
+    from scannertools_amd._native import COLOR_CODES
+    from util import cvt_source
+    rng = np.random.default_rng(H * W)
+    names = [n for n, c in COLOR_CODES.items() if 90 <= c <= 124]
+    assert len(names) == 71 and len({COLOR_CODES[n] for n in names}) == 31
+    for name in names:
+        code = COLOR_CODES[name]
+        src = np.stack([cvt_source(rng, code, H, W) for _ in range(2)])
+        if rng.random() < 0.5:                      # extreme chroma / luma: the saturating branches
+            src[0] = rng.choice(np.array([0, 15, 16, 17, 128, 234, 235, 236, 255], np.uint8), src[0].shape)
+        got = hip_ctx.cvt_color(torch.from_numpy(src).cuda(), name).cpu().numpy()
+        for i in range(2):
+            np.testing.assert_array_equal(got[i], oracle.cvt_color(src[i], code), err_msg=name)
+        assert got.shape[1:3] == (H, W)
+    # BT.601: (Y, U, V) = (235, 128, 128) white, (16, 128, 128) black, (81, 90, 240) red, (145, 54, 34) green, (41, 240, 110) blue
+    for (yy, uu, vv), rgb in (((235, 128, 128), (255, 255, 255)), ((16, 128, 128), (0, 0, 0)), ((81, 90, 240), (254, 0, 0)),
+                               ((145, 54, 34), (0, 255, 1)), ((41, 240, 110), (0, 0, 255))):
+        nv12 = np.zeros((1, H * 3 // 2, W, 1), np.uint8)
+        nv12[0, :H] = yy
+        nv12[0, H:, 0::2] = uu
+        nv12[0, H:, 1::2] = vv
+        out = hip_ctx.cvt_color(torch.from_numpy(nv12).cuda(), "COLOR_YUV2RGB_NV12").cpu().numpy()
+        assert np.abs(out.reshape(-1, 3).astype(int) - np.array(rgb)).max() <= 1, (yy, uu, vv, out[0, 0, 0])
+        assert (out == out[0, 0, 0]).all()
+        i420 = np.concatenate([np.full(H * W, yy), np.full(H * W // 4, uu), np.full(H * W // 4, vv)]).astype(np.uint8).reshape(1, H * 3 // 2, W, 1)
+        assert np.array_equal(hip_ctx.cvt_color(torch.from_numpy(i420).cuda(), "COLOR_YUV2RGB_I420").cpu().numpy(), out)
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.zeros((1, 4, 6, 3), dtype=torch.uint8, device="cuda"), "COLOR_YUV2RGB_NV12")     # not single-channel
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.zeros((1, 4, 6, 1), dtype=torch.uint8, device="cuda"), "COLOR_YUV2RGB_NV12")     # height not 3H/2
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.zeros((1, 6, 5, 1), dtype=torch.uint8, device="cuda"), "COLOR_YUV2RGB_NV12")     # odd width
+    with pytest.raises(ValueError):
+        hip_ctx.cvt_color(torch.zeros((1, 4, 5, 2), dtype=torch.uint8, device="cuda"), "COLOR_YUV2BGR_YUY2")     # odd width
+
+
+def test_nv12_ingest_pipeline():
+    """Decoder-style ingest: NV12 frames -> ConvertColor(COLOR_YUV2RGB_NV12) -> Histogram, through the
+    kernel classes; the output-shape probe turns (3H/2, W, 1) frames into (H, W, 3) ones."""
+    from scannertools_amd.engine import NamedStream
+    rng = np.random.default_rng(8)
+    H, W = 48, 64
+    nv12 = rng.integers(0, 256, (4, H * 3 // 2, W, 1), dtype=np.uint8)
+    sc = Client()
+    sc.ingest_frames('nv12', nv12)
+    frame = sc.io.Input([NamedVideoStream(sc, 'nv12')])
+    for device in (DeviceType.GPU, DeviceType.CPU):
+        rgb = sc.ops.ConvertColor(frame=frame, conversion='COLOR_YUV2RGB_NV12', device=device, batch=3)
+        hist = sc.ops.Histogram(frame=rgb, device=device, batch=2)
+        o_rgb, o_hist = NamedStream(sc, 'rgb'), NamedStream(sc, 'hist')
+        sc.run([sc.io.Output(rgb, [o_rgb]), sc.io.Output(hist, [o_hist])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        for i, (r, hh) in enumerate(zip(o_rgb.load(), o_hist.load())):
+            ref = oracle.cvt_color(nv12[i], 90)
+            assert r.shape == (H, W, 3)
+            np.testing.assert_array_equal(r, ref)
+            np.testing.assert_array_equal(np.stack(hh), oracle.hist_u8c3(ref, 16))
+
+
 @pytest.mark.parametrize("device", [DeviceType.CPU, DeviceType.GPU])
 def test_layout_conversions_through_the_kernel_classes(device):
     """ConvertColor with output frames of 4 and 2 channels, chained (RGB -> RGBA -> BGR565 -> gray): the op's

@@ -102,3 +102,16 @@ def synthetic_pose_maps(seed, H, W, n_people, max_peaks=64, clutter=3, drop=0.1)
             peaks[j, 0, 0] = c
     hm += (rng.standard_normal(hm.shape) * 0.02).astype(np.float32)
     return hm, peaks, truth
+
+
+def cvt_source(rng, code, h, w):
+    """A random uint8 frame of the shape cv::cvtColor code `code` takes, near (h, w): 1-, 2-, 3- or 4-channel pixels, the
+    (3H/2, W, 1) YUV 4:2:0 frames of codes 90..106 and the (H, W, 2) packed 4:2:2 frames of codes 107..124 (even sizes)."""
+    import oracle
+    if 90 <= code <= 106:
+        H, W = max(2, h - h % 2), max(2, w - w % 2)
+        return rng.integers(0, 256, (H * 3 // 2, W, 1), dtype=np.uint8)
+    if 107 <= code <= 124:
+        return rng.integers(0, 256, (max(1, h), max(2, w - w % 2), 2), dtype=np.uint8)
+    cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(code, c) > 0)
+    return rng.integers(0, 256, (h, w, cin), dtype=np.uint8)
