@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import oracle
+from scannertools_amd._native import COLOR_CODES as COLOR_CODES_ALL
 from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedVideoStream, PerfParams
 from util import random_frames, texture_stream
 
@@ -184,7 +185,7 @@ def test_resize_op_target_size_rules():
                                        ("COLOR_HSV2RGB_FULL", 71), ("COLOR_BGR2YUV", 82), ("COLOR_RGB2YUV", 83),
                                        ("COLOR_YUV2BGR", 84), ("COLOR_YUV2RGB", 85), ("COLOR_BGR2XYZ", 32), ("COLOR_RGB2XYZ", 33),
                                        ("COLOR_XYZ2BGR", 34), ("COLOR_XYZ2RGB", 35)])
-@pytest.mark.parametrize("h,w", [(1, 1), (37, 53), (480, 640)])
+@pytest.mark.parametrize("h,w", [(1, 1), (6, 10), (37, 53), (480, 640)])
 def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
     frames = random_frames(h + w + code, 2, h, w)
     got = hip_ctx.cvt_color(torch.from_numpy(frames).cuda(), name).cpu().numpy()
@@ -286,7 +287,7 @@ def test_hsv_histogram_pipeline(device):
         np.testing.assert_array_equal(gg, oracle.cvt_color(frames[i], oracle.COLOR_RGB2GRAY))
 
 
-@pytest.mark.parametrize("H,W", [(2, 2), (6, 10), (54, 98), (270, 480)])
+@pytest.mark.parametrize("H,W", [(2, 2), (6, 10), (10, 20), (8, 48), (54, 98), (270, 480)])
 def test_cvt_color_yuv_sources(hip_ctx, H, W):
     """cv::cvtColor codes 90..124: NV12 / NV21 / YV12 / IYUV 4:2:0 frames ((3H/2, W, 1), heights that are and are not
     multiples of 4) and UYVY / YUY2 / YVYU 4:2:2 frames ((H, W, 2)) to RGB / BGR / RGBA / BGRA / gray, every name, against the
@@ -325,6 +326,26 @@ def test_cvt_color_yuv_sources(hip_ctx, H, W):
         hip_ctx.cvt_color(torch.zeros((1, 6, 5, 1), dtype=torch.uint8, device="cuda"), "COLOR_YUV2RGB_NV12")     # odd width
     with pytest.raises(ValueError):
         hip_ctx.cvt_color(torch.zeros((1, 4, 5, 2), dtype=torch.uint8, device="cuda"), "COLOR_YUV2BGR_YUY2")     # odd width
+
+
+def test_cvt_color_unaligned_frames(hip_ctx):
+    """Frames that start on odd addresses (a view into a larger buffer) take the byte-wise kernels; 4-byte aligned ones with a
+    multiple of 4 pixels the 4-pixel kernels; results are the same."""
+    rng = np.random.default_rng(11)
+    for name, shape in (("COLOR_RGB2HSV", (16, 32, 3)), ("COLOR_RGB2BGR565", (16, 32, 3)), ("COLOR_YUV2RGB_NV12", (24, 32, 1)),
+                        ("COLOR_YUV2BGRA_UYVY", (16, 32, 2)), ("COLOR_BGRA2GRAY", (16, 32, 4))):
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        ref = oracle.cvt_color(src, COLOR_CODES_ALL[name])
+        nbytes = src.size
+        for off in (0, 1, 4, 6):
+            buf = torch.zeros(nbytes + 32, dtype=torch.uint8, device="cuda")
+            view = buf[off:off + nbytes].view(1, *shape)
+            view.copy_(torch.from_numpy(src))
+            obuf = torch.zeros(ref.size + 32, dtype=torch.uint8, device="cuda")
+            out = obuf[off:off + ref.size].view(1, *ref.shape)
+            hip_ctx.cvt_color(view, name, out=out)
+            np.testing.assert_array_equal(out[0].cpu().numpy(), ref, err_msg="%s offset %d" % (name, off))
+            assert int(obuf[:off].sum()) == 0 and int(obuf[off + ref.size:].sum()) == 0     # nothing written outside the frame
 
 
 def test_nv12_ingest_pipeline():
