@@ -354,6 +354,82 @@ __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
   }
 }
 
+// INTER_LINEAR on 3-channel frames, the op's default and commonest case, restructured around what k_resize_u8 spends its
+// time on (per-pixel double-precision coordinates and byte stores): a thread owns FOUR consecutive output columns for a
+// strip of RL_ROWS rows -- the column coordinates and weights are computed once per strip, the row's once per 4 pixels --
+// and stores each row's 12 bytes as three dwords.  Same arithmetic as the generic kernel, value for value.
+// (Rows of 3 * dw bytes start at any byte: the stores are unaligned dwords; a row's last, partial group goes out bytewise.)
+constexpr int RL_ROWS = 4;
+__global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
+  const int g = blockIdx.x * 256 + threadIdx.x;  // group of 4 output columns
+  if (4 * g >= a.dw) return;
+  const int npx = min(4, a.dw - 4 * g);          // the last group of a row may be partial
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(a.dst[blockIdx.z]);
+  const size_t srow = (size_t)a.sw * 3;
+  int sxo[4], a0[4], a1[4];
+  bool two[4], wide[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int dx = min(4 * g + p, a.dw - 1);
+    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; }
+    a0[p] = rs_coef((1.f - fx) * 2048); a1[p] = rs_coef(fx * 2048);
+    two[p] = sx + 1 < a.sw;  // the right edge takes a single tap * 2048
+    sxo[p] = sx * 3;
+    wide[p] = (size_t)sx * 3 + 8 <= srow;
+  }
+  const int dy0 = blockIdx.y * RL_ROWS;
+  for (int dy = dy0; dy < min(a.dh, dy0 + RL_ROWS); ++dy) {
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    const int b0 = rs_coef((1.f - fy) * 2048), b1 = rs_coef(fy * 2048);
+    const int y0 = sy < 0 ? 0 : (sy > a.sh - 1 ? a.sh - 1 : sy);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > a.sh - 1 ? a.sh - 1 : sy + 1);
+    const uint8_t* __restrict__ R0 = src + (size_t)y0 * srow;
+    const uint8_t* __restrict__ R1 = src + (size_t)y1 * srow;
+    unsigned out[3] = {0u, 0u, 0u};
+    typedef unsigned u32u __attribute__((aligned(1)));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      // the two source pixels of a row are 6 contiguous bytes at any byte offset: two unaligned dword loads instead of
+      // six byte loads (vector-memory instructions are what this kernel is short of), except where 8 bytes would run
+      // past the end of the row
+      int t0[6], t1[6];
+      if (wide[p]) {
+        const unsigned l0 = *reinterpret_cast<const u32u*>(R0 + sxo[p]), h0 = *reinterpret_cast<const u32u*>(R0 + sxo[p] + 4);
+        const unsigned l1 = *reinterpret_cast<const u32u*>(R1 + sxo[p]), h1 = *reinterpret_cast<const u32u*>(R1 + sxo[p] + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { t0[k] = (l0 >> (8 * k)) & 0xff; t1[k] = (l1 >> (8 * k)) & 0xff; }
+        t0[4] = h0 & 0xff; t0[5] = (h0 >> 8) & 0xff; t1[4] = h1 & 0xff; t1[5] = (h1 >> 8) & 0xff;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t0[k] = R0[sxo[p] + k]; t1[k] = R1[sxo[p] + k]; }
+#pragma unroll
+        for (int k = 3; k < 6; ++k) { t0[k] = two[p] ? R0[sxo[p] + k] : 0; t1[k] = two[p] ? R1[sxo[p] + k] : 0; }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int r0 = two[p] ? t0[c] * a0[p] + t0[3 + c] * a1[p] : t0[c] * 2048;
+        const int r1 = two[p] ? t1[c] * a0[p] + t1[3 + c] * a1[p] : t1[c] * 2048;
+        const unsigned v = (unsigned)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        out[(3 * p + c) >> 2] |= v << (8 * ((3 * p + c) & 3));
+      }
+    }
+    uint8_t* ob = reinterpret_cast<uint8_t*>(dst) + ((size_t)dy * a.dw + 4 * g) * 3;  // any byte when 3 * dw % 4 != 0
+    if (npx == 4) {
+      u32u* o = reinterpret_cast<u32u*>(ob);
+      o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    } else {
+      for (int k = 0; k < 3 * npx; ++k) ob[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+
 // ---- ConvertColor ---------------------------------------------------------------------------------
 struct CvtArgsK {
   const uint8_t* const* src;
@@ -927,7 +1003,11 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
     const int nf = n - f0 < 65535 ? n - f0 : 65535;
     a.src = d_src + f0; a.dst = d_dst + f0;
     st_timed t(ctx, ST_K_RESIZE);
-    hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
+    const bool fast = a.mode == RS_LINEAR && channels == 3;
+    if (fast)
+      hipLaunchKernelGGL(k_resize_linear_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;

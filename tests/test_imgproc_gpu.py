@@ -348,6 +348,26 @@ def test_cvt_color_unaligned_frames(hip_ctx):
             assert int(obuf[:off].sum()) == 0 and int(obuf[off + ref.size:].sum()) == 0     # nothing written outside the frame
 
 
+def test_resize_linear_fast_path_alignments(hip_ctx):
+    """INTER_LINEAR on 3-channel frames takes the 4-columns-per-thread kernel (unaligned dword loads and stores): widths that
+    are and are not multiples of 4, source and destination frames on odd addresses, single-column and single-row
+    targets, enlargement -- bit for bit the oracle's values and nothing written outside the frame."""
+    from scannertools_amd._native import INTER_LINEAR
+    rng = np.random.default_rng(21)
+    for (h, w, dh, dw) in ((37, 53, 20, 31), (37, 53, 21, 32), (64, 96, 100, 150), (9, 7, 1, 1), (9, 7, 3, 1), (9, 7, 1, 5), (120, 200, 67, 113)):
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = oracle.resize_u8(src, dw, dh, INTER_LINEAR)
+        for off in (0, 1, 3):
+            sbuf = torch.zeros(src.size + 16, dtype=torch.uint8, device="cuda")
+            sview = sbuf[off:off + src.size].view(1, h, w, 3)
+            sview.copy_(torch.from_numpy(src))
+            obuf = torch.zeros(ref.size + 16, dtype=torch.uint8, device="cuda")
+            out = obuf[off:off + ref.size].view(1, dh, dw, 3)
+            hip_ctx.resize(sview, dw, dh, INTER_LINEAR, out=out)
+            np.testing.assert_array_equal(out[0].cpu().numpy(), ref, err_msg="%dx%d -> %dx%d offset %d" % (h, w, dh, dw, off))
+            assert int(obuf[:off].sum()) == 0 and int(obuf[off + ref.size:].sum()) == 0
+
+
 def test_nv12_ingest_pipeline():
     """Decoder-style ingest: NV12 frames -> ConvertColor(COLOR_YUV2RGB_NV12) -> Histogram, through the
     kernel classes; the output-shape probe turns (3H/2, W, 1) frames into (H, W, 3) ones."""
