@@ -114,15 +114,9 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   if (b >= nb) return;
   const int lo = 3 * a.left, hi = 3 * (a.w - a.right);  // interior bytes of a row: [lo, hi)
   unsigned v[4] = {0, 0, 0, 0};
-  for (int r = 0; r < nrows; ++r) {
-    unsigned hn[4];
-    hsum(r, hn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += hn[j];
-    const int ro = r - (a.k - 1);  // output row of the tile completed by staged row r
-    if (ro < 0) continue;
+  auto emit = [&](int ro) {  // output row `ro` of the tile from the window sums in v; false: past the frame
     const int y = Y0 + ro;
-    if (y >= a.h) break;
+    if (y >= a.h) return false;
     const bool yin = y >= a.left && y < a.h - a.right;
     uint8_t* out = dst + (size_t)y * nb + b;
     unsigned packed = 0;
@@ -135,6 +129,38 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
     } else {
       for (int j = 0; b + j < nb; ++j) out[j] = (uint8_t)(packed >> (8 * j));
     }
+    return true;
+  };
+  if (KS > 0) {
+    // compile-time kernel size: the KS horizontal sums inside the window stay in a register ring (the loop is fully
+    // unrolled, so the ring is indexed statically) -- each staged row is read and summed ONCE
+    unsigned ring[KS > 0 ? KS : 1][4];
+#pragma unroll
+    for (int r = 0; r < BL_ROWS + KS - 1; ++r) {
+      unsigned hn[4];
+      hsum(r, hn);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += hn[j];
+      const int ro = r - (KS - 1);
+      if (ro >= 0) {
+        if (!emit(ro)) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] -= ring[ro % KS][j];  // the row that leaves: staged row ro
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ring[r % KS][j] = hn[j];    // slot of row r - KS, which left above (or was never used)
+    }
+    return;
+  }
+  for (int r = 0; r < nrows; ++r) {
+    unsigned hn[4];
+    hsum(r, hn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += hn[j];
+    const int ro = r - (a.k - 1);  // output row of the tile completed by staged row r
+    if (ro < 0) continue;
+    if (!emit(ro)) break;
+    // generic sizes: the row that leaves the window is summed again from the staged bytes rather than kept
     unsigned ho[4];
     hsum(ro, ho);
 #pragma unroll
