@@ -456,6 +456,41 @@ __global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
   }
 }
 
+// The exact 2 x 2 decimation (INTER_AREA, and INTER_LINEAR's reroute to it) on 3-channel frames: four output pixels per
+// thread = 24 contiguous source bytes in each of two rows (six unaligned dword loads per row instead of 24 byte loads),
+// twelve output bytes as three unaligned dword stores.  (v00 + v01 + v10 + v11 + 2) >> 2 as in k_resize_u8.
+__global__ __launch_bounds__(256) void k_resize_area2_c3_v4(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int g = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (4 * g >= a.dw) return;
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* ob = a.dst[blockIdx.z] + ((size_t)dy * a.dw + 4 * g) * 3;
+  const size_t srow = (size_t)a.sw * 3;
+  const uint8_t* S0 = src + (size_t)(2 * dy) * srow + (size_t)(8 * g) * 3;
+  const uint8_t* S1 = S0 + srow;
+  if (4 * g + 4 <= a.dw) {
+    unsigned w0[6], w1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { w0[k] = reinterpret_cast<const u32u*>(S0)[k]; w1[k] = reinterpret_cast<const u32u*>(S1)[k]; }
+    unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int i0 = 6 * p + c, i1 = 6 * p + 3 + c;  // bytes of the two source columns
+        const unsigned v = (((w0[i0 >> 2] >> (8 * (i0 & 3))) & 0xffu) + ((w0[i1 >> 2] >> (8 * (i1 & 3))) & 0xffu) +
+                            ((w1[i0 >> 2] >> (8 * (i0 & 3))) & 0xffu) + ((w1[i1 >> 2] >> (8 * (i1 & 3))) & 0xffu) + 2u) >> 2;
+        out[(3 * p + c) >> 2] |= v << (8 * ((3 * p + c) & 3));
+      }
+    u32u* o = reinterpret_cast<u32u*>(ob);
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+  } else {
+    for (int p = 0; 4 * g + p < a.dw; ++p)
+      for (int c = 0; c < 3; ++c)
+        ob[3 * p + c] = (uint8_t)((S0[6 * p + c] + S0[6 * p + 3 + c] + S1[6 * p + c] + S1[6 * p + 3 + c] + 2) >> 2);
+  }
+}
+
 // ---- ConvertColor ---------------------------------------------------------------------------------
 struct CvtArgsK {
   const uint8_t* const* src;
@@ -1030,7 +1065,9 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
     a.src = d_src + f0; a.dst = d_dst + f0;
     st_timed t(ctx, ST_K_RESIZE);
     const bool fast = a.mode == RS_LINEAR && channels == 3;
-    if (fast)
+    if (a.mode == RS_AREA2 && channels == 3)
+      hipLaunchKernelGGL(k_resize_area2_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
+    else if (fast)
       hipLaunchKernelGGL(k_resize_linear_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else
       hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);

@@ -368,6 +368,26 @@ def test_resize_linear_fast_path_alignments(hip_ctx):
             assert int(obuf[:off].sum()) == 0 and int(obuf[off + ref.size:].sum()) == 0
 
 
+def test_resize_exact_half_fast_path(hip_ctx):
+    """The exact 2x2 decimation (INTER_AREA and INTER_LINEAR's reroute) on 3-channel frames: 4 output pixels per thread with a
+    partial last group, odd addresses; other channel counts keep the generic kernel; all bit for bit the oracle's."""
+    from scannertools_amd._native import INTER_AREA, INTER_LINEAR
+    rng = np.random.default_rng(23)
+    for (h, w, cn) in ((20, 30, 3), (64, 96, 3), (2, 2, 3), (2, 10, 3), (18, 26, 1), (18, 26, 4)):
+        src = rng.integers(0, 256, (h, w, cn), dtype=np.uint8)
+        for interp in (INTER_LINEAR, INTER_AREA):
+            ref = oracle.resize_u8(src, w // 2, h // 2, interp)
+            for off in (0, 1):
+                sbuf = torch.zeros(src.size + 16, dtype=torch.uint8, device="cuda")
+                sview = sbuf[off:off + src.size].view(1, h, w, cn)
+                sview.copy_(torch.from_numpy(src))
+                obuf = torch.zeros(ref.size + 16, dtype=torch.uint8, device="cuda")
+                out = obuf[off:off + ref.size].view(1, h // 2, w // 2, cn)
+                hip_ctx.resize(sview, w // 2, h // 2, interp, out=out)
+                np.testing.assert_array_equal(out[0].cpu().numpy(), ref, err_msg="%dx%dx%d interp %d offset %d" % (h, w, cn, interp, off))
+                assert int(obuf[:off].sum()) == 0 and int(obuf[off + ref.size:].sum()) == 0
+
+
 def test_nv12_ingest_pipeline():
     """Decoder-style ingest: NV12 frames -> ConvertColor(COLOR_YUV2RGB_NV12) -> Histogram, through the
     kernel classes; the output-shape probe turns (3H/2, W, 1) frames into (H, W, 3) ones."""
