@@ -62,22 +62,48 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   // ---- stage rows Y0-left .. Y0+BL_ROWS-1+right: LDS byte i of a row <-> row byte B0 - H + i.
   // Unaligned dword loads; bytes of a neighbouring row or outside the frame only feed border
   // outputs, which are forced to 0 below.
-  for (int r = 0; r < nrows; ++r) {
+  auto fetch = [&](int r, int d) -> unsigned {
     const int y = Y0 - a.left + r;
     const int yc = y < 0 ? 0 : (y >= a.h ? a.h - 1 : y);
-    for (int d = t; d < a.row_dwords; d += BL_T) {
-      const long long g = (long long)yc * nb + B0 - a.H + 4 * d;
-      unsigned v;
-      if (g >= 0 && g + 4 <= total) {
-        typedef unsigned u32u __attribute__((aligned(1)));
-        v = *reinterpret_cast<const u32u*>(src + g);
-      } else {  // the dword straddles an end of the frame buffer: byte-wise, missing bytes read as 0
-        v = 0;
-        for (int j = 0; j < 4; ++j)
-          if (g + j >= 0 && g + j < total) v |= (unsigned)src[g + j] << (8 * j);
-      }
-      stage[(size_t)r * a.row_dwords + d] = v;
+    const long long g = (long long)yc * nb + B0 - a.H + 4 * d;
+    if (g >= 0 && g + 4 <= total) {
+      typedef unsigned u32u __attribute__((aligned(1)));
+      return *reinterpret_cast<const u32u*>(src + g);
     }
+    unsigned v = 0;  // the dword straddles an end of the frame buffer: byte-wise, missing bytes read as 0
+    for (int j = 0; j < 4; ++j)
+      if (g + j >= 0 && g + j < total) v |= (unsigned)src[g + j] << (8 * j);
+    return v;
+  };
+  if (KS > 0) {
+    // compile-time size: ALL the tile's rows are requested before any is stored to LDS, so the workgroup pays the memory
+    // latency once instead of once per row (the serial form bounded the kernel: 18 dependent round trips per tile)
+    constexpr int NR = BL_ROWS + (KS > 0 ? KS : 1) - 1;
+    unsigned va[NR], vb[NR];
+    const bool second = t + BL_T < a.row_dwords;  // the few dwords of a staged row beyond the first 256
+#pragma unroll
+    for (int r = 0; r < NR; ++r) va[r] = fetch(r, t);
+    if (second) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) vb[r] = fetch(r, t + BL_T);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) stage[(size_t)r * a.row_dwords + t] = va[r];
+    if (second) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) stage[(size_t)r * a.row_dwords + t + BL_T] = vb[r];
+    }
+  } else {
+    // any size: the same in chunks of 8 rows
+    for (int r0 = 0; r0 < nrows; r0 += 8)
+      for (int d = t; d < a.row_dwords; d += BL_T) {
+        unsigned v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = r0 + j < nrows ? fetch(r0 + j, d) : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (r0 + j < nrows) stage[(size_t)(r0 + j) * a.row_dwords + d] = v8[j];
+      }
   }
   __syncthreads();
   // ---- horizontal sums of every staged row for this thread's 4 bytes
