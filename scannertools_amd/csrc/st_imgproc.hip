@@ -127,10 +127,21 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
           s[c] += (wd[j >> 2] >> (8 * (j & 3))) & 0xffu;
         }
     } else {
+      // any size: window byte j (0 <= j < 3k) feeds output byte j % 3, and output byte 3 is output byte 0 shifted by one tap,
+      // so three residue-class sums do -- taken from whole dwords, twelve window bytes (four taps) per round with the
+      // residues known at compile time, the last k % 4 taps bytewise
+      const unsigned* rw = stage + (size_t)r * a.row_dwords + t;
       const uint8_t* row = sb + (size_t)r * a.row_dwords * 4 + 4 * t;
-      for (int i = 0; i < a.k; ++i) {
-        s[0] += row[3 * i]; s[1] += row[3 * i + 1]; s[2] += row[3 * i + 2]; s[3] += row[3 * i + 3];
+      unsigned A0 = 0, A1 = 0, A2 = 0;
+      const int rounds = a.k >> 2;
+      for (int m = 0; m < rounds; ++m) {
+        const unsigned d0 = rw[3 * m], d1 = rw[3 * m + 1], d2 = rw[3 * m + 2];
+        A0 += (d0 & 0xffu) + (d0 >> 24) + ((d1 >> 16) & 0xffu) + ((d2 >> 8) & 0xffu);
+        A1 += ((d0 >> 8) & 0xffu) + (d1 & 0xffu) + (d1 >> 24) + ((d2 >> 16) & 0xffu);
+        A2 += ((d0 >> 16) & 0xffu) + ((d1 >> 8) & 0xffu) + (d2 & 0xffu) + (d2 >> 24);
       }
+      for (int i = 4 * rounds; i < a.k; ++i) { A0 += row[3 * i]; A1 += row[3 * i + 1]; A2 += row[3 * i + 2]; }
+      s[0] = A0; s[1] = A1; s[2] = A2; s[3] = A0 - row[0] + row[3 * a.k];
     }
   };
   // ---- vertical running sums, divide, store.  The row that leaves the window is summed again
