@@ -1862,16 +1862,43 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? a.flow_ptrs[pr] : a.flow_out + (size_t)pr * 2 * (size_t)np;
 
-  // ---- phase 1: M on the tile + apron (Mt row j = source row Y0 - 7 + j, clamped)
-  for (int i = tid; i < FT_S * FT_S; i += 256) {
-    const int ty = i / FT_S, tx = i - ty * FT_S;
-    const int x = d_clamp(X0 - FT_M + tx, 0, w - 1), y = d_clamp(Y0 - FT_M + ty, 0, h - 1);
-    const CoarseX cx = (MODE == FLOW_COARSE) ? coarse_x(a, x) : CoarseX{0, 1.f, 0.f, false};
-    const float2 f = iter_flow_at<MODE>(a, fin, C, cx, x, y);
-    float m[5];
-    update_matrices_px(R0, R1, np, h, w, x, y, f.x, f.y, m);
+  // ---- phase 1: M on the tile + apron (Mt row j = source row Y0 - 7 + j, clamped).  A thread has up to NI = 9 of the
+  // 46 x 46 pixels.  Their flow vectors are requested together, then the expansions in chunks of three pixels: four memory
+  // round trips per tile instead of the eighteen of a pixel-by-pixel loop (flow, then the gather it addresses, nine
+  // times) -- these launches are latency-bound, so that is most of their time.
+  constexpr int NI = (FT_S * FT_S + 255) / 256;
+  int px[NI], py[NI];
+  FlowRaw raw[NI];
+  CoarseX cxs[NI];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
+  for (int k = 0; k < NI; ++k) {
+    const int i = min(tid + 256 * k, FT_S * FT_S - 1);  // the last, partial round recomputes the final pixel: harmless
+    const int ty = i / FT_S, tx = i - ty * FT_S;
+    px[k] = d_clamp(X0 - FT_M + tx, 0, w - 1);
+    py[k] = d_clamp(Y0 - FT_M + ty, 0, h - 1);
+    cxs[k] = (MODE == FLOW_COARSE) ? coarse_x(a, px[k]) : CoarseX{0, 1.f, 0.f, false};
+    flow_issue<MODE>(a, fin, C, cxs[k], px[k], py[k], raw[k]);
+  }
+  float2 fl[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) fl[k] = flow_finish<MODE>(a, fin, C, cxs[k], py[k], raw[k]);
+#pragma unroll
+  for (int k0 = 0; k0 < NI; k0 += 3) {
+    UmLoads L[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) um_issue(R0, R1, np, h, w, px[k0 + j], py[k0 + j], fl[k0 + j], L[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float m[5];
+      um_finish(L[j], h, w, px[k0 + j], py[k0 + j], fl[k0 + j], m);
+      const int i = tid + 256 * (k0 + j);
+      if (i < FT_S * FT_S) {
+        const int ty = i / FT_S, tx = i - ty * FT_S;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one chunk of gathers in flight at a time
   }
   __syncthreads();
   // ---- phase 2: column sums of the tile's 32 rows from the anchor at its first row; item = (channel, column)
