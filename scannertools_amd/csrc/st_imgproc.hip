@@ -528,6 +528,139 @@ __global__ __launch_bounds__(256) void k_resize_area2_c3_v4(ResizeArgsK a) {
   }
 }
 
+// INTER_NEAREST and INTER_CUBIC on 3-channel frames with the same recipe as k_resize_linear_c3_v4: four output columns x
+// RL_ROWS rows per thread, column positions / weights once per strip, a tap's pixels through unaligned dword loads, twelve
+// output bytes as three unaligned dword stores.  Arithmetic as in k_resize_u8, value for value.
+__global__ __launch_bounds__(256) void k_resize_nearest_c3_v4(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (4 * g >= a.dw) return;
+  const int npx = min(4, a.dw - 4 * g);
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const size_t srow = (size_t)a.sw * 3;
+  int sxo[4];
+  bool wide[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int dx = min(4 * g + p, a.dw - 1);
+    int sx = (int)floor(dx * a.scale_x);
+    sx = sx < a.sw - 1 ? sx : a.sw - 1;
+    sxo[p] = sx * 3;
+    wide[p] = (size_t)sx * 3 + 4 <= srow;
+  }
+  const int dy0 = blockIdx.y * RL_ROWS;
+  for (int dy = dy0; dy < min(a.dh, dy0 + RL_ROWS); ++dy) {
+    int sy = (int)floor(dy * a.scale_y);
+    sy = sy < a.sh - 1 ? sy : a.sh - 1;
+    const uint8_t* __restrict__ R = src + (size_t)sy * srow;
+    unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned v;
+      if (wide[p]) v = *reinterpret_cast<const u32u*>(R + sxo[p]) & 0xffffffu;
+      else v = (unsigned)R[sxo[p]] | ((unsigned)R[sxo[p] + 1] << 8) | ((unsigned)R[sxo[p] + 2] << 16);
+      // the pixel's 3 bytes land at output byte 3 p
+      if (p == 0) out[0] |= v;
+      else if (p == 1) { out[0] |= v << 24; out[1] |= v >> 8; }
+      else if (p == 2) { out[1] |= v << 16; out[2] |= v >> 16; }
+      else out[2] |= v << 8;
+    }
+    uint8_t* ob = dstb + ((size_t)dy * a.dw + 4 * g) * 3;
+    if (npx == 4) {
+      u32u* o = reinterpret_cast<u32u*>(ob);
+      o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    } else {
+      for (int k = 0; k < 3 * npx; ++k) ob[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_resize_cubic_c3_v4(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (4 * g >= a.dw) return;
+  const int npx = min(4, a.dw - 4 * g);
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const size_t srow = (size_t)a.sw * 3;
+  int ax[4][4], xs[4][4];
+  bool run[4];  // the four tap columns are consecutive and 12 bytes from the first stay inside the row
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int dx = min(4 * g + p, a.dw - 1);
+    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= sx;
+    float cx[4];
+    rs_cubic(fx, cx);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ax[p][k] = rs_coef(cx[k] * 2048);
+      const int xx = sx - 1 + k;
+      xs[p][k] = (xx < 0 ? 0 : (xx > a.sw - 1 ? a.sw - 1 : xx)) * 3;  // columns outside the row: edge pixel
+    }
+    run[p] = sx - 1 >= 0 && sx + 2 <= a.sw - 1;
+  }
+  const int dy0 = blockIdx.y * RL_ROWS;
+  for (int dy = dy0; dy < min(a.dh, dy0 + RL_ROWS); ++dy) {
+    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    float cy[4];
+    rs_cubic(fy, cy);
+    int by[4];
+    const uint8_t* R[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      by[k] = rs_coef(cy[k] * 2048);
+      const int yy = sy - 1 + k;
+      R[k] = src + (size_t)(yy < 0 ? 0 : (yy > a.sh - 1 ? a.sh - 1 : yy)) * srow;
+    }
+    unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int v[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int t[12];  // the row's four tap pixels, 3 bytes each
+        if (run[p]) {
+          const unsigned w0 = *reinterpret_cast<const u32u*>(R[k] + xs[p][0]), w1 = *reinterpret_cast<const u32u*>(R[k] + xs[p][0] + 4),
+                         w2 = *reinterpret_cast<const u32u*>(R[k] + xs[p][0] + 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { t[j] = (w0 >> (8 * j)) & 0xff; t[4 + j] = (w1 >> (8 * j)) & 0xff; t[8 + j] = (w2 >> (8 * j)) & 0xff; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[3 * q + c] = R[k][xs[p][q] + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int r = t[c] * ax[p][0] + t[3 + c] * ax[p][1] + t[6 + c] * ax[p][2] + t[9 + c] * ax[p][3];
+          v[c] += r * by[k];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int o = (v[c] + (1 << 21)) >> 22;
+        // Keeps hipcc (ROCm 7.2) from fusing shift + clamp + pack of two values into v_ashr_pk_u8_i32: on the GPU that
+        // instruction's result carries bits above 15, which the v_lshl_or that assembles the dword then ORs into bytes 2
+        // and 3 (measured: bytes 0 and 1 of every output dword right, 2 and 3 wrong).
+        asm volatile("" : "+v"(o));
+        out[(3 * p + c) >> 2] |= ((unsigned)(o < 0 ? 0 : (o > 255 ? 255 : o)) & 0xffu) << (8 * ((3 * p + c) & 3));
+      }
+    }
+    uint8_t* ob = dstb + ((size_t)dy * a.dw + 4 * g) * 3;
+    if (npx == 4) {
+      u32u* o = reinterpret_cast<u32u*>(ob);
+      o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    } else {
+      for (int k = 0; k < 3 * npx; ++k) ob[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+
 // ---- ConvertColor ---------------------------------------------------------------------------------
 struct CvtArgsK {
   const uint8_t* const* src;
@@ -941,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_cvt_yuv_u8_vec(YuvArgsK a) {
         d[0] = a.d.bidx ? c[2] : c[0]; d[1] = c[1]; d[2] = a.d.bidx ? c[0] : c[2]; d[3] = 255;
       }
 #pragma unroll
-      for (int k = 0; k < DCN; ++k) out[(p * DCN + k) >> 2] |= (unsigned)d[k] << (8 * ((p * DCN + k) & 3));
+      for (int k = 0; k < DCN; ++k) out[(p * DCN + k) >> 2] |= ((unsigned)d[k] & 0xffu) << (8 * ((p * DCN + k) & 3));
     }
     if (PX == 16) {
 #pragma unroll
@@ -1104,6 +1237,10 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
     const bool fast = a.mode == RS_LINEAR && channels == 3;
     if (a.mode == RS_AREA2 && channels == 3)
       hipLaunchKernelGGL(k_resize_area2_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
+    else if (a.mode == RS_NEAREST && channels == 3)
+      hipLaunchKernelGGL(k_resize_nearest_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
+    else if (a.mode == RS_CUBIC && channels == 3)
+      hipLaunchKernelGGL(k_resize_cubic_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else if (fast)
       hipLaunchKernelGGL(k_resize_linear_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else
