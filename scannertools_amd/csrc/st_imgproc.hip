@@ -661,6 +661,141 @@ __global__ __launch_bounds__(256) void k_resize_cubic_c3_v4(ResizeArgsK a) {
   }
 }
 
+// INTER_AREA with fractional cells (shrinking by a non-integer factor) on 3-channel frames: four output columns x RL_ROWS rows
+// per thread.  A column's cell (head, full cells, tail: at most AR_SPAN source columns here, else the generic kernel) is
+// worked out once per strip as a first column and AR_SPAN (4 or 8) weights in ascending column order -- absent ones are 0, and
+// adding 0.f is exact, so the row sum b = ((t0 + t1) + t2) + ... is ResizeArea_Invoker's, bit for bit; the rows are
+// accumulated as in k_resize_u8 (beta * rowsum, head / full / tail order).  Source pixels through unaligned dword loads.
+template <int AR_SPAN>
+__global__ __launch_bounds__(256) void k_resize_area_c3_v4(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (4 * g >= a.dw) return;
+  const int npx = min(4, a.dw - 4 * g);
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const size_t srow = (size_t)a.sw * 3;
+  int first[4];
+  float wx[4][AR_SPAN];
+  bool wide[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const AreaCell c = rs_area_cell(min(4 * g + p, a.dw - 1), a.sw, a.scale_x);
+    first[p] = c.head_si >= 0 ? c.head_si : c.sx1;
+#pragma unroll
+    for (int j = 0; j < AR_SPAN; ++j) {
+      const int sx = first[p] + j;
+      wx[p][j] = (c.head_si >= 0 && sx == c.head_si) ? c.head_w : ((sx >= c.sx1 && sx < c.sx2) ? c.full_w : ((c.tail && sx == c.sx2) ? c.tail_w : 0.f));
+    }
+    wide[p] = (size_t)first[p] * 3 + 3 * AR_SPAN <= srow;
+  }
+  const int dy0 = blockIdx.y * RL_ROWS;
+  for (int dy = dy0; dy < min(a.dh, dy0 + RL_ROWS); ++dy) {
+    const AreaCell cy = rs_area_cell(dy, a.sh, a.scale_y);
+    float sum[4][3];
+    bool started = false;
+    auto acc = [&](int sy, float beta) {
+      const uint8_t* __restrict__ R = src + (size_t)sy * srow;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        int t[3 * AR_SPAN];
+        if (wide[p]) {
+#pragma unroll
+          for (int q = 0; q < 3 * AR_SPAN / 4; ++q) {
+            const unsigned wv = *reinterpret_cast<const u32u*>(R + (size_t)first[p] * 3 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[4 * q + j] = (wv >> (8 * j)) & 0xff;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3 * AR_SPAN; ++j) {
+            const size_t o = (size_t)first[p] * 3 + j;
+            t[j] = o < srow ? R[o] : 0;  // columns past the row carry weight 0
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float b = (float)t[c] * wx[p][0];
+#pragma unroll
+          for (int j = 1; j < AR_SPAN; ++j) b += (float)t[3 * j + c] * wx[p][j];
+          const float v = beta * b;
+          sum[p][c] = started ? sum[p][c] + v : v;
+        }
+      }
+      started = true;
+    };
+    if (cy.head_si >= 0) acc(cy.head_si, cy.head_w);
+    for (int sy = cy.sx1; sy < cy.sx2; ++sy) acc(sy, cy.full_w);
+    if (cy.tail) acc(cy.sx2, cy.tail_w);
+    unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[(3 * p + c) >> 2] |= ((unsigned)rs_sat_float(started ? sum[p][c] : 0.f) & 0xffu) << (8 * ((3 * p + c) & 3));
+    uint8_t* ob = dstb + ((size_t)dy * a.dw + 4 * g) * 3;
+    if (npx == 4) {
+      u32u* o = reinterpret_cast<u32u*>(ob);
+      o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    } else {
+      for (int k = 0; k < 3 * npx; ++k) ob[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+
+// INTER_AREA with integer cells (shrinking by whole factors, here up to 4 columns per cell) on 3-channel frames: the
+// 4 * iscale_x source pixels of four output pixels are one contiguous run per source row, read as unaligned dwords;
+// integer sums, then saturate_cast<uchar>(sum * (1 / area)) as in k_resize_u8.
+template <int ISX>
+__global__ __launch_bounds__(256) void k_resize_area_int_c3_v4(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int g = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (4 * g >= a.dw) return;
+  const int npx = min(4, a.dw - 4 * g);
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* ob = a.dst[blockIdx.z] + ((size_t)dy * a.dw + 4 * g) * 3;
+  const size_t srow = (size_t)a.sw * 3;
+  constexpr int isx = ISX;                          // 2 .. 4 columns per cell
+  const size_t base = (size_t)(4 * g) * isx * 3;    // first source byte of the run in a row
+  constexpr int nbytes = 12 * isx;                  // 24, 36 or 48
+  const bool full = npx == 4 && base + (size_t)nbytes <= srow;
+  int sum[4][3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) sum[p][0] = sum[p][1] = sum[p][2] = 0;
+  for (int yy = 0; yy < a.iscale_y; ++yy) {
+    const uint8_t* __restrict__ R = src + (size_t)(dy * a.iscale_y + yy) * srow + base;
+    if (full) {
+      unsigned wv[3 * isx];
+#pragma unroll
+      for (int q = 0; q < 3 * isx; ++q) wv[q] = reinterpret_cast<const u32u*>(R)[q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int xx = 0; xx < isx; ++xx)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int j = (p * isx + xx) * 3 + c;  // byte of the run (compile-time)
+            sum[p][c] += (int)((wv[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          }
+    } else {
+      for (int p = 0; p < npx; ++p)
+        for (int xx = 0; xx < isx; ++xx)
+          for (int c = 0; c < 3; ++c) sum[p][c] += R[(p * isx + xx) * 3 + c];
+    }
+  }
+  const float scale = 1.f / (a.iscale_x * a.iscale_y);
+  unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(3 * p + c) >> 2] |= ((unsigned)rs_sat_float(sum[p][c] * scale) & 0xffu) << (8 * ((3 * p + c) & 3));
+  if (npx == 4) {
+    u32u* o = reinterpret_cast<u32u*>(ob);
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+  } else {
+    for (int k = 0; k < 3 * npx; ++k) ob[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+  }
+}
+
 // ---- ConvertColor ---------------------------------------------------------------------------------
 struct CvtArgsK {
   const uint8_t* const* src;
@@ -1237,6 +1372,17 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
     const bool fast = a.mode == RS_LINEAR && channels == 3;
     if (a.mode == RS_AREA2 && channels == 3)
       hipLaunchKernelGGL(k_resize_area2_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
+    else if (a.mode == RS_AREA && channels == 3 && a.scale_x <= 6) {  // a cell spans at most scale + 2 source columns
+      const dim3 gr(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf);
+      if (a.scale_x <= 2) hipLaunchKernelGGL(k_resize_area_c3_v4<4>, gr, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_resize_area_c3_v4<8>, gr, dim3(256), 0, ctx->stream, a);
+    }
+    else if (a.mode == RS_AREA_INT && channels == 3 && a.iscale_x >= 2 && a.iscale_x <= 4) {
+      const dim3 gr(((out_w + 3) / 4 + 255) / 256, out_h, nf);
+      if (a.iscale_x == 2) hipLaunchKernelGGL(k_resize_area_int_c3_v4<2>, gr, dim3(256), 0, ctx->stream, a);
+      else if (a.iscale_x == 3) hipLaunchKernelGGL(k_resize_area_int_c3_v4<3>, gr, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_resize_area_int_c3_v4<4>, gr, dim3(256), 0, ctx->stream, a);
+    }
     else if (a.mode == RS_NEAREST && channels == 3)
       hipLaunchKernelGGL(k_resize_nearest_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else if (a.mode == RS_CUBIC && channels == 3)

@@ -97,7 +97,8 @@ def test_resize_linear_matches_oracle(hip_ctx, sh, sw, dh, dw):
 
 @pytest.mark.parametrize("sh,sw,dh,dw", [(480, 640, 240, 426), (48, 60, 16, 20), (48, 60, 24, 30), (48, 60, 13, 21),
                                          (37, 53, 80, 91), (48, 60, 20, 90), (48, 60, 100, 13), (100, 100, 1, 1),
-                                         (1080, 1920, 360, 640), (9, 7, 9, 7)])
+                                         (1080, 1920, 360, 640), (9, 7, 9, 7), (270, 480, 180, 320), (50, 70, 33, 47), (50, 70, 26, 36),
+                                         (50, 70, 49, 69), (50, 71, 30, 36), (48, 60, 12, 15), (48, 60, 24, 15), (48, 60, 8, 20), (90, 120, 30, 24)])
 @pytest.mark.parametrize("interp", ["cubic", "area", "lanczos4"])
 def test_resize_cubic_and_area_match_oracle(hip_ctx, sh, sw, dh, dw, interp):
     """INTER_CUBIC; INTER_LANCZOS4; INTER_AREA with integer cells (3x, 2x), fractional cells,
