@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
 // and stores each row's 12 bytes as three dwords.  Same arithmetic as the generic kernel, value for value.
 // (Rows of 3 * dw bytes start at any byte: the stores are unaligned dwords; a row's last, partial group goes out bytewise.)
 constexpr int RL_ROWS = 4;
+// AREA_UP: INTER_AREA when an axis is enlarged = the same two-tap filter with cell-aligned weights (RS_LINEAR_AREA)
+template <bool AREA_UP>
 __global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x;  // group of 4 output columns
   if (4 * g >= a.dw) return;
@@ -435,9 +437,17 @@ __global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int dx = min(4 * g + p, a.dw - 1);
-    float fx = (float)((dx + 0.5) * a.scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= sx;
+    float fx;
+    int sx;
+    if (AREA_UP) {
+      sx = (int)floor(dx * a.scale_x);
+      fx = (float)((dx + 1) - (sx + 1) * a.inv_scale_x);
+      fx = fx <= 0 ? 0.f : fx - floorf(fx);
+    } else {
+      fx = (float)((dx + 0.5) * a.scale_x - 0.5);
+      sx = (int)floorf(fx);
+      fx -= sx;
+    }
     if (sx < 0) { fx = 0; sx = 0; }
     if (sx >= a.sw - 1) { fx = 0; sx = a.sw - 1; }
     a0[p] = rs_coef((1.f - fx) * 2048); a1[p] = rs_coef(fx * 2048);
@@ -447,9 +457,17 @@ __global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
   }
   const int dy0 = blockIdx.y * RL_ROWS;
   for (int dy = dy0; dy < min(a.dh, dy0 + RL_ROWS); ++dy) {
-    float fy = (float)((dy + 0.5) * a.scale_y - 0.5);
-    const int sy = (int)floorf(fy);
-    fy -= sy;
+    float fy;
+    int sy;
+    if (AREA_UP) {
+      sy = (int)floor(dy * a.scale_y);
+      fy = (float)((dy + 1) - (sy + 1) * a.inv_scale_y);
+      fy = fy <= 0 ? 0.f : fy - floorf(fy);
+    } else {
+      fy = (float)((dy + 0.5) * a.scale_y - 0.5);
+      sy = (int)floorf(fy);
+      fy -= sy;
+    }
     const int b0 = rs_coef((1.f - fy) * 2048), b1 = rs_coef(fy * 2048);
     const int y0 = sy < 0 ? 0 : (sy > a.sh - 1 ? a.sh - 1 : sy);
     const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > a.sh - 1 ? a.sh - 1 : sy + 1);
@@ -1387,8 +1405,10 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
       hipLaunchKernelGGL(k_resize_nearest_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else if (a.mode == RS_CUBIC && channels == 3)
       hipLaunchKernelGGL(k_resize_cubic_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
+    else if (a.mode == RS_LINEAR_AREA && channels == 3)
+      hipLaunchKernelGGL(k_resize_linear_c3_v4<true>, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else if (fast)
-      hipLaunchKernelGGL(k_resize_linear_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k_resize_linear_c3_v4<false>, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else
       hipLaunchKernelGGL(k_resize_u8, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
