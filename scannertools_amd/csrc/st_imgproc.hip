@@ -814,6 +814,55 @@ __global__ __launch_bounds__(256) void k_resize_area_int_c3_v4(ResizeArgsK a) {
   }
 }
 
+// INTER_LANCZOS4 on 3-channel frames: one output pixel per thread as in k_resize_u8, but a source row's eight tap pixels
+// (24 contiguous bytes when none of them is clamped at an edge) come in as six unaligned dword loads instead of 24 byte loads.
+__global__ __launch_bounds__(256) void k_resize_lanczos4_c3(ResizeArgsK a) {
+  typedef unsigned u32u __attribute__((aligned(1)));
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= a.dw) return;
+  const uint8_t* __restrict__ src = a.src[blockIdx.z];
+  uint8_t* __restrict__ D = a.dst[blockIdx.z] + ((size_t)dy * a.dw + dx) * 3;
+  const size_t srow = (size_t)a.sw * 3;
+  const int sx = a.xofs[dx], sy = a.yofs[dy];
+  int ax[8], xs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ax[k] = a.ialpha[8 * dx + k];
+    const int xx = sx - 3 + k;
+    xs[k] = (xx < 0 ? 0 : (xx > a.sw - 1 ? a.sw - 1 : xx)) * 3;
+  }
+  const bool run = sx - 3 >= 0 && sx + 4 <= a.sw - 1;
+  int v[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int yy = sy - 3 + k;
+    const uint8_t* __restrict__ S = src + (size_t)(yy < 0 ? 0 : (yy > a.sh - 1 ? a.sh - 1 : yy)) * srow;
+    const int by = a.ibeta[8 * dy + k];
+    int r[3] = {0, 0, 0};
+    if (run) {
+      unsigned w[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w[q] = *reinterpret_cast<const u32u*>(S + xs[0] + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] += (int)((w[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3))) & 0xffu) * ax[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] += S[xs[j] + c] * ax[j];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += r[c] * by;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int o = (v[c] + (1 << 21)) >> 22;
+    D[c] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+  }
+}
+
 // ---- ConvertColor ---------------------------------------------------------------------------------
 struct CvtArgsK {
   const uint8_t* const* src;
@@ -1401,6 +1450,8 @@ ST_EXPORT int st_resize_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
       else if (a.iscale_x == 3) hipLaunchKernelGGL(k_resize_area_int_c3_v4<3>, gr, dim3(256), 0, ctx->stream, a);
       else hipLaunchKernelGGL(k_resize_area_int_c3_v4<4>, gr, dim3(256), 0, ctx->stream, a);
     }
+    else if (a.mode == RS_LANCZOS4 && channels == 3)
+      hipLaunchKernelGGL(k_resize_lanczos4_c3, dim3((out_w + 255) / 256, out_h, nf), dim3(256), 0, ctx->stream, a);
     else if (a.mode == RS_NEAREST && channels == 3)
       hipLaunchKernelGGL(k_resize_nearest_c3_v4, dim3(((out_w + 3) / 4 + 255) / 256, (out_h + RL_ROWS - 1) / RL_ROWS, nf), dim3(256), 0, ctx->stream, a);
     else if (a.mode == RS_CUBIC && channels == 3)
