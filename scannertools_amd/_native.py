@@ -51,7 +51,8 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_BGR5552BGR": 24, "COLOR_BGR5552RGB": 25, "COLOR_BGRA2BGR555": 26, "COLOR_RGBA2BGR555": 27,
                "COLOR_BGR5552BGRA": 28, "COLOR_BGR5552RGBA": 29, "COLOR_GRAY2BGR555": 30, "COLOR_BGR5552GRAY": 31}
 K_HIST, K_GRAY, K_PYR, K_POLYEXP, K_UPDATE_MATRICES, K_BLUR_UPDATE, K_FLOW_HIST, K_DRAW_FLOW, K_BLUR_OP, K_RESIZE, K_CVT_COLOR, K_CPM2_INPUT, K_CPM2_LIMBS, K_CONV, K_CPM2_RESIZE, K_CPM2_NMS, K_COUNT = range(17)
-KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color", "cpm2_input", "cpm2_limbs", "conv"]
+KERNEL_NAMES = ["hist", "gray", "pyr", "polyexp", "update_matrices", "blur_update", "flow_hist", "draw_flow", "blur_op", "resize", "cvt_color", "cpm2_input", "cpm2_limbs", "conv", "cpm2_resize", "cpm2_nms"]
+assert len(KERNEL_NAMES) == K_COUNT
 
 
 class StError(RuntimeError):

@@ -16,9 +16,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <string>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "proto_lite.h"
 #include "scannertools_hip.h"
@@ -69,14 +72,21 @@ struct Blobs {
   std::vector<float> w, b;
 };
 
+// Whole file into memory; false for anything that is not a readable regular file of a plausible size (a directory
+// opens with fopen() and reports LONG_MAX from ftell()).
 inline bool read_file(const std::string& path, std::string* out) {
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+  constexpr long kMaxModelBytes = 1L << 32;  // the COCO body model is 209 MB
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  const long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out->resize(n > 0 ? (size_t)n : 0);
-  const bool ok = n >= 0 && fread(&(*out)[0], 1, out->size(), f) == out->size();
+  bool ok = fseek(f, 0, SEEK_END) == 0;
+  const long n = ok ? ftell(f) : -1;
+  ok = ok && n >= 0 && n <= kMaxModelBytes && fseek(f, 0, SEEK_SET) == 0;
+  if (ok) {
+    out->resize((size_t)n);
+    ok = n == 0 || fread(&(*out)[0], 1, out->size(), f) == out->size();
+  }
   fclose(f);
   return ok;
 }
@@ -98,7 +108,7 @@ inline bool blob_floats(const std::string& blob, std::vector<float>* out) {
   return true;
 }
 
-inline bool read_caffemodel(const std::string& path, std::map<std::string, Blobs>* out, std::string* err) {
+inline bool read_caffemodel_impl(const std::string& path, std::map<std::string, Blobs>* out, std::string* err) {
   std::string buf;
   if (!read_file(path, &buf)) { *err = "cannot read " + path; return false; }
   std::vector<proto_lite::Field> top;
@@ -122,6 +132,21 @@ inline bool read_caffemodel(const std::string& path, std::map<std::string, Blobs
   return true;
 }
 
+// The file is untrusted input and these readers sit behind extern "C" entry points and kernel constructors: nothing
+// may leave them as an exception (std::bad_alloc / std::length_error on a hostile length field would otherwise
+// cross the C ABI and end the host process instead of becoming a validate() error).
+inline bool read_caffemodel(const std::string& path, std::map<std::string, Blobs>* out, std::string* err) {
+  try {
+    return read_caffemodel_impl(path, out, err);
+  } catch (const std::exception& e) {
+    *err = "cannot parse " + path + ": " + e.what();
+  } catch (...) {
+    *err = "cannot parse " + path;
+  }
+  out->clear();
+  return false;
+}
+
 inline std::vector<LayerSpec> all_layers() {
   std::vector<LayerSpec> all = trunk_layers();
   for (int st = 1; st <= 6; ++st)
@@ -132,7 +157,7 @@ inline std::vector<LayerSpec> all_layers() {
 
 // Does the file hold weights of the right sizes for every layer of the architecture?  (No GPU involved: what
 // CPM2's validate() reports for a wrong or damaged model file, and a check a deployment can run up front.)
-inline bool check_caffemodel(const std::string& path, int* matched, std::string* err) {
+inline bool check_caffemodel(const std::string& path, int* matched, std::string* err) try {
   std::map<std::string, Blobs> blobs;
   if (matched) *matched = 0;
   if (!read_caffemodel(path, &blobs, err)) return false;
@@ -146,6 +171,9 @@ inline bool check_caffemodel(const std::string& path, int* matched, std::string*
     if (matched) ++*matched;
   }
   return true;
+} catch (const std::exception& e) {
+  *err = "cannot check " + path + ": " + e.what();
+  return false;
 }
 
 // ---- the network on one GPU ---------------------------------------------------------------------------------
@@ -154,7 +182,7 @@ class Net {
   ~Net() { release(); }
 
   // Loads the weights, packs them as [cout_pad][k][k][cin_pad] and uploads them to the current device.
-  bool load(const std::string& caffemodel, std::string* err) {
+  bool load(const std::string& caffemodel, std::string* err) try {
     std::map<std::string, Blobs> blobs;
     if (!read_caffemodel(caffemodel, &blobs, err)) return false;
     for (auto& l : all_layers()) {
@@ -186,6 +214,9 @@ class Net {
       }
     }
     return true;
+  } catch (const std::exception& e) {
+    *err = "cannot load " + caffemodel + ": " + e.what();
+    return false;
   }
 
   // inputs: n device pointers to planar (3, H, W) float32 frames (CPM2Input's output); H, W multiples of 8.

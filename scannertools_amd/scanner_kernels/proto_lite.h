@@ -38,11 +38,11 @@ inline bool parse(const uint8_t* p, size_t n, std::vector<Field>* out) {
     f.wire = (uint32_t)(key & 7);
     switch (f.wire) {
       case 0: if (!varint(&f.value)) return false; break;
-      case 1: if (i + 8 > n) return false; memcpy(&f.value, p + i, 8); i += 8; break;
-      case 5: { if (i + 4 > n) return false; uint32_t v; memcpy(&v, p + i, 4); f.value = v; i += 4; break; }
+      case 1: if (n - i < 8) return false; memcpy(&f.value, p + i, 8); i += 8; break;
+      case 5: { if (n - i < 4) return false; uint32_t v; memcpy(&v, p + i, 4); f.value = v; i += 4; break; }
       case 2: {
         uint64_t len;
-        if (!varint(&len) || i + len > n) return false;
+        if (!varint(&len) || len > (uint64_t)(n - i)) return false;  // no `i + len`: a 64-bit length must not wrap
         f.bytes.assign((const char*)p + i, (size_t)len);
         i += (size_t)len;
         break;

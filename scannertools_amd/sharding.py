@@ -15,30 +15,86 @@ import sys
 import numpy as np
 
 
-def spawn_ranks(script, argv, n, port=0):
+def spawn_ranks(script, argv, n, port=0, timeout=None, grace=5.0):
     """One process per GPU without an external launcher: start `n` children of `script argv` with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's stdout, return 0
     only if every rank exited 0.  The caller must not have touched the GPU (on this pool a process
     that has initialised HIP must not be replaced, and the children own the devices); this function
-    imports neither torch nor the HIP library."""
+    imports neither torch nor the HIP library.
+
+    All children are watched together: the first non-zero exit (a rank that runs out of memory or finds
+    no device) terminates the others -- they would otherwise sit in the rendezvous or a barrier until
+    torch's own timeout of ten minutes or more -- and so does `timeout` seconds overall (default: the
+    environment's ST_SPAWN_TIMEOUT, else 3600) or a SIGTERM / SIGINT delivered to this process.  Rank 0's
+    stdout is collected by a reader thread while it runs, so a full pipe never blocks it."""
+    import signal
+    import threading
+    import time
+    if timeout is None:
+        timeout = float(os.environ.get("ST_SPAWN_TIMEOUT", "3600"))
     if not port:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(codes):
-        sys.stderr.write("%s: rank exit codes %s\n" % (os.path.basename(script), codes))
-        sys.stderr.write(out0 or "")
+    procs, chunks = [], []
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + grace
+        for p in procs:
+            try:
+                p.wait(max(0.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Stop("signal %d" % signum)
+
+    in_main = threading.current_thread() is threading.main_thread()
+    saved = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)} if in_main else {}
+    reader, why = None, None
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        t_end = time.monotonic() + timeout
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                why = "rank %d exited with code %d" % next((r, c) for r, c in enumerate(codes) if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_end:
+                why = "no result within %.0f s" % timeout
+                break
+            time.sleep(0.05)
+    except _Stop as e:
+        why = str(e)
+    finally:
+        stop_all()
+        for sig, h in saved.items():
+            signal.signal(sig, h)
+    if reader is not None:
+        reader.join(grace)
+    out0 = "".join(c for c in chunks if c)
+    codes = [p.returncode for p in procs]
+    if why or any(codes):
+        sys.stderr.write("%s: %s; rank exit codes %s\n" % (os.path.basename(script), why or "failed", codes))
+        sys.stderr.write(out0)
         return 1
     sys.stdout.write(out0)
     sys.stdout.flush()

@@ -139,6 +139,29 @@ def test_shot_pipeline_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["frames"] == 1200 and line["planted_found"] is True
 
 
+def test_spawn_ranks_fails_fast_and_times_out(tmp_path, capfd):
+    """A rank that dies at once takes the others down with it (they would otherwise wait in the rendezvous for torch's
+    own timeout); a job that never finishes ends at the overall timeout; rank 0's output is relayed only on success."""
+    import time
+    from scannertools_amd.sharding import spawn_ranks
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nr = int(os.environ['RANK'])\nmode = sys.argv[1]\n"
+                      "print('hello from', r, flush=True)\n"
+                      "if mode == 'die' and r == 1: sys.exit(7)\n"
+                      "if mode != 'ok': time.sleep(60)\n")
+    t0 = time.monotonic()
+    assert spawn_ranks(str(script), ["die"], 3) == 1
+    assert time.monotonic() - t0 < 20
+    out, err = capfd.readouterr()
+    assert "rank 1 exited with code 7" in err and "hello from 0" not in out
+    t0 = time.monotonic()
+    assert spawn_ranks(str(script), ["hang"], 2, timeout=1.0, grace=2.0) == 1
+    assert time.monotonic() - t0 < 20
+    assert "no result within" in capfd.readouterr().err
+    assert spawn_ranks(str(script), ["ok"], 2) == 0
+    assert "hello from 0" in capfd.readouterr().out
+
+
 # ---- C ABI --------------------------------------------------------------------------------------
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "scannertools_hip.h")).read()
@@ -305,12 +328,15 @@ err = ctypes.create_string_buffer(256)
 layer = _proto.message(100, _proto.message(1, b"conv1_1") + _proto.message(7, _proto.message(5, np.zeros(64 * 27, "<f4").tobytes())) +
                        _proto.message(7, _proto.message(5, np.zeros(64, "<f4").tobytes())))
 rng = np.random.default_rng(1)
-for blob in (layer, layer[:len(layer) // 2], layer[:7], b"", rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(), layer * 3 + b"\xff"):
+overflow = b"\xa2\x06" + b"\xff" * 9 + b"\x01" + b"\x00"  # field 100, a length of 2**64 - 1: `i + len` wraps
+for blob in (layer, layer[:len(layer) // 2], layer[:7], b"", rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(), layer * 3 + b"\xff",
+             overflow, layer + overflow, b"\x09\x00", b"\x0d\x00\x00"):
     with tempfile.NamedTemporaryFile(delete=False) as fh:
         fh.write(blob)
     assert L.scannertools_caffe_check_model(fh.name.encode(), err, 256) == -1 and err.value
     os.unlink(fh.name)
 assert L.scannertools_caffe_check_model(None, err, 256) == -1
+assert L.scannertools_caffe_check_model(tempfile.gettempdir().encode(), err, 256) == -1 and b"cannot read" in err.value  # a directory
 print("sanitized run ok")
 ''' % (ROOT, str(lib), str(lib))
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")

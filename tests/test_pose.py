@@ -280,6 +280,12 @@ def test_op_library_checks_a_model_file(tmp_path):
         pose_net.check_caffemodel(junk)
     with pytest.raises(ValueError, match="cannot read"):
         pose_net.check_caffemodel(tmp_path / "absent.caffemodel")
+    with pytest.raises(ValueError, match="cannot read"):
+        pose_net.check_caffemodel(tmp_path)  # a directory: fopen() succeeds on it
+    hostile = tmp_path / "hostile.caffemodel"
+    hostile.write_bytes(b"\xa2\x06" + b"\xff" * 9 + b"\x01\x00")  # length-delimited field with a length of 2**64 - 1
+    with pytest.raises(ValueError, match="NetParameter"):
+        pose_net.check_caffemodel(hostile)
 
 
 @pytest.mark.gpu
