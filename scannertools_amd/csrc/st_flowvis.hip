@@ -26,7 +26,7 @@ struct FlowSrc {
   const float* base;         // strided stream
   size_t stride;             // bytes
   __device__ const float* frame(int i) const {
-    return ptrs ? ptrs[i] : reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)i * stride);
+    return ptrs ? st_gl(ptrs[i]) : reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)i * stride);
   }
 };
 
@@ -178,9 +178,9 @@ __global__ __launch_bounds__(kT) void k_draw_flow4(DrawArgs a) {
   if (x4 * 4 >= a.w) return;
   const int nan = a.stats[2 * frame + 1];
   const float m = nan ? NAN : key_float(a.stats[2 * frame]);
-  const uint8_t* fr = a.frames[frame] + ((size_t)y * a.w + (size_t)x4 * 4) * 3;
+  const uint8_t* fr = st_gl(a.frames[frame]) + ((size_t)y * a.w + (size_t)x4 * 4) * 3;
   const float* fl = a.flows.frame(frame) + ((size_t)y * a.w + (size_t)x4 * 4) * 2;
-  uint8_t* o = a.outs[frame] + (size_t)y * a.w * 6 + (size_t)x4 * 12;
+  uint8_t* o = st_gl(a.outs[frame]) + (size_t)y * a.w * 6 + (size_t)x4 * 12;
   const uint32_t* fr32 = reinterpret_cast<const uint32_t*>(fr);
   const uint32_t c0 = fr32[0], c1 = fr32[1], c2 = fr32[2];
   const float4 f0 = reinterpret_cast<const float4*>(fl)[0], f1 = reinterpret_cast<const float4*>(fl)[1];
@@ -201,9 +201,9 @@ __global__ __launch_bounds__(kT) void k_draw_flow1(DrawArgs a) {
   if (x >= a.w) return;
   const int nan = a.stats[2 * frame + 1];
   const float m = nan ? NAN : key_float(a.stats[2 * frame]);
-  const uint8_t* fr = a.frames[frame] + ((size_t)y * a.w + x) * 3;
+  const uint8_t* fr = st_gl(a.frames[frame]) + ((size_t)y * a.w + x) * 3;
   const float* fl = a.flows.frame(frame) + ((size_t)y * a.w + x) * 2;
-  uint8_t* o = a.outs[frame] + (size_t)y * a.w * 6;
+  uint8_t* o = st_gl(a.outs[frame]) + (size_t)y * a.w * 6;
   const uint8_t b = (uint8_t)vis_byte(fl[0], fl[1], m);
   o[x * 3 + 0] = fr[0]; o[x * 3 + 1] = fr[1]; o[x * 3 + 2] = fr[2];
   uint8_t* r = o + (size_t)a.w * 3 + (size_t)x * 3;

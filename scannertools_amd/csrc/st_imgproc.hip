@@ -54,8 +54,8 @@ __global__ __launch_bounds__(BL_T) void k_box_blur_u8c3(BlurArgsK a) {
   unsigned* stage = smem;                                // [nrows][row_dwords]
   const int nb = 3 * a.w;                                // bytes per frame row
   const long long total = (long long)nb * a.h;
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ dst = a.dst[blockIdx.z];
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ dst = st_gl(a.dst[blockIdx.z]);
   const int B0 = blockIdx.x * BL_TILEB;                  // first byte (within a row) of the tile
   const int Y0 = blockIdx.y * BL_ROWS;                   // first output row of the tile
 
@@ -273,8 +273,8 @@ __device__ __forceinline__ AreaCell rs_area_cell(int dx, int ssize, double scale
 __global__ __launch_bounds__(256) void k_resize_u8(ResizeArgsK a) {
   const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
   if (dx >= a.dw) return;
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ D = a.dst[blockIdx.z] + ((size_t)dy * a.dw + dx) * a.cn;
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ D = st_gl(a.dst[blockIdx.z]) + ((size_t)dy * a.dw + dx) * a.cn;
   const int cn = a.cn;
   const size_t srow = (size_t)a.sw * cn;
   if (a.mode == RS_COPY) {
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void k_resize_linear_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x;  // group of 4 output columns
   if (4 * g >= a.dw) return;
   const int npx = min(4, a.dw - 4 * g);          // the last group of a row may be partial
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(a.dst[blockIdx.z]);
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(st_gl(a.dst[blockIdx.z]));
   const size_t srow = (size_t)a.sw * 3;
   int sxo[4], a0[4], a1[4];
   bool two[4], wide[4];
@@ -518,8 +518,8 @@ __global__ __launch_bounds__(256) void k_resize_area2_c3_v4(ResizeArgsK a) {
   typedef unsigned u32u __attribute__((aligned(1)));
   const int g = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
   if (4 * g >= a.dw) return;
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* ob = a.dst[blockIdx.z] + ((size_t)dy * a.dw + 4 * g) * 3;
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* ob = st_gl(a.dst[blockIdx.z]) + ((size_t)dy * a.dw + 4 * g) * 3;
   const size_t srow = (size_t)a.sw * 3;
   const uint8_t* S0 = src + (size_t)(2 * dy) * srow + (size_t)(8 * g) * 3;
   const uint8_t* S1 = S0 + srow;
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256) void k_resize_nearest_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (4 * g >= a.dw) return;
   const int npx = min(4, a.dw - 4 * g);
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ dstb = st_gl(a.dst[blockIdx.z]);
   const size_t srow = (size_t)a.sw * 3;
   int sxo[4];
   bool wide[4];
@@ -599,8 +599,8 @@ __global__ __launch_bounds__(256) void k_resize_cubic_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (4 * g >= a.dw) return;
   const int npx = min(4, a.dw - 4 * g);
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ dstb = st_gl(a.dst[blockIdx.z]);
   const size_t srow = (size_t)a.sw * 3;
   int ax[4][4], xs[4][4];
   bool run[4];  // the four tap columns are consecutive and 12 bytes from the first stay inside the row
@@ -690,8 +690,8 @@ __global__ __launch_bounds__(256) void k_resize_area_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (4 * g >= a.dw) return;
   const int npx = min(4, a.dw - 4 * g);
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ dstb = a.dst[blockIdx.z];
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ dstb = st_gl(a.dst[blockIdx.z]);
   const size_t srow = (size_t)a.sw * 3;
   int first[4];
   float wx[4][AR_SPAN];
@@ -769,8 +769,8 @@ __global__ __launch_bounds__(256) void k_resize_area_int_c3_v4(ResizeArgsK a) {
   const int g = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
   if (4 * g >= a.dw) return;
   const int npx = min(4, a.dw - 4 * g);
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* ob = a.dst[blockIdx.z] + ((size_t)dy * a.dw + 4 * g) * 3;
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* ob = st_gl(a.dst[blockIdx.z]) + ((size_t)dy * a.dw + 4 * g) * 3;
   const size_t srow = (size_t)a.sw * 3;
   constexpr int isx = ISX;                          // 2 .. 4 columns per cell
   const size_t base = (size_t)(4 * g) * isx * 3;    // first source byte of the run in a row
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(256) void k_resize_lanczos4_c3(ResizeArgsK a) {
   typedef unsigned u32u __attribute__((aligned(1)));
   const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
   if (dx >= a.dw) return;
-  const uint8_t* __restrict__ src = a.src[blockIdx.z];
-  uint8_t* __restrict__ D = a.dst[blockIdx.z] + ((size_t)dy * a.dw + dx) * 3;
+  const uint8_t* __restrict__ src = st_gl(a.src[blockIdx.z]);
+  uint8_t* __restrict__ D = st_gl(a.dst[blockIdx.z]) + ((size_t)dy * a.dw + dx) * 3;
   const size_t srow = (size_t)a.sw * 3;
   const int sx = a.xofs[dx], sy = a.yofs[dy];
   int ax[8], xs[8];
@@ -1042,8 +1042,8 @@ __device__ __forceinline__ void cvt_tables(const CvtArgsK& a, int* sdiv, int* hd
 __global__ __launch_bounds__(256) void k_cvt_color_u8(CvtArgsK a) {
   __shared__ int sdiv[256], hdiv[256];
   cvt_tables(a, sdiv, hdiv);
-  const uint8_t* __restrict__ src = a.src[blockIdx.y];
-  uint8_t* __restrict__ dst = a.dst[blockIdx.y];
+  const uint8_t* __restrict__ src = st_gl(st_gl(a.src[blockIdx.y]));
+  uint8_t* __restrict__ dst = st_gl(st_gl(a.dst[blockIdx.y]));
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.npix; i += (long long)gridDim.x * 256) {
     int s[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1063,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_cvt_color_u8_vec(CvtArgsK a) {
   __shared__ int sdiv[256], hdiv[256];
   cvt_tables(a, sdiv, hdiv);
   constexpr int NI = SCN * PX / 4, NO = DCN * PX / 4;  // dwords in / out per thread
-  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(a.src[blockIdx.y]);
-  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(a.dst[blockIdx.y]);
+  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(st_gl(a.src[blockIdx.y]));
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(st_gl(a.dst[blockIdx.y]));
   const long long groups = a.npix / PX;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long long)gridDim.x * 256) {
     unsigned in[NI], out[NO];
@@ -1162,8 +1162,8 @@ __device__ __forceinline__ void yuv_px(int Y, int u, int v, int d[3]) {  // d = 
 
 // byte-wise front-end: any even size, any alignment
 __global__ __launch_bounds__(256) void k_cvt_yuv_u8(YuvArgsK a) {
-  const uint8_t* __restrict__ src = a.src[blockIdx.y];
-  uint8_t* __restrict__ dst = a.dst[blockIdx.y];
+  const uint8_t* __restrict__ src = st_gl(st_gl(a.src[blockIdx.y]));
+  uint8_t* __restrict__ dst = st_gl(st_gl(a.dst[blockIdx.y]));
   const long long npix = (long long)a.H * a.W;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
     const int y = (int)(i / a.W), x = (int)(i - (long long)y * a.W);
@@ -1213,8 +1213,8 @@ __device__ __forceinline__ int yuv_byte(const unsigned* w, int k) { return (int)
 
 template <int DCN, int PX>
 __global__ __launch_bounds__(256) void k_cvt_yuv_u8_vec(YuvArgsK a) {
-  const uint8_t* __restrict__ src = a.src[blockIdx.y];
-  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(a.dst[blockIdx.y]);
+  const uint8_t* __restrict__ src = st_gl(st_gl(a.src[blockIdx.y]));
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(st_gl(a.dst[blockIdx.y]));
   const long long npix = (long long)a.H * a.W, groups = npix / PX;
   const int gw = a.W / PX;  // groups per row
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long long)gridDim.x * 256) {

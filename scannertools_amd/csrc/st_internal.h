@@ -85,4 +85,15 @@ struct st_timed {
   ~st_timed() { if (open) (void)st_time_end(ctx, id); }
 };
 
+// A pointer read from a device-side pointer table (Scanner hands every frame as its own buffer) has no provable
+// address space, so loads and stores through it compile to flat_* instructions: those also count on lgkmcnt (an LDS
+// wait then waits for them too) and take a 64-bit address in VGPRs.  Everything this library is handed lives in
+// global memory; the round trip through address space 1 tells the compiler so (global_* instructions, SGPR base).
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ T* st_gl(T* p) {
+  return (T*)((__attribute__((address_space(1))) T*)(uintptr_t)p);
+}
+#endif
+
 #endif  // ST_INTERNAL_H_
