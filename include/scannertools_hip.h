@@ -264,6 +264,12 @@ int st_cvt_color_u8_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, 
  * Host-only (no context). */
 int st_cpm2_geometry(int h, int w, float scale, int* resize_h, int* resize_w, int* net_h, int* net_w);
 
+/* The float scale for which the rule above resizes a frame of height h to EXACTLY target_h rows: (int)(h * scale)
+ * == target_h.  (float)target_h / h can fall one row short under the truncation -- 368.f / 1080 gives 367 -- which
+ * would add a padded row and shift every normalised y coordinate of the OpenPose op, whose network input height is a
+ * given (op::Wrapper netInputSize = (-1, 368), scannertools_caffe_cpp/openpose_kernel.cpp:99).  Host-only. */
+int st_cpm2_scale_for_height(int h, int target_h, float* scale);
+
 /* CPM2Input: replaces the per-frame body of CPM2InputKernel::execute
  * (cpm2_input_kernel_gpu.cpp:104-140: cvtColor RGB2BGR, resize INTER_CUBIC, copyMakeBorder with 128,
  * convertTo(F32, 1/256, -0.5), split, three plane copies, cudaMemcpy2DAsync) for a whole batch in one

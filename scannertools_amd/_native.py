@@ -112,6 +112,7 @@ SIGNATURES = {
     "st_cvt_color_out_shape": (_i, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "st_cvt_color_u8_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
     "st_cpm2_geometry": (_i, [_i, _i, _c.c_float, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    "st_cpm2_scale_for_height": (_i, [_i, _i, _c.POINTER(_c.c_float)]),
     "st_cpm2_input_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _c.c_float, _c.POINTER(_vp)]),
     "st_cpm2_limb_scores": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _i, _i, _c.c_float, _i, _vp]),
     "st_conv2d_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),

@@ -2022,6 +2022,23 @@ int rows_per_segment(st_ctx* ctx, int h, int strips, int batch, int halo) {
   return rows;
 }
 
+// Segment height of the polynomial expansion (a scheduling choice: the vertical pass is a direct 11-tap sum, so a
+// pixel's value does not depend on where its segment starts).  Large launches take whole-height segments; a launch
+// of a few frames is latency-bound (a workgroup marches its rows one barrier per 4 rows), so it is cut into many
+// short segments even though each re-reads 2N rows of context.
+int polyexp_rows(st_ctx* ctx, int h, int strips, int n, int poly_n) {
+  static const int env_min = getenv("ST_PE_MINROWS") ? atoi(getenv("ST_PE_MINROWS")) : 0;
+  const int min_rows = env_min > 0 ? (env_min + PE_RB - 1) / PE_RB * PE_RB : 12;  // measured at 1-8 pairs of 1080p: 12 rows +4 % over the former 44, nothing below
+  const long long target = (long long)ctx->num_cus * 8, per = (long long)strips * n;
+  long long segs = (target + per - 1) / per;
+  if (segs < 1) segs = 1;
+  int rows = (int)((h + segs - 1) / segs);
+  rows = (rows + PE_RB - 1) / PE_RB * PE_RB;
+  if (rows < min_rows) rows = min_rows;
+  if (rows > h) rows = h;
+  return rows;
+}
+
 int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int h, int w, int bits, uint8_t* gray,
                 bool frames_aligned4) {
   GrayArgs a;
@@ -2149,7 +2166,8 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   rows = (rows + 7) / 8 * 8;
   // (a few frames only: down to 16-row segments -- twice the rows are read, but the launch is
   // latency-bound and needs the workgroups)
-  const int min_rows = (long long)strips * n * ((h + 63) / 64) >= 2LL * ctx->num_cus ? 64 : 16;
+  static const int env_min = getenv("ST_PYR_MINROWS") ? atoi(getenv("ST_PYR_MINROWS")) : 0;
+  const int min_rows = (long long)strips * n * ((h + 63) / 64) >= 2LL * ctx->num_cus ? 64 : (env_min > 0 ? (env_min + 7) / 8 * 8 : 16);
   if (rows < min_rows) rows = h < min_rows ? h : min_rows;
   a.rows_per_seg = rows;
   st_timed t(ctx, ST_K_PYR);
@@ -2164,7 +2182,7 @@ int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_
   a.img = img; a.R = R; a.h = h; a.w = w;
   poly_prepare(poly_n, poly_sigma, &a.c);
   const int strips = (w + PE_OUT - 1) / PE_OUT;
-  a.rows_per_seg = rows_per_segment(ctx, h, strips, n, 2 * poly_n + 1);
+  a.rows_per_seg = polyexp_rows(ctx, h, strips, n, poly_n);
   dim3 grid(strips, (h + a.rows_per_seg - 1) / a.rows_per_seg, n);
   st_timed t(ctx, ST_K_POLYEXP);
   if (poly_n == 5) hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), 0, ctx->stream, a);

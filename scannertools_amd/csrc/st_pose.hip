@@ -379,6 +379,16 @@ ST_EXPORT int st_cpm2_geometry(int h, int w, float scale, int* resize_h, int* re
   return ST_OK;
 }
 
+ST_EXPORT int st_cpm2_scale_for_height(int h, int target_h, float* scale) {
+  if (h <= 0 || target_h <= 0 || !scale) return ST_ERR_INVALID;
+  float s = (float)target_h / (float)h;
+  for (int i = 0; i < 8 && (int)(h * s) < target_h; ++i) s = nextafterf(s, INFINITY);
+  for (int i = 0; i < 8 && (int)(h * s) > target_h; ++i) s = nextafterf(s, 0.f);
+  if ((int)(h * s) != target_h) return ST_ERR_INVALID;
+  *scale = s;
+  return ST_OK;
+}
+
 ST_EXPORT int st_cpm2_input_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int h, int w, float scale,
                                   float* const* out_dev) {
   ST_TRY(st_enter(ctx));

@@ -529,6 +529,16 @@ def cpm2_geometry(h, w, scale):
     return tuple(x.value for x in v)
 
 
+def cpm2_scale_for_height(h, target_h):
+    """The float scale at which `cpm2_geometry` resizes a frame of height h to exactly target_h rows (what the OpenPose
+    op uses for its fixed network input height: 368.f / 1080 truncates to 367)."""
+    v = ctypes.c_float()
+    st = _native.lib().st_cpm2_scale_for_height(int(h), int(target_h), ctypes.byref(v))
+    if st != 0:
+        raise StError(st, "st_cpm2_scale_for_height(%d, %d)" % (h, target_h))
+    return float(v.value)
+
+
 def fb_levels(h, w, params=None):
     prm = params if params is not None else default_params()
     return _native.lib().st_fb_levels(h, w, ctypes.byref(prm))

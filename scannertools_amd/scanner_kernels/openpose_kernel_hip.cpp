@@ -110,8 +110,11 @@ class OpenPoseKernelHIPImpl : public BatchedKernel, public VideoKernel {
     geom_.clear();
     for (int i = 0; i < scales_; ++i) {
       Geom g;
-      g.scale = (float)kNetHeight / (float)H * (1.f - (float)i * args_.pose_scale_gap);
-      const int st = st_cpm2_geometry(H, W, g.scale, &g.rh, &g.rw, &g.nh, &g.nw);
+      // the network input height is a given (368 rows at scale 0, openpose_kernel.cpp:99; 368 (1 - i gap) rounded at
+      // scale i): the transform's float scale is chosen so that its truncating size rule lands on exactly that height
+      const int target = (int)lroundf((float)kNetHeight * (1.f - (float)i * args_.pose_scale_gap));
+      int st = st_cpm2_scale_for_height(H, target, &g.scale);
+      if (st == ST_OK) st = st_cpm2_geometry(H, W, g.scale, &g.rh, &g.rw, &g.nh, &g.nw);
       LOG_IF(FATAL, st != ST_OK || g.rh < 8 || g.rw < 8) << "OpenPose: a " << W << "x" << H << " frame at scale " << g.scale
                                                             << " leaves no network input";
       geom_.push_back(g);

@@ -17,6 +17,21 @@ from util import random_frames, synthetic_pose_maps
 
 
 # ------------------------------------------------------------------------------------------- CPU
+def test_cpm2_scale_for_a_given_height():
+    """368.f / 1080 resizes to 367 rows under the truncating size rule; the OpenPose op asks for the scale that lands
+    on exactly its network input height (host-only entry point, no GPU)."""
+    from scannertools_amd.hip import cpm2_geometry, cpm2_scale_for_height
+    for h in (1080, 2160, 720, 480, 96, 1, 367, 369, 4320):
+        for target in (368, 313, 184, 8):
+            s = cpm2_scale_for_height(h, target)
+            assert cpm2_geometry(h, 16 * h, s)[0] == target
+            assert abs(s - target / h) <= 4e-7 * max(1.0, target / h)
+    naive = float(np.float32(368) / np.float32(1080))
+    assert cpm2_geometry(1080, 1920, naive)[0] in (367, 368) and cpm2_geometry(1080, 1920, cpm2_scale_for_height(1080, 368))[0] == 368
+    with pytest.raises(Exception):
+        cpm2_scale_for_height(0, 368)
+
+
 def test_cpm2_geometry_rules():
     # cpm2_input_kernel_gpu.cpp:48-55: truncating float product, padding up to a multiple of 8
     assert oracle.cpm2_geometry(1080, 1920, 368 / 1080.) == (368, 654, 368, 656)

@@ -231,7 +231,7 @@ def test_openpose_op(hip_ctx, model_dir, scales, gap, device):
     import oracle
     from scannertools_amd import pose_detection
     from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
-    from scannertools_amd.hip import cpm2_geometry
+    from scannertools_amd.hip import cpm2_geometry, cpm2_scale_for_height
     from util import random_frames
     root, _, net = model_dir
     frames = random_frames(17, 3, 96, 160)
@@ -249,8 +249,10 @@ def test_openpose_op(hip_ctx, model_dir, scales, gap, device):
     fr = torch.from_numpy(frames).cuda()
     geo, raws = [], []
     for i in range(scales):
-        s = float(np.float32(368) / np.float32(H) * (np.float32(1) - np.float32(i) * np.float32(gap)))
+        target = int(np.floor(np.float32(368) * (np.float32(1) - np.float32(i) * np.float32(gap)) + np.float32(0.5)))
+        s = cpm2_scale_for_height(H, target)
         geo.append(cpm2_geometry(H, W, s))
+        assert geo[-1][0] == target
         raws.append(net.forward_raw(hip_ctx.cpm2_input(fr, s)))
     (rh0, rw0, nh0, nw0) = geo[0]
     f32 = np.float32
