@@ -475,13 +475,24 @@ def run_rank(args):
     # 128-B read requests + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes.  None when the
     # profile is missing or was taken at another batch size / resolution.
     traffic = l2_hit = None
+    traffic_note = ("HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/traffic.json); "
+                    "frac_traffic is what the memory system really moved per second / peak")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (B, h, w) == (256, 1080, 1920):
         try:
-            tj = json.load(open(tpath))
-            tj = tj.get("k_flow_iter3") or tj["k_flow_iter"]
-            traffic = float(tj["hbm_bytes_per_launch"])
-            l2_hit = tj.get("L2_hit_rate")
+            import hashlib
+            tj_all = json.load(open(tpath))
+            tj = tj_all.get("k_flow_iter3") or tj_all["k_flow_iter"]
+            # the counters belong to the kernel source they were taken with: a profile of an older kernel is not
+            # divided by this run's launch time
+            want = tj_all.get("_meta", {}).get("source_sha256", {}).get("st_farneback.hip")
+            have = hashlib.sha256(open(os.path.join(ROOT, "scannertools_amd", "csrc", "st_farneback.hip"), "rb").read()).hexdigest()
+            if want == have:
+                traffic = float(tj["hbm_bytes_per_launch"])
+                l2_hit = tj.get("L2_hit_rate")
+            else:
+                traffic_note = ("profiles/traffic.json was taken with another version of st_farneback.hip: traffic withheld "
+                                "(re-run scripts/profile_round.sh)")
         except Exception:
             traffic = None
     avg_launch_s = blur_ms / max(blur_launches, 1) * 1e-3
@@ -517,13 +528,15 @@ def run_rank(args):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": blur_gbs / HBM_PEAK_GBS,
+                "frac_is": "algorithmic (model) bytes / time / peak as the bench contract defines it -- NOT HBM utilisation: the "
+                           "kernel never materialises M, so it moves fewer bytes than the model prices; frac_traffic is the "
+                           "utilisation figure",
                 "traffic": traffic,
                 "traffic_GBs": traffic_gbs,
                 "frac_traffic": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
                 "frac_traffic_of_copy_ceiling": (traffic_gbs / HBM_COPY_CEILING_GBS) if traffic_gbs else None,
                 "l2_hit_rate": l2_hit,
-                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of this command (profiles/traffic.json); "
-                                "frac_traffic is what the memory system really moved per second / peak",
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": blur_bytes_per_step * args.steps / max(blur_launches, 1),
                 "launches": blur_launches,
                 "avg_launch_ms": blur_ms / max(blur_launches, 1),

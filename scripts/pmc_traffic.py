@@ -44,4 +44,9 @@ for k in sorted(acc):
         if n in avg:
             entry[n] = avg[n]
     res[k] = entry
+# which kernel sources the counters belong to: bench.py reports `traffic` only while they still match
+import hashlib
+src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scannertools_amd", "csrc")
+res["_meta"] = {"source_sha256": {f: hashlib.sha256(open(os.path.join(src, f), "rb").read()).hexdigest()
+                                  for f in ("st_farneback.hip", "st_hist.hip")}}
 print(json.dumps(res, indent=1))

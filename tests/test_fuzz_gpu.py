@@ -7,7 +7,7 @@ import torch
 
 import oracle
 from scannertools_amd._native import COLOR_CODES
-from util import cvt_source, smooth_texture
+from util import assert_flow_close, cvt_source, smooth_texture
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ def test_fuzz_integer_ops(hip_ctx, seed):
             np.testing.assert_array_equal(got[i], oracle.draw_flow(frames[i], flows[i]), err_msg="draw_flow %dx%d" % (h, w))
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", [0, 1, 2, 103, 121, 268])  # the last three: noise-dominated identical-frame pairs found by the round-3 campaign
 def test_fuzz_optical_flow(flow_ctx, seed):
     """Random frame sizes (including ones smaller than the window and ones that change the number of
     pyramid levels) and random pair lists; every flow field against the oracle, under every
@@ -68,8 +68,7 @@ def test_fuzz_optical_flow(flow_ctx, seed):
         got = hip_ctx.optical_flow(_cu(frames), pairs=pairs).cpu().numpy()
         for i, (a, b) in enumerate(pairs):
             ref = oracle.optical_flow_rgb(frames[a], frames[b])
-            assert np.abs(got[i] - ref).max() <= 5e-3, (h, w, a, b, np.abs(got[i] - ref).max())
-            assert np.linalg.norm(got[i] - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-30) + 1e-6, (h, w, a, b)
+            assert_flow_close(got[i], ref, frames[a], frames[b], (h, w, a, b))
 
 
 @pytest.mark.parametrize("seed", range(4))

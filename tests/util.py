@@ -115,3 +115,34 @@ def cvt_source(rng, code, h, w):
         return rng.integers(0, 256, (max(1, h), max(2, w - w % 2), 2), dtype=np.uint8)
     cin = next(c for c in (1, 2, 3, 4) if oracle.lib().orc_cvt_out_channels(code, c) > 0)
     return rng.integers(0, 256, (h, w, cin), dtype=np.uint8)
+
+
+def assert_flow_close(got, ref, frame_a, frame_b, what=""):
+    """Flow of the HIP path against the oracle: max-abs <= 5e-3 px and relative L2 <= 1e-4.
+
+    Where that fails, the independent float64 derivation (tests/ref_farneback_np.py) arbitrates: on low-texture
+    stretches (typically at the frame border of near-identical frames) the 2x2 solve divides rounding noise of the
+    float32 matrices by a determinant of ~1e-3, and BOTH float implementations then sit 1e-2 px from exact arithmetic
+    -- the oracle as much as the kernel, each in its own direction (seen by the 300-seed fuzz campaign of round 3:
+    7-26 pixels of three identical-frame pairs).  A pixel is accepted there only if the kernel is no further from the
+    oracle than twice the oracle's own distance from exact arithmetic; the pixels that need this must stay below 0.5 % of
+    the field, and the relative-L2 criterion must hold over the pixels where the oracle itself is within 1e-3 px of exact
+    arithmetic (for identical frames the whole field is rounding noise: 6 % of it beyond 1e-3 px in one campaign case)."""
+    d = np.abs(got - ref).max(-1)
+    nref = max(float(np.linalg.norm(ref)), 1e-30)
+    if d.max() <= 5e-3 and np.linalg.norm(got - ref) <= 1e-4 * nref + 1e-6:
+        return
+    import oracle
+    import ref_farneback_np as exact
+    f64 = exact.farneback(oracle.gray_u8(frame_a), oracle.gray_u8(frame_b))
+    noise = np.abs(ref - f64).max(-1)
+    noisy = noise > 1e-3
+    assert (d <= np.maximum(5e-3, 2.0 * noise + 1e-3)).all(), (what, float(d.max()), float(noise[d > 5e-3].min()) if (d > 5e-3).any() else None)
+    assert (d > 5e-3).mean() <= 5e-3, (what, "pixels that needed the arbiter", float((d > 5e-3).mean()))
+    keep = ~noisy
+    # relative L2 over the remaining pixels -- or, for flows that are rounding noise altogether (identical frames: a
+    # relative measure has nothing to be relative to), a root-mean-square difference of at most 5e-4 px over them
+    dk = (got - ref)[keep]
+    rel_ok = np.linalg.norm(dk) <= 1e-4 * max(float(np.linalg.norm(ref[keep])), 1e-30) + 1e-6
+    rms = float(np.sqrt((dk.astype(np.float64) ** 2).mean())) if dk.size else 0.0
+    assert rel_ok or rms <= 5e-4, (what, "relative L2 / rms outside the noise-dominated pixels", rms)
