@@ -11,17 +11,23 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 # the headline region only (the CPU baseline and the extra records run other sizes / no kernels)
 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --no-cpu-baseline --no-extras > $out/trace.log 2>&1
 pass() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/$name.log 2>&1
+  # only this library's kernels are instrumented (the input generator's thousands of torch launches would otherwise
+  # dominate the run time of a counter pass)
+  rocprofv3 --kernel-include-regex "k_(flow_iter|polyexp|pyr|gray|hist)" --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/$name.log 2>&1
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 pass wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
 pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS
+pass tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+pass ta TA_TA_BUSY_sum GRBM_GUI_ACTIVE
+pass valu SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SALU
 # summarise on the box (the raw rocprofv3 output exceeds what gpurun copies back) and drop the raw data
 mkdir -p $out/summary
 python3 scripts/rocpd_stats.py $out/trace/trace_results.db > $out/summary/kernel_stats.txt
 python3 scripts/pmc_traffic.py $out > $out/summary/pmc_traffic.json
 cp $out/bench.json $out/summary/bench.json
-rm -rf $out/trace $out/fetch $out/write $out/rdreq $out/wrreq $out/sq
+python3 scripts/pmc_summary.py $out > $out/summary/pmc_by_launch.txt
+rm -rf $out/trace $out/fetch $out/write $out/rdreq $out/wrreq $out/sq $out/tcp $out/ta $out/valu
 cat $out/bench.json
