@@ -1647,6 +1647,13 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   const int y1 = min(h, y0 + a.rows_per_seg);
   const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
   const int vpos = f3_pos(tid);
+  // paired flow stores (even widths): writer k = tid - HALO stores pixels (2 j, 2 j + 1) of rows 4 hh .. 4 hh + 3 of a group,
+  // j = k mod (OUT / 2), hh = k / (OUT / 2)
+  typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
+  const int pair_k = tid - B2_HALO, pair_j = pair_k % (B2_OUT / 2);
+  const int pair_r0 = (pair_k / (B2_OUT / 2)) * (F3_GROUP / 2);
+  const int pair_x = (int)bx * B2_OUT + 2 * pair_j;
+  const int pair_pos = f3_pos(B2_HALO + 2 * pair_j);
 
   const float* __restrict__ R0;
   const float* __restrict__ R1;
@@ -1746,14 +1753,30 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
       const int yg = ybase + g * F3_GROUP;
       if (yg >= y1) break;  // uniform over the workgroup
       // ---- flow rows of the PREVIOUS group go out ahead of this group's loads
-      if (writer && yg > y0) {
+      if (yg > y0) {
+        if (!(w & 1)) {
+          // even widths: a thread stores TWO adjacent pixels (16 bytes) of four of the eight rows -- half as many
+          // vector-memory instructions as one pixel per thread and row (the texture-address unit is this kernel's
+          // busiest resource, and an instruction costs it the same whatever its width)
+          if (pair_x < w && tid >= B2_HALO && tid < B2_T - B2_HALO) {
 #pragma unroll
-        for (int r = 0; r < F3_GROUP; ++r) {
-          // non-temporal: the next reader is another launch, tens of gigabytes later
-          const float2 fv = Fs[r][vpos];
-          f2v v2;
-          v2.x = fv.x; v2.y = fv.y;
-          __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)));
+            for (int r = 0; r < F3_GROUP / 2; ++r) {
+              const int rr = pair_r0 + r;
+              const float2 fa = Fs[rr][pair_pos], fb = Fs[rr][pair_pos + 1];
+              f4v v4;
+              v4.x = fa.x; v4.y = fa.y; v4.z = fb.x; v4.w = fb.y;
+              // non-temporal: the next reader is another launch, tens of gigabytes later
+              __builtin_nontemporal_store(v4, reinterpret_cast<f4v*>(fout + 2 * (size_t)((yg - F3_GROUP + rr) * w + pair_x)));
+            }
+          }
+        } else if (writer) {
+#pragma unroll
+          for (int r = 0; r < F3_GROUP; ++r) {
+            const float2 fv = Fs[r][vpos];
+            f2v v2;
+            v2.x = fv.x; v2.y = fv.y;
+            __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)));
+          }
         }
       }
       // ---- phase 1: GROUP / RB batches back to back
