@@ -292,6 +292,43 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                 "resize_maps_GBs": nb5 * 57 * nh5 * nw5 * 4 / (kms5[_native.K_CPM2_RESIZE][1] / 2 * 1e-3) / 1e9,
                 "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
                            "max_abs": float((got5 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max())}}
+            # the same chain with the opt-in split-bf16 arithmetic (bf16x3: float32-grade accuracy on the bf16 matrix
+            # pipe, six bf16 MFMAs per float32-equivalent product block); never the config's headline figure
+            try:
+                net3 = pose_net.PoseNet(ctx, seed=1, math="bf16x3")
+
+                def pose_step3():
+                    maps3, joints3 = net3.detect(ctx.cpm2_input(fr5, sc5))
+                    return ctx.cpm2_limb_scores(maps3, joints3)
+
+                pose_step3()
+                sync()
+                ctx.timing_enable([_native.K_CONV])
+                ctx.timing_reset()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    pose_step3()
+                sync()
+                dt3 = (time.perf_counter() - t0) / 2
+                nl3, ms3 = ctx.timing_read(_native.K_CONV)
+                ctx.timing_enable([])
+                got3 = net3.forward(xs5.to(device)).permute(0, 3, 1, 2).cpu()
+                tf3 = nb5 * fl5 / (ms3 / 2 * 1e-3) / 1e12
+                out["config5_pose_conv_stack"]["bf16x3"] = {
+                    "what": "the same chain with every convolution's operands split into three bf16 terms (opt-in: PoseNet(math='bf16x3') / "
+                            "SCANNERTOOLS_POSE_MATH=bf16x3); useful flops counted once, the matrix pipe executes six bf16 products per "
+                            "float32-equivalent one",
+                    "dtype": "bf16x3 (v_mfma_f32_32x32x16_bf16 on hi/mid/lo terms, f32 accumulation)",
+                    "frames_per_s": nb5 / dt3, "ms_per_batch": dt3 * 1e3,
+                    "roofline": {"kernel": "k_conv_nhwc_bf16x3", "bound": "mfma", "achieved_useful": tf3, "achieved_executed": 6 * tf3,
+                                 "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * tf3 / 2500.0, "frac_of_f32_matrix_peak": tf3 / 157.3,
+                                 "kernel_ms_per_batch": ms3 / 2},
+                    "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
+                               "max_abs": float((got3 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max()),
+                               "max_abs_vs_f32_kernels": float((got3 - got5).abs().max())}}
+                del net3
+            except Exception as e:  # auxiliary record
+                out["config5_pose_conv_stack"]["bf16x3"] = {"error": repr(e)}
             # the same work through the reference's user-facing op: sc.ops.OpenPose on device frames (kernel class: transform,
             # network, merge, nms, limb scores, assembly of people on the host, element formatting), one scale, batch 32;
             # the model file holds the same random weights

@@ -304,6 +304,17 @@ int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int
                        const float* w_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
                        float* y_dev, int y_stride, int y_offset);
 /* 2x2 max pooling, stride 2: (n, h, w, c) -> (n, h/2, w/2, c), c a multiple of 4. */
+/* The same convolution on the bf16 matrix pipe at float32-grade accuracy ("bf16x3": every operand split into three
+ * bf16 terms, the six significant products accumulated in float32; 2.67 x the float32 matrix rate on CDNA4, results
+ * within one float32 rounding per product of st_conv2d_nhwc_f32's, not bit-identical to it).  Opt-in replacement for
+ * the same Caffe layers (cpm2_kernel.cpp:8-52).  Activations and outputs as above; w3_dev: the layer's weights
+ * rearranged ONCE by st_conv_pack_weights_bf16x3 from the [cout_pad][kh][kw][cin] float32 tensor
+ * (cout_pad * kh * kw * cin * 6 bytes, 16-byte aligned). */
+int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
+int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                          const void* w3_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
+                          float* y_dev, int y_stride, int y_offset);
+
 int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int c, int x_stride, float* y_dev,
                          int y_stride);
 /* planar (n, c, h, w) -> NHWC (n, h, w, y_stride) with zero pad channels: CPM2Input's frame as the first

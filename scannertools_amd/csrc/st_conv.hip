@@ -190,6 +190,215 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_f32(ConvArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same convolution on the bf16 matrix pipe with float32-grade accuracy ("bf16x3").
+// CDNA4's float32 MFMA rate is 1/16 of its bf16 rate (157 against 2 500 TFLOP/s dense), so the idiomatic way to a
+// float32-accurate contraction on this chip is to split every operand into three bf16 terms, v = hi + mid + lo
+// (round-to-nearest at each step; 3 x 8 mantissa bits represent a float32 exactly), and to accumulate the six
+// products that carry more than 2^-24 of the result -- hi hi, hi mid, mid hi, hi lo, lo hi, mid mid -- in the
+// float32 accumulators of v_mfma_f32_32x32x16_bf16.  Every bf16 x bf16 product is exact in float32; what is dropped
+// (mid lo, lo mid, lo lo) is below 2^-23 of a product, the size of one float32 rounding.  Six matrix instructions of
+// 32 cycles replace eight of 64 (v_mfma_f32_32x32x2_f32 per 16 k): 2.67 x the float32 pipe rate.
+// NOT bit-identical to the float32 kernel (different roundings of the same accuracy): opt-in, the default stays the
+// float32 instruction, and the tests bound both against torch's float32 convolution.
+//
+// Operands: activations stay float32 in memory and are split on their way into LDS (44 VALU instructions per thread
+// and slice, hidden under the matrix pipe); weights are split once (st_conv_pack_weights_bf16x3) into
+// [cout_pad][tap][cin / 16][3 splits][16 channels] bf16, i.e. 96 contiguous bytes per (output channel, K slice).
+// LDS: per split a [128 rows][16 k] bf16 tile, 32-byte rows, the two 16-byte halves of a row swapped on rows
+// 8..15 mod 16 so that the 16-byte operand reads of 32 consecutive rows touch every bank once.
+// Operand layout of the instruction (checked by the known-answer test): lane l holds A[row l & 31][k 8 (l >> 5) .. + 7],
+// B[k 8 (l >> 5) .. + 7][col l & 31]; C/D as for the 32x32x2 instruction.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> packed bf16 pairs of the three terms
+__device__ __forceinline__ void split3(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  f32x2 v = {v0, v1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  v.x = v0 - __uint_as_float(hi << 16);
+  v.y = v1 - __uint_as_float(hi & 0xffff0000u);
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  v.x -= __uint_as_float(mid << 16);
+  v.y -= __uint_as_float(mid & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+__global__ __launch_bounds__(256) void k_pack_weights_bf16x3(const float* __restrict__ w, int cout_pad, int taps, int cin,
+                                                             unsigned* __restrict__ out) {
+  // thread = (row = cout * taps + tap, channel pair)
+  const long long total = (long long)cout_pad * taps * (cin / 2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cp = (int)(i % (cin / 2));
+    const long long row = i / (cin / 2);
+    const float* src = w + row * cin + 2 * cp;
+    unsigned h, m, l;
+    split3(src[0], src[1], h, m, l);
+    const int c = 2 * cp, slice = c >> 4, k = c & 15;
+    unsigned* dst = out + (((size_t)row * (cin / 16) + slice) * 3) * 8 + (k >> 1);  // 8 dwords (16 bf16) per split
+    dst[0] = h; dst[8] = m; dst[16] = l;
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 3) void k_conv_nhwc_bf16x3(ConvArgs a, const unsigned* __restrict__ w3) {
+  constexpr int BK = 16;
+  // [buffer][split][row][8 dwords]
+  __shared__ unsigned As[2][3][CV_BM][8];
+  __shared__ unsigned Bs[2][3][BN][8];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const long long m0 = (long long)blockIdx.x * CV_BM;
+  const int n0 = blockIdx.y * BN;
+
+  // A: thread loads channels 4 cq .. 4 cq + 3 of pixels pm0 and pm0 + 64
+  const int pm0 = t >> 2, cq = t & 3;
+  int px[2], py[2];
+  bool mvalid[2];
+  const float* __restrict__ xpix[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long long gm = m0 + pm0 + 64 * j;
+    mvalid[j] = gm < a.m;
+    int pn = 0;
+    px[j] = py[j] = 0;
+    if (mvalid[j]) {
+      px[j] = (int)(gm % a.wd);
+      const long long r = gm / a.wd;
+      py[j] = (int)(r % a.h);
+      pn = (int)(r / a.h);
+    }
+    xpix[j] = a.x + ((size_t)((size_t)pn * a.h + py[j]) * a.wd + px[j]) * a.xs + a.xoff + 4 * cq;
+  }
+  // B: thread loads the 16-byte half `bh` of the three splits of output channel(s) nb0 (+ 128 t-rows for BN = 128: one)
+  // (BN = 64: threads 128..255 repeat the loads of 0..127 and store nothing)
+  const int nb0 = (t >> 1) & (BN - 1), bh = t & 1;
+  const bool bload = (t >> 1) < BN;
+  const int cslices = a.cin / BK, taps = a.kh * a.kw;
+  const int nslices = taps * cslices;
+  const unsigned* __restrict__ wrow = w3 + ((size_t)(n0 + nb0) * taps * cslices) * 24 + 4 * bh;
+
+  int f_ky = 0, f_kx = 0, f_c = 0, f_s = 0;
+  float4 ra[2];
+  uint4 rb0, rb1, rb2;
+  auto fetch = [&]() {
+    const long long shift = ((long long)(f_ky - a.pad) * a.wd + (f_kx - a.pad)) * a.xs + f_c * BK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yy = py[j] + f_ky - a.pad, xx = px[j] + f_kx - a.pad;
+      const bool inb = mvalid[j] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd;
+      ra[j] = inb ? *reinterpret_cast<const float4*>(xpix[j] + shift) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const unsigned* __restrict__ ws = wrow + (size_t)f_s * 24;
+    rb0 = *reinterpret_cast<const uint4*>(ws);
+    rb1 = *reinterpret_cast<const uint4*>(ws + 8);
+    rb2 = *reinterpret_cast<const uint4*>(ws + 16);
+    ++f_s;
+    if (++f_c == cslices) {
+      f_c = 0;
+      if (++f_kx == a.kw) { f_kx = 0; ++f_ky; }
+    }
+  };
+  // row r, 16-byte half c -> dword offset inside the [row][8] tile
+  auto swz = [](int r, int c) { return r * 8 + ((c ^ ((r >> 3) & 1)) << 2); };
+  // the next slice goes to the other LDS buffer in three pieces (activation pixel 0, pixel 1, weights) that the main
+  // loop places BETWEEN its matrix instructions: the split arithmetic and the LDS stores of a wave then run while its
+  // own MFMAs occupy the matrix pipe
+  auto stashA = [&](int buf, int j) {
+    unsigned h0, m0_, l0, h1, m1, l1;
+    split3(ra[j].x, ra[j].y, h0, m0_, l0);
+    split3(ra[j].z, ra[j].w, h1, m1, l1);
+    const int r = pm0 + 64 * j;
+    const int o = swz(r, cq >> 1) + 2 * (cq & 1);
+    *reinterpret_cast<uint2*>(&As[buf][0][0][0] + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(&As[buf][1][0][0] + o) = make_uint2(m0_, m1);
+    *reinterpret_cast<uint2*>(&As[buf][2][0][0] + o) = make_uint2(l0, l1);
+  };
+  auto stashB = [&](int buf) {
+    if (bload) {
+      const int o = swz(nb0, bh);
+      *reinterpret_cast<uint4*>(&Bs[buf][0][0][0] + o) = rb0;
+      *reinterpret_cast<uint4*>(&Bs[buf][1][0][0] + o) = rb1;
+      *reinterpret_cast<uint4*>(&Bs[buf][2][0][0] + o) = rb2;
+    }
+  };
+  auto stash = [&](int buf) { stashA(buf, 0); stashA(buf, 1); stashB(buf); };
+
+  constexpr int MT = BN == 128 ? 2 : 1, NT = 2;
+  const int wm = BN == 128 ? (wv >> 1) * 64 : wv * 32;
+  const int wn = BN == 128 ? (wv & 1) * 64 : 0;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch();
+  stash(0);
+  __syncthreads();
+  const int l31 = lane & 31, lk = lane >> 5;
+  for (int s = 0; s < nslices; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslices) fetch();
+    bf16x8 af[3][MT], bfr[3][NT];
+    auto rdA = [&](int sp) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[sp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[buf][sp][0][0] + swz(wm + 32 * i + l31, lk)));
+    };
+    auto rdB = [&](int sp) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bfr[sp][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][sp][0][0] + swz(wn + 32 * j + l31, lk)));
+    };
+    // one product term over the wave's 2 x 2 tiles: four independent accumulators between two uses of the same one
+    auto term = [&](int sa, int sb) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sa][i], bfr[sb][j], acc[i][j], 0, 0, 0);
+    };
+    // operands are requested in the order the terms consume them (LDS returns in order: each term waits only for its own)
+    rdA(0); rdB(0); rdB(1); rdA(1); rdB(2); rdA(2);
+    const bool more = s + 1 < nslices;   // uniform
+    term(0, 0);
+    term(0, 1);
+    term(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stashB(buf ^ 1);
+    term(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stashA(buf ^ 1, 0);
+    term(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stashA(buf ^ 1, 1);
+    term(2, 0);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nn = n0 + wn + 32 * j + l31;
+    if (nn >= a.cout) continue;
+    const float b = a.bias[nn];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long mm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (mm < a.m) {
+          float v = acc[i][j][r] + b;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          a.y[(size_t)mm * a.ys + a.yoff + nn] = v;
+        }
+      }
+  }
+}
+
 struct PoolArgs {
   const float* x;
   float* y;
@@ -271,6 +480,47 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
   st_timed t(ctx, ST_K_CONV);
   if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_f32<128, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL((k_conv_nhwc_f32<64, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+
+ST_EXPORT int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!w_dev || !out_dev || cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0 || cin % 16 || ((uintptr_t)out_dev & 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "conv pack: bad arguments (cin a multiple of 16, 16-byte aligned output)");
+  const long long total = (long long)cout_pad * kh * kw * (cin / 2);
+  long long bx = (total + 255) / 256;
+  if (bx > 65536) bx = 65536;
+  hipLaunchKernelGGL(k_pack_weights_bf16x3, dim3((unsigned)bx), dim3(256), 0, ctx->stream, w_dev, cout_pad, kh * kw, cin, (unsigned*)out_dev);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                                    const void* w3_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
+                                    float* y_dev, int y_stride, int y_offset) {
+  ST_TRY(st_enter(ctx));
+  if (!x_dev || !w3_dev || !bias_dev || !y_dev || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0)
+    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
+  if (cin % 16 || x_offset % 4 || x_stride % 4 || x_offset + cin > x_stride || ((uintptr_t)x_dev & 15) || ((uintptr_t)w3_dev & 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: input channels must be a multiple of 16 inside a 16-byte aligned buffer (cin=%d stride=%d offset=%d)", cin, x_stride, x_offset);
+  if (kh != kw || !(kh & 1) || kh > 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: %dx%d kernels (odd square kernels up to 7 are implemented)", kh, kw);
+  const int bn = cout_pad % 128 == 0 ? 128 : 64;
+  if (cout_pad < cout || cout_pad % 64) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: cout_pad must be a multiple of 64 >= cout");
+  if (y_offset + cout > y_stride) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: output slice exceeds the buffer's channel count");
+  ConvArgs a;
+  a.x = x_dev; a.w = nullptr; a.bias = bias_dev; a.y = y_dev;
+  a.n = n; a.h = h; a.wd = w; a.cin = cin; a.xs = x_stride; a.xoff = x_offset;
+  a.kh = kh; a.kw = kw; a.pad = kh / 2;
+  a.cout = cout; a.ys = y_stride; a.yoff = y_offset; a.relu = relu ? 1 : 0;
+  a.m = (long long)n * h * w;
+  const long long bm = (a.m + CV_BM - 1) / CV_BM;
+  if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+  dim3 grid((unsigned)bm, cout_pad / bn);
+  st_timed t(ctx, ST_K_CONV);
+  if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_bf16x3<128>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)w3_dev);
+  else hipLaunchKernelGGL((k_conv_nhwc_bf16x3<64>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)w3_dev);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
 }

@@ -181,10 +181,16 @@ def _pad64(c):
 class PoseNet:
     """Random-weight instance of the network on one GPU."""
 
-    def __init__(self, ctx, seed=0, caffemodel=None):
+    def __init__(self, ctx, seed=0, caffemodel=None, math="f32"):
         """caffemodel: path of the model's weights (pose_iter_440000.caffemodel of the COCO body model); None =
-        random weights from `seed` (He initialisation)."""
+        random weights from `seed` (He initialisation).
+        math: "f32" (default; the float32 matrix instruction, what the reference's Caffe pass computes in) or "bf16x3"
+        (opt-in: every operand split into three bf16 terms on the bf16 matrix pipe -- float32-grade accuracy at a
+        multiple of the float32 matrix rate, not bit-identical to "f32")."""
         import torch
+        if math not in ("f32", "bf16x3"):
+            raise ValueError("math must be 'f32' or 'bf16x3'")
+        self.math = math
         self.ctx, self.torch = ctx, torch
         self.device = ctx.device
         g = torch.Generator().manual_seed(seed)
@@ -210,6 +216,15 @@ class PoseNet:
             bp = torch.zeros((_pad64(co),))
             bp[:co] = b
             self.packed[name] = (wp.contiguous().to(self.device), bp.to(self.device))
+        self.packed3 = {}   # name -> weights as bf16 triples (st_conv_pack_weights_bf16x3), math == "bf16x3" only
+        if math == "bf16x3":
+            ctx._bind()
+            for name, (wp, _) in self.packed.items():
+                w3 = torch.empty((wp.numel() * 6,), dtype=torch.uint8, device=self.device)
+                ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], wp.shape[1], wp.shape[2],
+                                                              wp.shape[3], ctypes.c_void_p(w3.data_ptr())))
+                self.packed3[name] = w3
+            torch.cuda.synchronize(self.device)
 
     # -- plumbing -------------------------------------------------------------------------------------
     def _conv(self, name, x, cin, xoff, y, cout, yoff, k, relu):
@@ -217,6 +232,11 @@ class PoseNet:
         wp, bp = self.packed[name]
         L = self.ctx._L
         self.ctx._bind()
+        if self.math == "bf16x3":
+            self.ctx._check(L.st_conv2d_nhwc_bf16x3(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, cin, xs, xoff,
+                                                    ctypes.c_void_p(self.packed3[name].data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, cout,
+                                                    wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
+            return
         self.ctx._check(L.st_conv2d_nhwc_f32(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, cin, xs, xoff,
                                              ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, cout,
                                              wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))

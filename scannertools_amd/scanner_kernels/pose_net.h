@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -179,7 +180,15 @@ inline bool check_caffemodel(const std::string& path, int* matched, std::string*
 // ---- the network on one GPU ---------------------------------------------------------------------------------
 class Net {
  public:
+  // SCANNERTOOLS_POSE_MATH=bf16x3 (read when the kernel instance is created) selects the split-bf16 arithmetic of
+  // st_conv2d_nhwc_bf16x3 for every layer -- float32-grade accuracy on the bf16 matrix pipe, not bit-identical to the
+  // default float32 instruction.  The reference's op arguments (CPM2Args / OpenPoseArgs) have no field for it.
+  Net() {
+    const char* m = getenv("SCANNERTOOLS_POSE_MATH");
+    bf16x3_ = m && std::string(m) == "bf16x3";
+  }
   ~Net() { release(); }
+  bool bf16x3() const { return bf16x3_; }
 
   // Loads the weights, packs them as [cout_pad][k][k][cin_pad] and uploads them to the current device.
   bool load(const std::string& caffemodel, std::string* err) try {
@@ -236,16 +245,15 @@ class Net {
     const auto trunk = trunk_layers();
     for (int i = 0; i < (int)trunk.size(); ++i) {
       const LayerSpec& l = trunk[i];
-      const Packed& p = packed_[l.name];
+      Packed& p = packed_[l.name];
       if (i == (int)trunk.size() - 1) {
         // conv4_4_CPM: the features go straight into BOTH stage buffers (stage s reads buffer (s-1)&1)
         for (int t = 0; t < 2; ++t)
-          if (st_conv2d_nhwc_f32(ctx, x, n, h, w, xc, xc, 0, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, cat_[t], kCatPad, kOffFeat) != ST_OK)
-            return fail("st_conv2d_nhwc_f32");
+          if (conv(ctx, x, n, h, w, xc, xc, 0, p, l, cat_[t], kCatPad, kOffFeat) != ST_OK) return fail("st_conv2d_nhwc");
         break;
       }
       const int yc = (l.cout + 15) / 16 * 16;
-      if (st_conv2d_nhwc_f32(ctx, x, n, h, w, xc, xc, 0, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, yc, 0) != ST_OK) return fail("st_conv2d_nhwc_f32");
+      if (conv(ctx, x, n, h, w, xc, xc, 0, p, l, y, yc, 0) != ST_OK) return fail("st_conv2d_nhwc");
       std::swap(x, y);
       xc = yc;
       if (pool_after(i)) {
@@ -263,14 +271,13 @@ class Net {
         int xs = kCatPad, xcin = st == 1 ? kFeat : kCatPad, xoff = st == 1 ? kOffFeat : 0;
         for (int i = 0; i < (int)layers.size(); ++i) {
           const LayerSpec& l = layers[i];
-          const Packed& p = packed_[l.name];
+          Packed& p = packed_[l.name];
           float* yout;
           int ys, yoff;
           if (i == (int)layers.size() - 1) { yout = dst; ys = kCatPad; yoff = br == 1 ? kOffPaf : kOffHeat; }
           else if (l.cout == 512) { yout = wide_; ys = 512; yoff = 0; }
           else { yout = tmp_[i & 1]; ys = 128; yoff = 0; }
-          if (st_conv2d_nhwc_f32(ctx, xin, n, h, w, xcin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, yout, ys, yoff) != ST_OK)
-            return fail("st_conv2d_nhwc_f32");
+          if (conv(ctx, xin, n, h, w, xcin, xs, xoff, p, l, yout, ys, yoff) != ST_OK) return fail("st_conv2d_nhwc");
           xin = yout; xs = ys; xcin = ys; xoff = 0;
         }
       }
@@ -282,8 +289,20 @@ class Net {
   struct Packed {
     float* w = nullptr;
     float* b = nullptr;
-    int cin_pad = 0, cout_pad = 0;
+    void* w3 = nullptr;  // the same weights as bf16 triples (bf16x3 arithmetic only; packed on first use)
+    int cin_pad = 0, cout_pad = 0, k = 0;
   };
+
+  // one convolution layer in the selected arithmetic
+  int conv(st_ctx* ctx, const float* x, int n, int h, int w, int cin, int xs, int xoff, Packed& p, const LayerSpec& l, float* y, int ys, int yoff) {
+    if (!bf16x3_) return st_conv2d_nhwc_f32(ctx, x, n, h, w, cin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
+    if (!p.w3) {
+      if (hipMalloc(&p.w3, (size_t)p.cout_pad * l.k * l.k * p.cin_pad * 6) != hipSuccess) return ST_ERR_HIP;
+      const int st = st_conv_pack_weights_bf16x3(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, p.w3);
+      if (st != ST_OK) return st;
+    }
+    return st_conv2d_nhwc_bf16x3(ctx, x, n, h, w, cin, xs, xoff, p.w3, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
+  }
 
   bool reserve(int n, int H, int W, int slot, std::string* err) {
     const size_t big = (size_t)n * H * W * 64, small = (size_t)n * (H / 8) * (W / 8);
@@ -334,11 +353,13 @@ class Net {
     for (auto& kv : packed_) {
       if (kv.second.w) (void)hipFree(kv.second.w);
       if (kv.second.b) (void)hipFree(kv.second.b);
+      if (kv.second.w3) (void)hipFree(kv.second.w3);
     }
     packed_.clear();
   }
 
   std::map<std::string, Packed> packed_;
+  bool bf16x3_ = false;
   static constexpr int kMaxSlots = 8;
   struct Slot {
     float* cat[2] = {nullptr, nullptr};

@@ -12,7 +12,10 @@ from scannertools_amd import pose_net
 pytestmark = pytest.mark.gpu
 
 
-def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0):
+MATH = ["f32", "bf16x3"]   # the float32 matrix instruction (default) and the opt-in split-bf16 arithmetic of the same accuracy
+
+
+def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math="f32"):
     """x_nhwc (n,h,w,C) cuda; wt (co,ci,k,k), b (co,) cpu -> y (n,h,w,cout_total) cuda."""
     n, h, w, xs = x_nhwc.shape
     co, ci, k, _ = wt.shape
@@ -27,6 +30,13 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0):
     ys = cout_total or (co + 3) // 4 * 4
     y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
     hip_ctx._bind()
+    if math == "bf16x3":
+        w3 = torch.empty((wp.numel() * 6,), dtype=torch.uint8, device="cuda")
+        hip_ctx._check(hip_ctx._L.st_conv_pack_weights_bf16x3(hip_ctx._h, ctypes.c_void_p(wp.data_ptr()), cop, k, k, cip, ctypes.c_void_p(w3.data_ptr())))
+        hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_bf16x3(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
+                                                         ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
+                                                         int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
+        return y
     hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_f32(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
                                                   ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
                                                   int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
@@ -36,7 +46,8 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0):
 @pytest.mark.parametrize("n,h,w,ci,co,k,relu", [(1, 9, 13, 3, 64, 3, 1), (2, 23, 31, 16, 128, 3, 1), (1, 17, 19, 128, 38, 1, 0),
                                                  (2, 12, 20, 64, 19, 7, 0), (1, 46, 82, 185, 128, 7, 1), (3, 8, 8, 512, 512, 3, 1),
                                                  (1, 5, 7, 32, 200, 5, 1)])
-def test_conv_layer_matches_torch(hip_ctx, n, h, w, ci, co, k, relu):
+@pytest.mark.parametrize("math", MATH)
+def test_conv_layer_matches_torch(hip_ctx, n, h, w, ci, co, k, relu, math):
     g = torch.Generator().manual_seed(n * 1000 + ci + co + k)
     x = torch.randn((n, ci, h, w), generator=g)
     wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))
@@ -47,14 +58,18 @@ def test_conv_layer_matches_torch(hip_ctx, n, h, w, ci, co, k, relu):
     cip = (ci + 15) // 16 * 16
     xn = torch.zeros((n, h, w, cip))
     xn[..., :ci] = x.permute(0, 2, 3, 1)
-    y = _conv(hip_ctx, xn.cuda(), cip, 0, wt, b, relu)
+    y = _conv(hip_ctx, xn.cuda(), cip, 0, wt, b, relu, math=math)
     got = y[..., :co].permute(0, 3, 1, 2).cpu().double()
     scale = float(ref.abs().max())
+    # the same bound for both: against float64, the split-bf16 products must be as good as float32 products
     assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (float((got - ref).abs().max()), scale)
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel <= 2e-6, rel
     assert (y[..., co:] == -7.0).all()                       # nothing written outside the cout channels
 
 
-def test_conv_channel_slices_and_identity_known_answer(hip_ctx):
+@pytest.mark.parametrize("math", MATH)
+def test_conv_channel_slices_and_identity_known_answer(hip_ctx, math):
     """Reads a channel slice of a wider buffer, writes into a slice of another; a 1x1 identity kernel and a
     3x3 shift kernel have known answers (asymmetric, so a transposed operand layout cannot pass)."""
     n, h, w = 1, 11, 14
@@ -64,14 +79,14 @@ def test_conv_channel_slices_and_identity_known_answer(hip_ctx):
     wt = torch.zeros((16, 16, 1, 1))
     for c in range(16):
         wt[c, (c + 3) % 16, 0, 0] = 1.0                       # out channel c = in channel c+3: a permutation, not symmetric
-    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt, torch.zeros(16), 0, cout_total=40, yoff=20)
+    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt, torch.zeros(16), 0, cout_total=40, yoff=20, math=math)
     got = y.cpu()
     np.testing.assert_array_equal(got[..., 20:36].numpy(), x[..., [(c + 3) % 16 for c in range(16)]].numpy())
     assert (got[..., :20] == -7).all() and (got[..., 36:] == -7).all()
     wt3 = torch.zeros((16, 16, 3, 3))
     for c in range(16):
         wt3[c, c, 0, 2] = 1.0                                 # tap (ky=0, kx=2): out(y, x) = in(y-1, x+1), zero outside
-    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt3, torch.zeros(16), 0)
+    y = _conv(hip_ctx, buf.cuda(), 16, 16, wt3, torch.zeros(16), 0, math=math)
     exp = torch.zeros((n, h, w, 16))
     exp[:, 1:, :-1] = x[:, :-1, 1:]
     np.testing.assert_array_equal(y[..., :16].cpu().numpy(), exp.numpy())
@@ -92,11 +107,12 @@ def test_maxpool_and_layout(hip_ctx):
     assert torch.equal(y[..., :3], ref)
 
 
-def test_pose_network_end_to_end(hip_ctx):
+@pytest.mark.parametrize("math", MATH)
+def test_pose_network_end_to_end(hip_ctx, math):
     """All 92 convolutions + 3 poolings on a small input, against the float32 torch network (CPU, so that no
     other GPU library is in the comparison); the reference's own precision, so the bound is float32 round-off
     accumulated over the depth."""
-    net = pose_net.PoseNet(hip_ctx, seed=3)
+    net = pose_net.PoseNet(hip_ctx, seed=3, math=math)
     g = torch.Generator().manual_seed(9)
     x = (torch.rand((2, 3, 48, 80), generator=g) - 0.5)
     got = net.forward(x.cuda()).permute(0, 3, 1, 2).cpu()
@@ -190,6 +206,25 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, model_dir, tmp_path):
         for i, (m, j) in enumerate(zip(om.load(), oj.load())):
             np.testing.assert_array_equal(m, maps[i].cpu().numpy())
             np.testing.assert_array_equal(j, joints[i].cpu().numpy())
+
+    # the opt-in split-bf16 arithmetic: the kernel class (SCANNERTOOLS_POSE_MATH, read when the instance is created)
+    # equals PoseNet(math="bf16x3") bit for bit, and the two arithmetics agree to float32 round-off over the 92 layers
+    import os
+    c_net = pose_net.PoseNet(hip_ctx, caffemodel=path, math="bf16x3")
+    low32, low3 = a.forward(x), c_net.forward(x)
+    assert float((low32 - low3).abs().max()) <= 2e-5 * float(low32.abs().max()) and not torch.equal(low32, low3)
+    maps3, joints3 = c_net.detect(x)
+    os.environ["SCANNERTOOLS_POSE_MATH"] = "bf16x3"
+    try:
+        sc = Client()
+        m_col, j_col = sc.ops.CPM2(cpm2_input=_Rows([f for f in x]), weights=path, device=DeviceType.GPU, batch=2)
+        om, oj = NamedStream(sc, "maps3"), NamedStream(sc, "joints3")
+        sc.run([sc.io.Output(m_col, [om]), sc.io.Output(j_col, [oj])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        for i, (m, j) in enumerate(zip(om.load(), oj.load())):
+            np.testing.assert_array_equal(m, maps3[i].cpu().numpy())
+            np.testing.assert_array_equal(j, joints3[i].cpu().numpy())
+    finally:
+        del os.environ["SCANNERTOOLS_POSE_MATH"]
 
     cut = tmp_path / "cut.caffemodel"
     with open(path, "rb") as fh:
