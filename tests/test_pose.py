@@ -447,6 +447,21 @@ def test_pose_entry_points_reject_bad_arguments_and_accept_empty_batches(hip_ctx
     assert conv(xoff=16) != 0            # 16 + 32 channels > 32
     assert conv(cin=16, xoff=2) != 0     # offset not a multiple of 4
     assert conv(cop=96) != 0 and conv(cout=80) != 0 and conv(yoff=8) != 0
+    # the split-bf16 entry points refuse the same things (and a misaligned / missing weight buffer)
+    w3 = torch.zeros((w.numel() * 6,), dtype=torch.uint8, device="cuda")
+    assert L.st_conv_pack_weights_bf16x3(h, vp(w.data_ptr()), 64, 3, 3, 32, vp(w3.data_ptr())) == 0
+    assert L.st_conv_pack_weights_bf16x3(h, vp(w.data_ptr()), 64, 3, 3, 24, vp(w3.data_ptr())) == _native.ST_ERR_INVALID
+    assert L.st_conv_pack_weights_bf16x3(h, vp(w.data_ptr()), 64, 3, 3, 32, vp(w3.data_ptr() + 2)) == _native.ST_ERR_INVALID
+    assert L.st_conv_pack_weights_bf16x3(h, None, 64, 3, 3, 32, vp(w3.data_ptr())) == _native.ST_ERR_INVALID
+
+    def conv3(cin=32, xs=32, xoff=0, k=3, cout=64, cop=64, ys=64, yoff=0, wp=None):
+        return L.st_conv2d_nhwc_bf16x3(h, vp(x.data_ptr()), 1, 4, 4, cin, xs, xoff, vp(w3.data_ptr()) if wp is None else wp, vp(b.data_ptr()), k, k, cout, cop, 1,
+                                       vp(y.data_ptr()), ys, yoff)
+
+    assert conv3() == 0
+    assert conv3(cin=24) == _native.ST_ERR_INVALID and conv3(k=4) == _native.ST_ERR_UNSUPPORTED
+    assert conv3(xoff=16) != 0 and conv3(cop=96) != 0 and conv3(cout=80) != 0 and conv3(yoff=8) != 0
+    assert conv3(wp=vp(w3.data_ptr() + 4)) == _native.ST_ERR_INVALID and conv3(wp=None if False else vp(0)) == _native.ST_ERR_INVALID
     assert L.st_maxpool2_nhwc_f32(h, vp(x.data_ptr()), 1, 1, 4, 32, 32, vp(y.data_ptr()), 32) != 0
     assert L.st_maxpool2_nhwc_f32(h, vp(x.data_ptr() + 4), 1, 4, 4, 32, 32, vp(y.data_ptr()), 32) != 0
     assert L.st_planar_to_nhwc_f32(h, vp(x.data_ptr()), 1, 3, 4, 4, vp(y.data_ptr()), 2) != 0
