@@ -107,6 +107,18 @@ int st_hist_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, int n, int
 int st_hist_u8c3_strided(st_ctx* ctx, const uint8_t* base_dev, size_t frame_stride_bytes, int n,
                          int h, int w, int bins, int32_t* out_dev);
 
+/* ---- ShotBoundaries (device-resident histograms) -------------------------------------------
+ * Replaces the body of the ShotBoundaries python op, scannertools/shot_detection.py:12-28, for histograms that are
+ * already on the GPU (the op itself stays host code in the reference; with resident frames its 10 000-window loop is
+ * two thirds of the Histogram -> ShotBoundaries pipeline).  hist_dev: n * 3 * bins int32 as st_hist_u8c3_* writes
+ * them; flags_dev[i] = 1 where frame i opens a shot: diffs[i] - mean(win) > k_std * std(win), win =
+ * diffs[max(i - window, 0) : min(i + window, n)], diffs[i] = mean over the channels of the Chebyshev distance between
+ * frames i-1 and i (shot_detection.py:14-18, :23-26; the reference's window = 500, k_std = 2.5).  Means and standard
+ * deviations are formed in numpy's summation order, so the flags equal the reference's decisions bit for bit.
+ * diffs_dev: optional n doubles that receive diffs (null: context scratch). */
+int st_shot_boundaries(st_ctx* ctx, const int32_t* hist_dev, int n, int bins, int window, double k_std, uint8_t* flags_dev,
+                       double* diffs_dev);
+
 /* ---- OpticalFlow ---------------------------------------------------------------------------
  * Parameters of cv::FarnebackOpticalFlow::create(numLevels, pyrScale, fastPyramids, winSize,
  * numIters, polyN, polySigma, flags); st_fb_params_default() gives the reference's

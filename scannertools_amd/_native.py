@@ -91,6 +91,7 @@ SIGNATURES = {
     "st_ctx_timing_read": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_d)]),
     "st_hist_u8c3_batch": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp]),
     "st_hist_u8c3_strided": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "st_shot_boundaries": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "st_fb_params_default": (None, [_c.POINTER(FbParams)]),
     "st_farneback_pairs": (_i, [_vp, _c.POINTER(_vp), _i, _c.POINTER(_c.c_int32), _i, _i, _i,
                                 _c.POINTER(FbParams), _c.POINTER(_vp)]),

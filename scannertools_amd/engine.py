@@ -659,8 +659,20 @@ class _Ops:
         node.reader = _types.poses
         return node
 
-    def ShotBoundaries(self, histograms):
-        """sc.ops.ShotBoundaries(histograms=hist) (tests/test_all.py:227)."""
+    def ShotBoundaries(self, histograms, device=DeviceType.CPU):
+        """sc.ops.ShotBoundaries(histograms=hist) (tests/test_all.py:227): the reference's host python op.
+        device=DeviceType.GPU: the same decisions computed on the GPU (st_shot_boundaries) from the histogram rows
+        uploaded in one piece -- an explicit choice, never a fallback in either direction."""
+        if device == DeviceType.GPU:
+            sc = self.sc
+
+            def on_device(config, elements):
+                import torch
+                from .hip import HipContext
+                h = torch.from_numpy(np.ascontiguousarray(np.stack([np.stack(e) for e in elements]).astype(np.int32))).to("cuda:%d" % sc.device_id)
+                with HipContext(sc.device_id) as ctx:
+                    return _shot.shot_boundaries_device(ctx, h)
+            return _PyOpNode(on_device, histograms, _types.histograms)
         return _PyOpNode(_shot.shot_boundaries, histograms, _types.histograms)
 
 

@@ -137,6 +137,24 @@ class HipContext:
         return out
 
     # -- flow consumers ---------------------------------------------------------------------
+    def shot_boundaries(self, hist, window=500, k_std=2.5, return_diffs=False):
+        """ShotBoundaries on device-resident histograms (shot_detection.py:12-28): hist = CUDA int32 (n, 3, bins) as
+        `histogram` returns them.  Returns the list of boundary frame indices (the reference op's row 0), bit for bit
+        the host op's; with return_diffs also the float64 distances diffs[i]."""
+        self._bind()
+        _require_cuda(hist, torch.int32, "hist", self.device)
+        if hist.dim() != 3 or hist.shape[1] != 3:
+            raise ValueError("hist must be (n, 3, bins)")
+        hist = hist.contiguous()
+        n, _, bins = hist.shape
+        flags = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        diffs = torch.empty((n,), dtype=torch.float64, device=self.device) if return_diffs else None
+        self._check(self._L.st_shot_boundaries(self._h, ctypes.c_void_p(hist.data_ptr()), n, bins, int(window), float(k_std),
+                                               ctypes.c_void_p(flags.data_ptr()), ctypes.c_void_p(diffs.data_ptr()) if return_diffs else None))
+        self.sync()
+        idx = [int(i) for i in torch.nonzero(flags).flatten().cpu()]
+        return (idx, diffs) if return_diffs else idx
+
     def flow_histogram(self, flows, out=None):
         """FlowHistogram (old/cpp_ops/flow_histogram_kernel_cpu.cpp:26-57): magnitude and angle
         histograms (64 bins on [0,64) px and [0,360) degrees) of flow frames.

@@ -73,3 +73,15 @@ def outlier_boundaries(diffs: np.ndarray) -> list:
         flag[i] = diffs[i] - np.mean(window) > 2.5 * np.std(window)
     return [int(i) for i in np.nonzero(flag)[0]]
 
+
+
+def shot_boundaries_device(ctx, histograms) -> Sequence[Any]:
+    """The same op for histograms that are already on the GPU (a CUDA int32 (n, 3, bins) tensor, what HipContext.histogram
+    returns): the distances and the windowed outlier test run on the device in numpy's summation order
+    (st_shot_boundaries), so the boundary list equals `shot_boundaries`' bit for bit; same output contract.  An explicit
+    choice of the caller (sc.ops.ShotBoundaries(..., device=DeviceType.GPU)): without a GPU it raises, it does not fall
+    back to the host op."""
+    n = int(histograms.shape[0])
+    if n == 0:
+        return []
+    return [ctx.shot_boundaries(histograms, WINDOW_SIZE, 2.5)] + [None for _ in range(n - 1)]

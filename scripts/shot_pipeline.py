@@ -118,11 +118,21 @@ def main():
         t_hist = float(t.item())
     full = gather_rows(hist, n, dst=0)
     if rank == 0:
+        # ShotBoundaries on the gathered rows: on the device (st_shot_boundaries, the same decisions bit for bit) and,
+        # beside it, the reference's host formulation
+        from scannertools_amd.shot_detection import shot_boundaries_device
+        shot_boundaries_device(ctx, full)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res_dev = shot_boundaries_device(ctx, full)
+        t_sb_dev = time.perf_counter() - t0
         t0 = time.perf_counter()
         res = shot_boundaries(None, list(full.cpu().numpy()))
         t_sb = time.perf_counter() - t0
+        assert res_dev[0] == res[0], "device and host ShotBoundaries disagree"
         print(json.dumps({"frames": n, "resolution": [w, h], "n_gpus": world, "bins": args.bins,
-                          "histogram_frames_per_s": n / t_hist, "shot_boundaries_s": t_sb,
+                          "histogram_frames_per_s": n / t_hist, "shot_boundaries_s": t_sb_dev, "shot_boundaries_host_s": t_sb,
+                          "pipeline_frames_per_s": n / (t_hist + t_sb_dev),
                           "boundaries": res[0], "planted": cuts,
                           # the detector is a 2.5-sigma outlier test over +-500 frames: windows without a
                           # cut also flag noise peaks (so does the reference); every planted cut must be found
