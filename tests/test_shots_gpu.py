@@ -90,6 +90,29 @@ def test_device_shot_boundaries_equal_the_host_op(hip_ctx, seed, n, bins):
 
 
 @pytest.mark.gpu
+def test_device_shot_boundaries_extremes(hip_ctx):
+    """Counts at the ends of int32 (the distance needs 33 bits), a 200 000-frame stream, windows longer than the stream."""
+    import torch
+    from scannertools_amd import shot_detection
+    rng = np.random.default_rng(11)
+    h = rng.integers(0, 2, (300, 3, 16)).astype(np.int64) * (2 ** 32 - 1) - 2 ** 31     # INT32_MIN / INT32_MAX only
+    h = h.astype(np.int32)
+    hd = torch.from_numpy(h).cuda()
+    idx, diffs = hip_ctx.shot_boundaries(hd, return_diffs=True)
+    np.testing.assert_array_equal(diffs.cpu().numpy(), shot_detection.histogram_diffs(h))
+    assert idx == shot_detection.outlier_boundaries(shot_detection.histogram_diffs(h))
+    n = 200000
+    level = np.cumsum(rng.random(n) < 2e-4)                      # ~40 scene changes
+    base = ((level * 7919) % 13)[:, None, None] * 500
+    h = (base + rng.integers(0, 60, (n, 3, 16))).astype(np.int32)
+    got = hip_ctx.shot_boundaries(torch.from_numpy(h).cuda())
+    assert got == shot_detection.shot_boundaries(None, list(h))[0] and len(got) > 10
+    short = torch.from_numpy(h[:40]).cuda()
+    assert hip_ctx.shot_boundaries(short, window=5000) == [i for i in range(1, 40) if
+                                                            (lambda d: d[i] - np.mean(d) > 2.5 * np.std(d))(shot_detection.histogram_diffs(h[:40]))]
+
+
+@pytest.mark.gpu
 def test_shot_boundaries_op_on_the_gpu_through_the_engine(hip_ctx):
     """sc.ops.ShotBoundaries(histograms=..., device=GPU) after the Histogram op: the same rows as the host op."""
     from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
