@@ -24,4 +24,5 @@ for seed in range(4, n_pose):
         F.test_fuzz_pose_ops(ctx, seed)
     except AssertionError as e:
         bad += 1; print("POSE FAIL seed", seed, str(e)[:300])
+print("flow fields by tolerance tier (1 plain, 2 noise-arbitrated, 3 branch flip):", F.FLOW_TIERS)
 print("done, failures:", bad)

@@ -10,6 +10,7 @@ from scannertools_amd._native import COLOR_CODES
 from util import assert_flow_close, cvt_source, smooth_texture
 
 pytestmark = pytest.mark.gpu
+FLOW_TIERS = {1: 0, 2: 0, 3: 0}   # how many flow fields passed under which tier of util.assert_flow_close (campaign statistics)
 
 
 def _cu(a):
@@ -52,7 +53,8 @@ def test_fuzz_integer_ops(hip_ctx, seed):
             np.testing.assert_array_equal(got[i], oracle.draw_flow(frames[i], flows[i]), err_msg="draw_flow %dx%d" % (h, w))
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 103, 121, 268])  # the last three: noise-dominated identical-frame pairs found by the round-3 campaign
+# seeds >= 100: the pairs of the round-3 campaigns (300 + 1 500 seeds) that need tiers 2 / 3 of util.assert_flow_close
+@pytest.mark.parametrize("seed", [0, 1, 2, 103, 121, 268, 520, 976, 1420, 2876, 4079])
 def test_fuzz_optical_flow(flow_ctx, seed):
     """Random frame sizes (including ones smaller than the window and ones that change the number of
     pyramid levels) and random pair lists; every flow field against the oracle, under every
@@ -68,7 +70,7 @@ def test_fuzz_optical_flow(flow_ctx, seed):
         got = hip_ctx.optical_flow(_cu(frames), pairs=pairs).cpu().numpy()
         for i, (a, b) in enumerate(pairs):
             ref = oracle.optical_flow_rgb(frames[a], frames[b])
-            assert_flow_close(got[i], ref, frames[a], frames[b], (h, w, a, b))
+            FLOW_TIERS[assert_flow_close(got[i], ref, frames[a], frames[b], (h, w, a, b))] += 1
 
 
 @pytest.mark.parametrize("seed", range(4))
