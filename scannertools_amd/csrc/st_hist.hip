@@ -167,7 +167,11 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   if (head > nbytes) head = nbytes;
   const long long nvec = (nbytes - head) >> 4;
   const long long tail = head + (nvec << 4);
-  const uint4* vp = reinterpret_cast<const uint4*>(p + head);
+  // every byte is read once: non-temporal loads (no L1 allocation, early eviction further out) -- measured +7-8 % (64 frames
+  // per launch: 5.07 -> 5.54 TB/s)
+  typedef unsigned u4nt __attribute__((ext_vector_type(4)));
+  const u4nt* vq = reinterpret_cast<const u4nt*>(p + head);
+  auto ld = [&](long long j) { const u4nt v = __builtin_nontemporal_load(vq + j); return make_uint4(v.x, v.y, v.z, v.w); };
   const long long per = (nvec + chunks - 1) / chunks;
   const long long v0 = (long long)chunk * per;
   long long v1 = v0 + per;
@@ -182,12 +186,12 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   // vmcnt bookkeeping sees the same number of outstanding loads on every path into the loop.
   const int full = v1 > v0 ? (int)((v1 - v0) / (6 * T)) : 0;
   if (full > 0) {
-    uint4 a = vp[i], b = vp[i + T], c = vp[i + 2 * T];
-    uint4 d = vp[i + 3 * T], e = vp[i + 4 * T], f = vp[i + 5 * T];
+    uint4 a = ld(i), b = ld(i + T), c = ld(i + 2 * T);
+    uint4 d = ld(i + 3 * T), e = ld(i + 4 * T), f = ld(i + 5 * T);
     for (int it = 1; it < full; ++it) {
       i += 6 * T;
-      const uint4 na = vp[i], nb = vp[i + T], nc = vp[i + 2 * T];
-      const uint4 nd = vp[i + 3 * T], ne = vp[i + 4 * T], nf = vp[i + 5 * T];
+      const uint4 na = ld(i), nb = ld(i + T), nc = ld(i + 2 * T);
+      const uint4 nd = ld(i + 3 * T), ne = ld(i + 4 * T), nf = ld(i + 5 * T);
       __builtin_amdgcn_sched_barrier(0);
       count16c<C>(sh, a, o0, o1, o2);
       count16c<C>(sh, b, o1, o2, o0);
@@ -206,16 +210,16 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
     i += 6 * T;
   }
   for (; i + 2 * T < v1; i += 3 * T) {
-    uint4 a = vp[i], b = vp[i + T], c = vp[i + 2 * T];
+    uint4 a = ld(i), b = ld(i + T), c = ld(i + 2 * T);
     count16c<C>(sh, a, o0, o1, o2);
     count16c<C>(sh, b, o1, o2, o0);
     count16c<C>(sh, c, o2, o0, o1);
   }
   if (i < v1) {
-    uint4 a = vp[i];
+    uint4 a = ld(i);
     count16c<C>(sh, a, o0, o1, o2);
     if (i + T < v1) {
-      uint4 b = vp[i + T];
+      uint4 b = ld(i + T);
       count16c<C>(sh, b, o1, o2, o0);
     }
   }
