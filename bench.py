@@ -453,10 +453,18 @@ def run_rank(args):
             dist.destroy_process_group()
         return 0
 
+    # ST_BENCH_SHARE_GPU=1 (self-test of the multi-rank path on a box with fewer GPUs than ranks): ranks share the
+    # visible GPUs round-robin and synchronise over gloo (RCCL refuses two ranks on one device); never a measurement
+    share = os.environ.get("ST_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -479,7 +487,7 @@ def run_rank(args):
     dt, blur_launches, blur_ms = timed_flow_hist(torch, ctx, _native, batches, B, args.bins, args.steps, args.warmup,
                                                  barrier, flow_out, hist_out)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -554,6 +562,7 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            **({"ranks_share_gpus": True} if share else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

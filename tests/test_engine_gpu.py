@@ -204,3 +204,29 @@ def test_front_end_runners(sc):
             assert abs(int(np.stack(h)[0].sum()) - 80 * 60) <= 0 and np.stack(h)[1].sum() == 80 * 60
             # histogram of the oracle's flow agrees except for vectors that straddle a bin edge
             assert np.abs(np.stack(h) - oracle.flow_hist(flow_ref)).sum() <= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["own", "torchrun"])
+def test_bench_two_ranks_sharing_this_gpu(launcher):
+    """The multi-rank path of bench.py on real hardware with the one GPU a test box has: two rank processes (started by
+    bench.py itself, and by torch.distributed.run as the driver does) share device 0 and synchronise over gloo
+    (ST_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one device).  Per-rank shards, barriers, max-over-ranks time and
+    rank 0's single JSON line are the code the 8-GPU run uses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ST_BENCH_SHARE_GPU"] = "1"
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--height", "270", "--width", "480"]
+    cmd = [sys.executable] + tail if launcher == "own" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                              "--master-addr", "127.0.0.1", "--master-port", "29581"] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_share_gpus"] is True and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]   # whole-job aggregate
