@@ -101,11 +101,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ST_BENCH_SHARE_GPU=1: self-test of the multi-rank path on a box with fewer GPUs than ranks (ranks share the visible
+    # GPUs, gloo instead of RCCL, the histogram rows gathered through host memory); never a measurement
+    share = os.environ.get("ST_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, h, w = args.frames, args.height, args.width
     cuts = planted_cuts(n, args.cuts)
@@ -113,10 +121,12 @@ def main():
     ctx = HipContext(local)
     hist, t_hist = shard_histograms(torch, ctx, dev, a, b, h, w, args.bins, args.chunk, cuts, seed=99 + rank)
     if world > 1:
-        t = torch.tensor([t_hist], dtype=torch.float64, device=dev)
+        t = torch.tensor([t_hist], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_hist = float(t.item())
-    full = gather_rows(hist, n, dst=0)
+    full = gather_rows(hist.cpu() if share and world > 1 else hist, n, dst=0)
+    if full is not None and not full.is_cuda:
+        full = full.to(dev)
     if rank == 0:
         # ShotBoundaries on the gathered rows: on the device (st_shot_boundaries, the same decisions bit for bit) and,
         # beside it, the reference's host formulation

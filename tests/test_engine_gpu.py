@@ -230,3 +230,22 @@ def test_bench_two_ranks_sharing_this_gpu(launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_share_gpus"] is True and d["value"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 8 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]   # whole-job aggregate
+
+
+@pytest.mark.gpu
+def test_shot_pipeline_two_ranks_sharing_this_gpu():
+    """Config 3's multi-rank path on real hardware (scripts/shot_pipeline.py --gpus 2, ranks sharing device 0, gloo): shards of a
+    stream with planted cuts -> Histogram kernel per rank -> gather on rank 0 -> ShotBoundaries on the device, which the run itself
+    compares with the host op."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ST_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "shot_pipeline.py"), "--gpus", "2", "--frames", "3000", "--height", "72", "--width", "128",
+                        "--cuts", "4", "--chunk", "500"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["frames"] == 3000 and d["planted_found"] is True and d["shot_boundaries_s"] < d["shot_boundaries_host_s"]
