@@ -78,7 +78,10 @@ __global__ __launch_bounds__(kT) void k_flow_hist(FlowSrc src, long long npx, in
   if (head > npx) head = npx;
   const long long nvec = (npx - head) >> 1;  // float4 = 2 px
   const long long tail = head + (nvec << 1);
-  const float4* vp = reinterpret_cast<const float4*>(p + 2 * head);
+  // the flow field is read once: non-temporal loads (as in the Histogram kernel)
+  typedef float f4nt __attribute__((ext_vector_type(4)));
+  const f4nt* vq = reinterpret_cast<const f4nt*>(p + 2 * head);
+  auto ld = [&](long long j) { const f4nt v = __builtin_nontemporal_load(vq + j); return make_float4(v.x, v.y, v.z, v.w); };
   const long long per = (nvec + chunks - 1) / chunks;
   const long long v0 = (long long)chunk * per;
   long long v1 = v0 + per;
@@ -86,14 +89,14 @@ __global__ __launch_bounds__(kT) void k_flow_hist(FlowSrc src, long long npx, in
 
   long long i = v0 + tid;
   for (; i + 3 * kT < v1; i += 4 * kT) {
-    const float4 a = vp[i], b = vp[i + kT], c = vp[i + 2 * kT], d = vp[i + 3 * kT];
+    const float4 a = ld(i), b = ld(i + kT), c = ld(i + 2 * kT), d = ld(i + 3 * kT);
     count_px(sh, copy, a.x, a.y); count_px(sh, copy, a.z, a.w);
     count_px(sh, copy, b.x, b.y); count_px(sh, copy, b.z, b.w);
     count_px(sh, copy, c.x, c.y); count_px(sh, copy, c.z, c.w);
     count_px(sh, copy, d.x, d.y); count_px(sh, copy, d.z, d.w);
   }
   for (; i < v1; i += kT) {
-    const float4 a = vp[i];
+    const float4 a = ld(i);
     count_px(sh, copy, a.x, a.y); count_px(sh, copy, a.z, a.w);
   }
   if (chunk == 0) {
