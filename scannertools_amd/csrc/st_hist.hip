@@ -159,8 +159,6 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   const int frame = blockIdx.y;
   const int chunk = blockIdx.x;
   const uint8_t* p = src.ptrs ? src.ptrs[frame] : src.base + (size_t)frame * src.stride;
-  for (int i = tid; i < 768 * C; i += T) sh[i] = 0;
-  __syncthreads();
   const unsigned copy = tid & (C - 1);
 
   long long head = (long long)((16 - ((uintptr_t)p & 15)) & 15);
@@ -172,7 +170,9 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   typedef unsigned u4nt __attribute__((ext_vector_type(4)));
   const u4nt* vq = reinterpret_cast<const u4nt*>(p + head);
   auto ld = [&](long long j) { const u4nt v = __builtin_nontemporal_load(vq + j); return make_uint4(v.x, v.y, v.z, v.w); };
-  const long long per = (nvec + chunks - 1) / chunks;
+  // vectors per chunk: a whole number of pipelined steps (6 T vectors), so that only the frame's last chunk runs the
+  // un-pipelined remainder loops below
+  const long long per = ((nvec + chunks - 1) / chunks + 6 * T - 1) / (6 * T) * (6 * T);
   const long long v0 = (long long)chunk * per;
   long long v1 = v0 + per;
   if (v1 > nvec) v1 = nvec;
@@ -185,9 +185,16 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   // of step k.  The trip count is uniform and the loop has no conditional loads, so the compiler's
   // vmcnt bookkeeping sees the same number of outstanding loads on every path into the loop.
   const int full = v1 > v0 ? (int)((v1 - v0) / (6 * T)) : 0;
+  // the first step's loads are requested BEFORE the counters are cleared: the clear (96 KB of LDS stores) and its
+  // barrier then run under the first memory round trip instead of ahead of it (matters for short launches)
+  uint4 a = {}, b = {}, c = {}, d = {}, e = {}, f = {};
   if (full > 0) {
-    uint4 a = ld(i), b = ld(i + T), c = ld(i + 2 * T);
-    uint4 d = ld(i + 3 * T), e = ld(i + 4 * T), f = ld(i + 5 * T);
+    a = ld(i); b = ld(i + T); c = ld(i + 2 * T);
+    d = ld(i + 3 * T); e = ld(i + 4 * T); f = ld(i + 5 * T);
+  }
+  for (int z = tid; z < 768 * C; z += T) sh[z] = 0;
+  __syncthreads();
+  if (full > 0) {
     for (int it = 1; it < full; ++it) {
       i += 6 * T;
       const uint4 na = ld(i), nb = ld(i + T), nc = ld(i + 2 * T);
