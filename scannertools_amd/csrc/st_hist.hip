@@ -129,32 +129,35 @@ __global__ __launch_bounds__(kThreads) void k_hist_u8c3(FrameSrc src, long long 
 // address and the bank pattern is (bin * C + lane) % 32: random data costs ~1.5x (C = 16) instead
 // of the ~3.5x of one histogram per wave, and the all-equal frame costs 32/C-way instead of 32-way.
 // ---------------------------------------------------------------------------------------------
-template <int C>
+// SHIFT: counters are kept for byte >> SHIFT (0: all 256 values; 4: the reference's 16 bins directly, histogram_kernel_cpu.cpp:8)
+template <int C, int SHIFT = 0>
 __device__ __forceinline__ void count16c(unsigned* h, uint4 q, unsigned c0, unsigned c1, unsigned c2) {
   // c0/c1/c2 already include the lane's copy index; counters of a bin are C dwords apart
-  lds_inc(h + c0 + (q.x & 0xff) * C);
-  lds_inc(h + c1 + ((q.x >> 8) & 0xff) * C);
-  lds_inc(h + c2 + ((q.x >> 16) & 0xff) * C);
-  lds_inc(h + c0 + (q.x >> 24) * C);
-  lds_inc(h + c1 + (q.y & 0xff) * C);
-  lds_inc(h + c2 + ((q.y >> 8) & 0xff) * C);
-  lds_inc(h + c0 + ((q.y >> 16) & 0xff) * C);
-  lds_inc(h + c1 + (q.y >> 24) * C);
-  lds_inc(h + c2 + (q.z & 0xff) * C);
-  lds_inc(h + c0 + ((q.z >> 8) & 0xff) * C);
-  lds_inc(h + c1 + ((q.z >> 16) & 0xff) * C);
-  lds_inc(h + c2 + (q.z >> 24) * C);
-  lds_inc(h + c0 + (q.w & 0xff) * C);
-  lds_inc(h + c1 + ((q.w >> 8) & 0xff) * C);
-  lds_inc(h + c2 + ((q.w >> 16) & 0xff) * C);
-  lds_inc(h + c0 + (q.w >> 24) * C);
+  constexpr unsigned MK = 0xffu >> SHIFT;
+  lds_inc(h + c0 + ((q.x >> SHIFT) & MK) * C);
+  lds_inc(h + c1 + ((q.x >> (8 + SHIFT)) & MK) * C);
+  lds_inc(h + c2 + ((q.x >> (16 + SHIFT)) & MK) * C);
+  lds_inc(h + c0 + (q.x >> (24 + SHIFT)) * C);
+  lds_inc(h + c1 + ((q.y >> SHIFT) & MK) * C);
+  lds_inc(h + c2 + ((q.y >> (8 + SHIFT)) & MK) * C);
+  lds_inc(h + c0 + ((q.y >> (16 + SHIFT)) & MK) * C);
+  lds_inc(h + c1 + (q.y >> (24 + SHIFT)) * C);
+  lds_inc(h + c2 + ((q.z >> SHIFT) & MK) * C);
+  lds_inc(h + c0 + ((q.z >> (8 + SHIFT)) & MK) * C);
+  lds_inc(h + c1 + ((q.z >> (16 + SHIFT)) & MK) * C);
+  lds_inc(h + c2 + (q.z >> (24 + SHIFT)) * C);
+  lds_inc(h + c0 + ((q.w >> SHIFT) & MK) * C);
+  lds_inc(h + c1 + ((q.w >> (8 + SHIFT)) & MK) * C);
+  lds_inc(h + c2 + ((q.w >> (16 + SHIFT)) & MK) * C);
+  lds_inc(h + c0 + (q.w >> (24 + SHIFT)) * C);
 }
 
-template <int C, int T>
+template <int C, int T, int SHIFT = 0>
 __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
                                                            int32_t* __restrict__ out) {
   static_assert(T % 3 == 1, "the channel phase of a thread's vectors must advance by one per step");
-  __shared__ unsigned sh[768 * C];
+  constexpr int NB = 256 >> SHIFT;   // counters per channel
+  __shared__ unsigned sh[3 * NB * C];
   const int tid = threadIdx.x;
   const int frame = blockIdx.y;
   const int chunk = blockIdx.x;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
 
   long long i = v0 + tid;
   const unsigned ph = (unsigned)((head + i) % 3);
-  const unsigned o0 = ph * 256 * C + copy, o1 = ((ph + 1) % 3) * 256 * C + copy, o2 = ((ph + 2) % 3) * 256 * C + copy;
+  const unsigned o0 = ph * NB * C + copy, o1 = ((ph + 1) % 3) * NB * C + copy, o2 = ((ph + 2) % 3) * NB * C + copy;
   // Software pipeline over the steps every thread of the workgroup takes in full (six vectors =
   // two phase cycles per step): the loads of step k+1 are requested before the 96 counter updates
   // of step k.  The trip count is uniform and the loop has no conditional loads, so the compiler's
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
     a = ld(i); b = ld(i + T); c = ld(i + 2 * T);
     d = ld(i + 3 * T); e = ld(i + 4 * T); f = ld(i + 5 * T);
   }
-  for (int z = tid; z < 768 * C; z += T) sh[z] = 0;
+  for (int z = tid; z < 3 * NB * C; z += T) sh[z] = 0;
   __syncthreads();
   if (full > 0) {
     for (int it = 1; it < full; ++it) {
@@ -200,43 +203,43 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
       const uint4 na = ld(i), nb = ld(i + T), nc = ld(i + 2 * T);
       const uint4 nd = ld(i + 3 * T), ne = ld(i + 4 * T), nf = ld(i + 5 * T);
       __builtin_amdgcn_sched_barrier(0);
-      count16c<C>(sh, a, o0, o1, o2);
-      count16c<C>(sh, b, o1, o2, o0);
-      count16c<C>(sh, c, o2, o0, o1);
-      count16c<C>(sh, d, o0, o1, o2);
-      count16c<C>(sh, e, o1, o2, o0);
-      count16c<C>(sh, f, o2, o0, o1);
+      count16c<C, SHIFT>(sh, a, o0, o1, o2);
+      count16c<C, SHIFT>(sh, b, o1, o2, o0);
+      count16c<C, SHIFT>(sh, c, o2, o0, o1);
+      count16c<C, SHIFT>(sh, d, o0, o1, o2);
+      count16c<C, SHIFT>(sh, e, o1, o2, o0);
+      count16c<C, SHIFT>(sh, f, o2, o0, o1);
       a = na; b = nb; c = nc; d = nd; e = ne; f = nf;
     }
-    count16c<C>(sh, a, o0, o1, o2);
-    count16c<C>(sh, b, o1, o2, o0);
-    count16c<C>(sh, c, o2, o0, o1);
-    count16c<C>(sh, d, o0, o1, o2);
-    count16c<C>(sh, e, o1, o2, o0);
-    count16c<C>(sh, f, o2, o0, o1);
+    count16c<C, SHIFT>(sh, a, o0, o1, o2);
+    count16c<C, SHIFT>(sh, b, o1, o2, o0);
+    count16c<C, SHIFT>(sh, c, o2, o0, o1);
+    count16c<C, SHIFT>(sh, d, o0, o1, o2);
+    count16c<C, SHIFT>(sh, e, o1, o2, o0);
+    count16c<C, SHIFT>(sh, f, o2, o0, o1);
     i += 6 * T;
   }
   for (; i + 2 * T < v1; i += 3 * T) {
     uint4 a = ld(i), b = ld(i + T), c = ld(i + 2 * T);
-    count16c<C>(sh, a, o0, o1, o2);
-    count16c<C>(sh, b, o1, o2, o0);
-    count16c<C>(sh, c, o2, o0, o1);
+    count16c<C, SHIFT>(sh, a, o0, o1, o2);
+    count16c<C, SHIFT>(sh, b, o1, o2, o0);
+    count16c<C, SHIFT>(sh, c, o2, o0, o1);
   }
   if (i < v1) {
     uint4 a = ld(i);
-    count16c<C>(sh, a, o0, o1, o2);
+    count16c<C, SHIFT>(sh, a, o0, o1, o2);
     if (i + T < v1) {
       uint4 b = ld(i + T);
-      count16c<C>(sh, b, o1, o2, o0);
+      count16c<C, SHIFT>(sh, b, o1, o2, o0);
     }
   }
   if (chunk == 0) {
-    for (long long b = tid; b < head; b += T) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
-    for (long long b = tail + tid; b < nbytes; b += T) lds_inc(sh + ((unsigned)(b % 3) * 256 + p[b]) * C + copy);
+    for (long long b = tid; b < head; b += T) lds_inc(sh + ((unsigned)(b % 3) * NB + (p[b] >> SHIFT)) * C + copy);
+    for (long long b = tail + tid; b < nbytes; b += T) lds_inc(sh + ((unsigned)(b % 3) * NB + (p[b] >> SHIFT)) * C + copy);
   }
   __syncthreads();
   // fold the C copies of every counter into copy 0
-  for (int b = tid; b < 768; b += T) {
+  for (int b = tid; b < 3 * NB; b += T) {
     unsigned s = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) s += sh[b * C + ((c + tid) & (C - 1))];
@@ -244,6 +247,14 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   }
   __syncthreads();
   int32_t* o = out + (size_t)frame * 3 * bins;
+  if (SHIFT) {
+    // the counters ARE the output bins (bins == NB, checked by the launcher)
+    for (int ob = tid; ob < 3 * NB; ob += T) {
+      const unsigned v = sh[ob * C];
+      if (v) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, v);
+    }
+    return;
+  }
   for (int ob = tid; ob < 3 * bins; ob += T) {
     const int ch = ob / bins, bin = ob - ch * bins;
     const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
@@ -276,8 +287,17 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
   // ST_HIST_VARIANT selects the older kernels for A/B runs: 8 = eight copies per 256-thread
   // workgroup, 0 = one copy per wave.  Default: 32 lane-indexed copies, 1024 threads.
   static const int variant = getenv("ST_HIST_VARIANT") ? atoi(getenv("ST_HIST_VARIANT")) : 32;
+  // the reference's own bin count (16) gets counters for byte >> 4 directly: 6 KB of LDS instead of 96 KB, 256-thread workgroups,
+  // eight resident per CU -- clearing and folding shrink 16-fold and overlap with other workgroups' streaming
+  // (ST_HIST16=0 keeps the general kernel)
+  static const bool use16 = !(getenv("ST_HIST16") && atoi(getenv("ST_HIST16")) == 0);
   long long chunks;
-  if (variant == 32) {
+  if (variant == 32 && bins == 16 && use16) {
+    chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
+    long long max_chunks = (nvec + 3 * 256 * 4 - 1) / (3 * 256 * 4);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+  } else if (variant == 32) {
     chunks = chunks_for(ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
   } else {
     chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
@@ -294,7 +314,9 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     int32_t* o = out_dev + (size_t)f0 * 3 * bins;
     const dim3 grid((unsigned)chunks, (unsigned)nf);
     st_timed t(ctx, ST_K_HIST);
-    if (variant == 32)
+    if (variant == 32 && bins == 16 && use16)
+      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+    else if (variant == 32)
       hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 8)
       hipLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
