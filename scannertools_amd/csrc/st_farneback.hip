@@ -787,6 +787,189 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same one-pass pyramid with the levels split over three ROLES of four waves each (768-thread workgroups):
+// role 0 = levels 0 and 1, role 1 = level 2, role 2 = level 3, all reading the same staged rows.  A gfx950 wave issues
+// at most one vector-ALU instruction per ~8 clocks while a SIMD can issue one per 4 (scripts/ubench/valu1wave.hip), so a
+// launch that leaves one wave per SIMD -- a call of one or a few pairs -- runs at half the ALU rate; here the
+// instruction stream of a strip segment is cut in three (~120 / 90 / 110 instructions per source row instead of ~330
+// in one wave), three waves share a SIMD, and each role keeps only its own rings in registers.  Arithmetic and
+// association are those of k_pyr_fused (and of k_pyr0 / k_pyr_dec): bit-identical images.
+// ---------------------------------------------------------------------------------------------
+template <int ROLE>
+__device__ __forceinline__ void pyr_role_run(const PyrFusedArgs& a, unsigned (*srow)[PF_RB][PF_ROWDW]) {
+  const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
+  const int h = a.h, w = a.w;
+  const int SW = a.strip_w;
+  const int X0 = blockIdx.x * SW;
+  const int Y0 = blockIdx.y * a.rows_per_seg, Y1 = min(h, Y0 + a.rows_per_seg);
+  const size_t np = (size_t)h * w;
+  const uint8_t* __restrict__ g = a.gray + (size_t)blockIdx.z * np;
+  float* __restrict__ o0 = a.img0 + (size_t)blockIdx.z * np;
+  float* __restrict__ o1 = a.img1 + (size_t)blockIdx.z * (np >> 2);
+  float* __restrict__ o2 = a.img2 + (size_t)blockIdx.z * (np >> 4);
+  float* __restrict__ o3 = a.img3 + (size_t)blockIdx.z * (np >> 6);
+  const int u = wv * 32 + (lane & 31), half = lane >> 5;
+  const bool live = 4 * t < SW && X0 + 4 * t < w;
+  const bool live3 = 8 * u < SW && X0 + 8 * u < w;
+  const int hq = t & 3, hrow = (t >> 2) & 7;
+  const int hcol = hq < 2 ? X0 - 8 + 4 * hq : X0 + SW + 4 * (hq - 2);
+  const int hidx = hq < 2 ? hq : 2 + (SW >> 2) + (hq - 2);
+
+  // staging: role r fetches rows r, r + 3, r + 6 (< 8) of a batch, dword column t; role 0's threads 0..31 the halo
+  unsigned pre[3], preh = 0u;
+  auto fetch = [&](int ybase) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = ROLE + 3 * j;
+      if (r < PF_RB) pre[j] = pf_load4(g + (size_t)d_reflect101(ybase + r, h) * w, X0 + 4 * t, w);
+    }
+    if (ROLE == 0 && t < 32) preh = pf_load4(g + (size_t)d_reflect101(ybase + hrow, h) * w, hcol, w);
+  };
+  auto stash = [&](int buf) {
+    if (4 * t < SW) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int r = ROLE + 3 * j;
+        if (r < PF_RB) srow[buf][r][2 + t] = pre[j];
+      }
+    }
+    if (ROLE == 0 && t < 32) srow[buf][hrow][hidx] = preh;
+  };
+
+  float hm[4], hc[4], r1A[2][4], r1B[2][4];  // role 0
+  float r2A[10], r2B[10];                    // role 1
+  float r3[20];                              // role 2
+  if (ROLE == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hm[j] = hc[j] = 0.f; r1A[0][j] = r1A[1][j] = r1B[0][j] = r1B[1][j] = 0.f; }
+  } else if (ROLE == 1) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) r2A[j] = r2B[j] = 0.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 20; ++j) r3[j] = 0.f;
+  }
+
+  const int nb = (Y1 - Y0) / PF_RB + 2;
+  fetch(Y0 - PF_RB);
+  stash(0);
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    const int ybase = Y0 - PF_RB + b * PF_RB;
+    const int buf = b & 1;
+    if (b + 1 < nb) fetch(ybase + PF_RB);
+#pragma unroll
+    for (int r = 0; r < PF_RB; ++r) {
+      const int y = ybase + r;
+      const unsigned* __restrict__ s = srow[buf][r];
+      if (ROLE == 0) {
+        const unsigned d0 = s[t + 1], d1 = s[t + 2], d2 = s[t + 3];
+        float bb[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bb[k] = pf_byte(d0, k); bb[4 + k] = pf_byte(d1, k); bb[8 + k] = pf_byte(d2, k); }
+        {
+          float hp[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hp[j] = bb[4 + j] * a.k0[1] + (bb[3 + j] + bb[5 + j]) * a.k0[0];
+          const int yo = y - 1;
+          if (live && yo >= Y0 && yo < Y1) {
+            float4 v;
+            v.x = (hm[0] + hp[0]) * a.k0[0] + hc[0] * a.k0[1];
+            v.y = (hm[1] + hp[1]) * a.k0[0] + hc[1] * a.k0[1];
+            v.z = (hm[2] + hp[2]) * a.k0[0] + hc[2] * a.k0[1];
+            v.w = (hm[3] + hp[3]) * a.k0[0] + hc[3] * a.k0[1];
+            *reinterpret_cast<float4*>(o0 + (size_t)yo * w + X0 + 4 * t) = v;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hm[j] = hc[j]; hc[j] = hp[j]; }
+        }
+        {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float nA = pf_rowfilter<3>(bb + 3 + 2 * e, a.k1), nB = pf_rowfilter<3>(bb + 4 + 2 * e, a.k1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { r1A[e][j] = r1A[e][j + 1]; r1B[e][j] = r1B[e][j + 1]; }
+            r1A[e][3] = nA; r1B[e][3] = nB;
+          }
+          if ((r & 1) == 0) {
+            const int dy = (y - 2) >> 1;
+            if (live && dy >= (Y0 >> 1) && dy < (Y1 >> 1)) {
+              float2 v;
+              {
+                const float b00 = pf_colfilter<3>(r1A[0], a.k1), b01 = pf_colfilter<3>(r1B[0], a.k1);
+                const float b10 = pf_colfilter<3>(r1A[0] + 1, a.k1), b11 = pf_colfilter<3>(r1B[0] + 1, a.k1);
+                v.x = ((b00 + b01) + (b10 + b11)) * 0.25f;
+              }
+              {
+                const float b00 = pf_colfilter<3>(r1A[1], a.k1), b01 = pf_colfilter<3>(r1B[1], a.k1);
+                const float b10 = pf_colfilter<3>(r1A[1] + 1, a.k1), b11 = pf_colfilter<3>(r1B[1] + 1, a.k1);
+                v.y = ((b00 + b01) + (b10 + b11)) * 0.25f;
+              }
+              *reinterpret_cast<float2*>(o1 + (size_t)dy * (w >> 1) + (X0 >> 1) + 2 * t) = v;
+            }
+          }
+        }
+      } else if (ROLE == 1) {
+        const unsigned d0 = s[t + 1], d1 = s[t + 2], d2 = s[t + 3];
+        float bb[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bb[k] = pf_byte(d0, k); bb[4 + k] = pf_byte(d1, k); bb[8 + k] = pf_byte(d2, k); }
+        const float nA = pf_rowfilter<9>(bb + 1, a.k2), nB = pf_rowfilter<9>(bb + 2, a.k2);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { r2A[j] = r2A[j + 1]; r2B[j] = r2B[j + 1]; }
+        r2A[9] = nA; r2B[9] = nB;
+        if ((r & 3) == 2) {
+          const int dy = (y - 6) >> 2;
+          if (live && dy >= (Y0 >> 2) && dy < (Y1 >> 2)) {
+            const float b00 = pf_colfilter<9>(r2A, a.k2), b01 = pf_colfilter<9>(r2B, a.k2);
+            const float b10 = pf_colfilter<9>(r2A + 1, a.k2), b11 = pf_colfilter<9>(r2B + 1, a.k2);
+            const float q0 = b00 * 0.5f + b01 * 0.5f, q1 = b10 * 0.5f + b11 * 0.5f;
+            o2[(size_t)dy * (w >> 2) + (X0 >> 2) + t] = q0 * 0.5f + q1 * 0.5f;
+          }
+        }
+      } else {
+        unsigned dw[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dw[q] = s[2 * u + q];
+        float cb[21];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const unsigned d = __builtin_amdgcn_alignbyte(dw[q + 1 < 6 ? q + 1 : 5], dw[q], (unsigned)half);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * q + k < 21) cb[4 * q + k] = pf_byte(d, k);
+        }
+        const float n3 = pf_rowfilter<19>(cb + 2, a.k3);
+#pragma unroll
+        for (int j = 0; j < 19; ++j) r3[j] = r3[j + 1];
+        r3[19] = n3;
+        if (r == 5) {
+          const int dy = (y - 13) >> 3;
+          if (dy >= (Y0 >> 3) && dy < (Y1 >> 3)) {
+            const float c0 = pf_colfilter<19>(r3, a.k3), c1 = pf_colfilter<19>(r3 + 1, a.k3);
+            const float p0 = __shfl_xor(c0, 32), p1 = __shfl_xor(c1, 32);
+            if (half == 0 && live3) {
+              const float q0 = c0 * 0.5f + p0 * 0.5f, q1 = c1 * 0.5f + p1 * 0.5f;
+              o3[(size_t)dy * (w >> 3) + (X0 >> 3) + u] = q0 * 0.5f + q1 * 0.5f;
+            }
+          }
+        }
+      }
+    }
+    if (b + 1 < nb) stash(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(768) void k_pyr_roles(PyrFusedArgs a) {
+  __shared__ unsigned srow[2][PF_RB][PF_ROWDW];
+  const int role = threadIdx.x >> 8;  // wave-uniform; every role passes the same barriers
+  if (role == 0) pyr_role_run<0>(a, srow);
+  else if (role == 1) pyr_role_run<1>(a, srow);
+  else pyr_role_run<2>(a, srow);
+}
+
+// ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
 // vertically filtered values go through LDS for the horizontal pass.
@@ -805,18 +988,19 @@ constexpr int PE_RB = 4;     // rows per barrier
 // horizontal pass fails to overlap: 3.6 ms without stores, 4.4 ms with, per 257 1080p frames).
 constexpr int PE_OUT = 240;
 
-template <int N>
-__global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
+// One (strip bx, segment by) of frame z of one level; A carries the coefficients (a.c)
+template <int N, class A>
+__device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict__ img, float* __restrict__ Rbase, int h, int w,
+                                             int rows_per_seg, int bx, int by, int z) {
   __shared__ float sv[2][PE_RB][3][256];
   const int tid = threadIdx.x;
-  const int h = a.h, w = a.w;
   const int np = h * w;
-  const float* __restrict__ I = a.img + (size_t)blockIdx.z * (size_t)np;
-  float* __restrict__ R = a.R + (size_t)blockIdx.z * 5 * (size_t)np;
-  const int x = (int)blockIdx.x * PE_OUT - N + tid;
+  const float* __restrict__ I = img + (size_t)z * (size_t)np;
+  float* __restrict__ R = Rbase + (size_t)z * 5 * (size_t)np;
+  const int x = bx * PE_OUT - N + tid;
   const int xc = d_clamp(x, 0, w - 1);
-  const int y0 = blockIdx.y * a.rows_per_seg;
-  const int y1 = min(h, y0 + a.rows_per_seg);
+  const int y0 = by * rows_per_seg;
+  const int y1 = min(h, y0 + rows_per_seg);
   const bool writer = tid >= N && tid < N + PE_OUT && x < w;
 
   // ring[j] = source row (y - N + j) of this column for the batch starting at row y
@@ -888,6 +1072,40 @@ __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
     }
     buf ^= 1;
   }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
+  polyexp_body<N>(a, a.img, a.R, a.h, a.w, a.rows_per_seg, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several pyramid levels in ONE launch (small batches: the expansions of the coarse levels are launches of a few dozen
+// workgroups each, and every dependent launch costs its ramp and drain): blockIdx.x runs over the (strip, segment)
+// pairs of the listed levels, blockIdx.y over the frames.  Same body, so the same bits.
+struct PolyLevel {
+  const float* img;
+  float* R;
+  int h, w, rows_per_seg, strips, block0;  // block0: first linear block of this level
+};
+struct PolyArgsML {
+  PolyLevel lv[4];
+  int nlv;
+  PolyCoef c;
+};
+template <int N>
+__global__ __launch_bounds__(256) void k_polyexp_ml(PolyArgsML a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < a.nlv && (int)blockIdx.x >= a.lv[i].block0) l = i;
+  // select the level's fields with scalar compares (keeps the argument block in scalar registers)
+  const float* img = a.lv[0].img; float* R = a.lv[0].R;
+  int h = a.lv[0].h, w = a.lv[0].w, rows = a.lv[0].rows_per_seg, strips = a.lv[0].strips, b0 = a.lv[0].block0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (l == i) { img = a.lv[i].img; R = a.lv[i].R; h = a.lv[i].h; w = a.lv[i].w; rows = a.lv[i].rows_per_seg; strips = a.lv[i].strips; b0 = a.lv[i].block0; }
+  const int local = (int)blockIdx.x - b0;
+  polyexp_body<N>(a, img, R, h, w, rows, local % strips, local / strips, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1444,6 +1662,7 @@ struct IterArgs {
   float* flow_out;          // per pair (h,w,2), or
   float* const* flow_ptrs;  // device table of per-pair output frames (used when non-null)
   int h, w, ch, cw, rows_per_seg;
+  int out_w;                // k_flow_iter_roles: output columns per strip (multiple of 8)
   double scale_x, scale_y;  // coarse/fine size ratios as cv::resize computes them
   float mul;                // 1/pyr_scale
   double scale;             // 1/(block_size^2)
@@ -1875,6 +2094,293 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_flow_iter_roles: the marching iteration with its three kinds of work on three kinds of waves.
+//
+// Why: k_flow_iter3 needs ~230 registers (the 16-row ring of M, the running sums, a batch of gathers in flight, the
+// solver's temporaries), so two of its waves share a SIMD -- and a gfx950 wave issues at most one vector-ALU instruction
+// per ~8 clocks (scripts/ubench/valu1wave.hip): a launch that leaves one workgroup per compute unit (one pair at 1080p:
+// 272 workgroups) runs at half the ALU rate with every memory and LDS latency exposed, ~1 us per row.  Here a strip of
+// the frame is marched by ONE workgroup of 3 x NCW waves in three roles, pipelined through LDS in steps of FR_G = 4
+// rows with one barrier per step:
+//   makers   thread = column: flow_in -> UpdateMatrices (the gathers, ~100 instructions per pixel) -> M row -> LDS
+//   summers  thread = column: the 16-slot ring of M rows and the double running column sums (anchored every 32 rows)
+//            -> column sums as float -> LDS; then, for the rows of the PREVIOUS step, thread = (row, 8-pixel segment,
+//            channel): the fresh 15-term horizontal sum at the segment's first column and the four slides to its
+//            fifth -> both sums as double -> LDS
+//   solvers  thread = (row, half segment): starts from the handed-over sum, three slides, four 2x2 solves, flow stored
+//            straight to global memory
+// (the horizontal chain of a segment -- fresh sum at column 8 i, seven slides -- is the longest serial piece of the
+// iteration: 700 instructions in one thread; cut this way no thread runs more than ~400 per step).  No role needs more
+// than 128 registers, so 12 or 15 waves fit a compute unit; they sit on the four SIMDs round-robin (one wave of each role
+// per SIMD) and interleave at the full issue rate, the solves of step s overlapping the gathers of step s + 3.
+// Arithmetic, operand order and association are k_flow_iter3's (the canonical association: vertical anchors at rows
+// 32 j, horizontal anchors at columns 8 i; the slides of a segment are the same operations in the same order whoever
+// performs them), so the two kernels -- and k_flow_iter_tile -- agree bit for bit and the choice between them is a
+// scheduling matter.
+// Stream of M rows of a segment [y0, y1): index k = 0 .. 15 + (y1 - y0), row(k) = clamp(y0 - 8 + k) (k = 0 is a dummy
+// that aligns output row j = k - 16 with the 4-row steps).  Step s: the makers produce k = 4 s .. 4 s + 3; the summers
+// turn the rows of step s - 1 into column sums and the column sums of step s - 2 into horizontal sums; the solvers
+// finish the rows whose horizontal sums were formed in step s - 1.
+// LDS: M rows double-buffered, column sums in three generations (written, summed horizontally, slid by the solvers),
+// horizontal sums double-buffered: 129 KB (NCW = 4), 158 KB (NCW = 5).
+// ---------------------------------------------------------------------------------------------
+constexpr int FR_G = 4;
+template <int NCW>
+struct FrGeom {
+  static constexpr int COLS = 64 * NCW, OUTMAX = COLS - 2 * B2_HALO, PADW = COLS + COLS / 8;
+  static constexpr int NSEGMAX = OUTMAX / F3_SW;
+  static constexpr int THREADS = 3 * COLS;
+  static_assert(FR_G * 2 * NSEGMAX <= COLS, "one solver thread per (row, half segment)");
+};
+
+template <int NCW, int MODE>
+__global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterArgs a) {
+  typedef FrGeom<NCW> G;
+  constexpr int M = 7, W = 15, RB = 2;
+  __shared__ float Mb[2][FR_G][5][G::COLS];
+  __shared__ float Vs[3][FR_G][5][G::PADW];
+  __shared__ double Ts[2][FR_G][2 * G::NSEGMAX][5];
+  const int tid = threadIdx.x;
+  const int role = tid < G::COLS ? 0 : (tid < 2 * G::COLS ? 1 : 2);  // wave-uniform
+  const int h = a.h, w = a.w;
+  const int np = h * w;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  const int pr = bz;
+  const int y0 = by * a.rows_per_seg;
+  const int y1 = min(h, y0 + a.rows_per_seg);
+  const int SM = 4 + (y1 - y0 + FR_G - 1) / FR_G;  // maker steps 0 .. SM - 1
+  const int T = SM + 3;                            // column sums 1 .. SM, horizontal sums 6 .. SM + 1, solves 7 .. SM + 2
+  const int nseg = a.out_w / F3_SW;
+
+  if (role == 0) {
+    // ---------------- makers ----------------
+    const int t = tid;
+    const int x = (int)bx * a.out_w - B2_HALO + t;
+    const int xc = d_clamp(x, 0, w - 1);
+    const float* __restrict__ R0;
+    const float* __restrict__ R1;
+    if (a.pairs) {
+      R0 = a.R + (size_t)a.pairs[2 * pr] * 5 * (size_t)np;
+      R1 = a.R + (size_t)a.pairs[2 * pr + 1] * 5 * (size_t)np;
+    } else {
+      R0 = a.R;
+      R1 = a.R1_direct;
+    }
+    const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
+    const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
+    const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
+    auto rowk = [&](int k) { return d_clamp(y0 - 8 + k, 0, h - 1); };
+    // software pipeline over batches of RB rows (as k_flow_iter3): gathers of the next batch in flight while this one
+    // is finished, flows one batch further ahead, their loads one more
+    float2 fcur[RB], fnext[RB];
+    UmLoads L[RB];
+    FlowRaw raw[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      fcur[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(r));
+      um_issue(R0, R1, np, h, w, xc, rowk(r), fcur[r], L[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) fnext[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(RB + r));
+#pragma unroll
+    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(2 * RB + r), raw[r]);
+    for (int sb = 0; sb < T; sb += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = sb + u;
+        if (s < T) {
+          if (s < SM) {
+#pragma unroll
+            for (int bb = 0; bb < FR_G / RB; ++bb) {
+              const int k0 = FR_G * s + bb * RB;
+#pragma unroll
+              for (int r = 0; r < RB; ++r) {
+                float m[5];
+                um_finish(L[r], h, w, xc, rowk(k0 + r), fcur[r], m);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) Mb[u][bb * RB + r][c][t] = m[c];
+                fcur[r] = fnext[r];
+                um_issue(R0, R1, np, h, w, xc, rowk(k0 + RB + r), fcur[r], L[r]);
+              }
+#pragma unroll
+              for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, rowk(k0 + 2 * RB + r), raw[r]);
+#pragma unroll
+              for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(k0 + 3 * RB + r), raw[r]);
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  } else if (role == 1) {
+    // ---------------- summers ----------------
+    const int t = tid - G::COLS;
+    const int vpos = f3_pos(t);
+    float ring[F3_RING][5];
+    double vs[5];
+#pragma unroll
+    for (int s2 = 0; s2 < F3_RING; ++s2)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) ring[s2][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) vs[c] = 0;
+    const int nitem = FR_G * nseg * 5;  // horizontal-sum items of a step: (row, segment, channel), segment fastest
+    int vgen = 0;  // generation (mod 3) of Vs this step's column sums go to
+    for (int sb = 0; sb < T; sb += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = sb + u;
+        if (s < T) {
+          const int c4 = (u + 3) & 3;  // (s - 1) mod 4: compile-time
+          // ---- (i) column sums of the rows the makers produced in step s - 1
+          if (s >= 1 && s <= SM) {
+            const int cstep = s - 1;
+            if (cstep < 4) {
+              // prologue: rows k = 4 cstep + i into ring slot k (cstep == c4 here)
+#pragma unroll
+              for (int i = 0; i < FR_G; ++i)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) ring[4 * c4 + i][c] = Mb[c4 & 1][i][c][t];
+              if (c4 == 3) {
+                // window of output row 0 = slots 1 .. 15 (rows y0 - 7 .. y0 + 7)
+                if (y0 == 0) {
+                  // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
+#pragma unroll
+                  for (int c = 0; c < 5; ++c) vs[c] = (double)(ring[M + 1][c] * (float)(M + 2));
+#pragma unroll
+                  for (int yy = 1; yy < M; ++yy)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) vs[c] += (double)ring[M + 1 + yy][c];
+#pragma unroll
+                  for (int c = 0; c < 5; ++c) {
+                    const float d = ring[2 * M + 1][c] - ring[M + 1][c];
+                    vs[c] += d;
+                  }
+                } else {
+#pragma unroll
+                  for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+                  for (int s2 = 1; s2 <= W; ++s2)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s2][c];
+                }
+              }
+            } else {
+              // entering rows k = 4 cstep + i, output rows j = k - 16; ring slot of k = 4 c4 + i
+              if (c4 == 0 && cstep > 4 && ((FR_G * cstep) & 31) == 16) {
+                // anchor rows 32 j > 0: fresh sum of the window (slots 1 .. 15) in row order
+#pragma unroll
+                for (int c = 0; c < 5; ++c) vs[c] = 0;
+#pragma unroll
+                for (int s2 = 1; s2 <= W; ++s2) {
+#pragma unroll
+                  for (int c = 0; c < 5; ++c) vs[c] += (double)ring[s2][c];
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+#pragma unroll
+              for (int i = 0; i < FR_G; ++i) {
+                const int slot = 4 * c4 + i;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                  const float m = Mb[c4 & 1][i][c][t];
+                  Vs[vgen][i][c][vpos] = (float)vs[c];
+                  const float d = m - ring[(slot + 1) & 15][c];
+                  vs[c] += d;
+                  ring[slot][c] = m;
+                }
+              }
+            }
+          }
+          // ---- (ii) horizontal sums of the column sums written in step s - 1 (generation vgen - 1): per (row, segment,
+          // channel) the fresh 15-term sum at the segment's first column, then the four slides to its fifth
+          if (s >= 6 && s <= SM + 1) {
+            const int pg = vgen == 0 ? 2 : vgen - 1;
+            for (int e = t; e < nitem; e += G::COLS) {
+              const int sg = e % nseg, rc = e / nseg, c = rc % 5, r = rc / 5;
+              const float* __restrict__ vp = &Vs[pg][r][c][9 + 9 * sg];  // f3_pos(8 + 8 sg)
+              double acc = vp[-8];
+#pragma unroll
+              for (int k = -6; k <= 7; ++k) acc += (double)vp[k < 0 ? k - 1 : k];
+              Ts[u & 1][r][2 * sg][c] = acc;
+#pragma unroll
+              for (int i = 1; i <= 4; ++i) acc += (double)vp[8 + i] - (double)vp[i - 9];
+              Ts[u & 1][r][2 * sg + 1][c] = acc;
+            }
+          }
+          if (s >= 5 && s <= SM) vgen = vgen == 2 ? 0 : vgen + 1;
+          __syncthreads();
+        }
+      }
+    }
+  } else {
+    // ---------------- solvers ----------------
+    const int t = tid - 2 * G::COLS;
+    const int nq = 2 * nseg;
+    const int r = t / nq, q = t - r * nq;
+    const int sg = q >> 1, hf = q & 1;
+    const bool item = t < FR_G * nq;
+    float* fout = a.flow_ptrs ? st_gl(a.flow_ptrs[pr]) : a.flow_out + (size_t)pr * 2 * (size_t)np;
+    const int x0 = (int)bx * a.out_w + sg * F3_SW + 4 * hf;   // frame column of the first of this thread's four pixels
+    const bool wide = !(w & 1) && (((uintptr_t)fout) & 15) == 0;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    int rgen = 0;  // generation of Vs the solver reads
+    for (int sb = 0; sb < T; sb += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = sb + u;
+        if (s < T) {
+          const int y = y0 + FR_G * (s - 7) + r;
+          if (s >= 7 && item && y < y1 && x0 < w) {
+            // sums formed in step s - 1 (Ts[(s - 1) & 1]) over the column sums of generation rgen
+            const float* __restrict__ vrow = &Vs[rgen][r][0][9 + 9 * sg + 4 * hf];
+            double tt[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) tt[c] = Ts[(u + 1) & 1][r][q][c];
+            float2 res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (i > 0) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                  const float* vp = vrow + c * G::PADW;
+                  tt[c] += (double)vp[8 + i] - (double)vp[i - 9];
+                }
+              }
+              const double g11 = tt[0] * a.scale, g12 = tt[1] * a.scale, g22 = tt[2] * a.scale;
+              const double h1 = tt[3] * a.scale, h2 = tt[4] * a.scale;
+              const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
+              res[i] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+            }
+            float* dst = fout + 2 * ((size_t)y * w + x0);
+            if (wide && x0 + 4 <= w) {
+#pragma unroll
+              for (int i = 0; i < 4; i += 2) {
+                f4v v4;
+                v4.x = res[i].x; v4.y = res[i].y; v4.z = res[i + 1].x; v4.w = res[i + 1].y;
+                __builtin_nontemporal_store(v4, reinterpret_cast<f4v*>(dst + 2 * i));
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (x0 + i < w) {
+                  f2v v2;
+                  v2.x = res[i].x; v2.y = res[i].y;
+                  __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(dst + 2 * i));
+                }
+            }
+          }
+          if (s >= 7) rgen = rgen == 2 ? 0 : rgen + 1;
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_flow_iter_tile: the same iteration for launches too small to fill the chip by marching
 // (few pairs, coarse pyramid levels).  A workgroup produces one 32 x 32 tile: UpdateMatrices on
 // the tile plus its 7-pixel apron (replicated at the frame border, as the box filter's
@@ -2196,7 +2702,13 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   if (rows < min_rows) rows = h < min_rows ? h : min_rows;
   a.rows_per_seg = rows;
   st_timed t(ctx, ST_K_PYR);
-  if (gray) hipLaunchKernelGGL(k_pyr_fused<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
+  // role-split instance (k_pyr_roles): ST_PYR_ROLES=0 never, 1 always, default by launch size (experiments below)
+  const int roles_env = ctx->pyr_roles;
+  static const long long roles_max = getenv("ST_PYR_ROLES_MAX") ? atoll(getenv("ST_PYR_ROLES_MAX")) : 4096;
+  const long long wgs = (long long)strips * ((h + rows - 1) / rows) * n;
+  const bool roles = gray && (roles_env == 1 || (roles_env != 0 && wgs <= roles_max));
+  if (roles) hipLaunchKernelGGL(k_pyr_roles, dim3(strips, (h + rows - 1) / rows, n), dim3(768), 0, ctx->stream, a);
+  else if (gray) hipLaunchKernelGGL(k_pyr_fused<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_pyr_fused<true>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
@@ -2214,6 +2726,55 @@ int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_
   else hipLaunchKernelGGL(k_polyexp<7>, grid, dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
+}
+
+// Expansions of several levels (imgs[k], geom[k], R[k] for k in ks[0..nk)) in one launch; the listed order is the
+// dispatch order (largest level first, so that the small ones fill its tail).
+int launch_polyexp_ml(st_ctx* ctx, float* const* imgs, const LevelGeom* geom, float* const* R, const int* ks, int nk, int n,
+                      int poly_n, double poly_sigma) {
+  if (nk < 1 || nk > 4) return st_set_error(ctx, ST_ERR_INVALID, "polyexp: bad level list");
+  PolyArgsML a;
+  memset(&a, 0, sizeof(a));
+  poly_prepare(poly_n, poly_sigma, &a.c);
+  a.nlv = nk;
+  int blocks = 0;
+  for (int i = 0; i < nk; ++i) {
+    const LevelGeom& g = geom[ks[i]];
+    PolyLevel& l = a.lv[i];
+    l.img = imgs[ks[i]]; l.R = R[ks[i]]; l.h = g.lh; l.w = g.lw;
+    l.strips = (g.lw + PE_OUT - 1) / PE_OUT;
+    l.rows_per_seg = polyexp_rows(ctx, g.lh, l.strips, n, poly_n);
+    l.block0 = blocks;
+    blocks += l.strips * ((g.lh + l.rows_per_seg - 1) / l.rows_per_seg);
+  }
+  st_timed t(ctx, ST_K_POLYEXP);
+  if (poly_n == 5) hipLaunchKernelGGL(k_polyexp_ml<5>, dim3(blocks, n), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_polyexp_ml<7>, dim3(blocks, n), dim3(256), 0, ctx->stream, a);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
+
+// The three pointer / index tables of a pass, written by ONE small launch whose arguments carry the values (a call
+// of a few pairs is a chain of short dependent launches: three pageable host-to-device copies ahead of it cost 5 us
+// each on the stream).  Larger tables take the copies.
+constexpr int kTabMax = 40;
+struct TablesArg {
+  const uint8_t** d_frames;
+  float** d_outs;
+  int* d_pairs;
+  int nf, npairs;
+  const uint8_t* frames[kTabMax];
+  float* outs[kTabMax];
+  int pairs[2 * kTabMax];
+};
+__global__ __launch_bounds__(64) void k_set_tables(TablesArg a) {
+  const int t = threadIdx.x;
+  if (t < a.nf) a.d_frames[t] = a.frames[t];
+  if (t < a.npairs) {
+    a.d_outs[t] = a.outs[t];
+    a.d_pairs[2 * t] = a.pairs[2 * t];
+    a.d_pairs[2 * t + 1] = a.pairs[2 * t + 1];
+  }
 }
 
 int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
@@ -2270,6 +2831,52 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     else hipLaunchKernelGGL(k_flow_iter_tile<FLOW_ZERO>, grid, dim3(256), 0, ctx->stream, a);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
+  }
+  // Role-split marching kernel (k_flow_iter_roles, one 10- or 13-wave workgroup per compute unit): ST_ITER_ROLES=1
+  // always, 0 never; default: by predicted time against k_flow_iter3's two 4-wave workgroups per unit (below).
+  const int roles_env = ctx->roles_mode, roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
+  if (roles_env != 0) {
+    const int periods = (a.h + F3_ANCHOR - 1) / F3_ANCHOR;
+    int best_ncw = 0, best_out = 0, best_rows = 0;
+    double best = 1e300;
+    for (int ncw = 5; ncw >= 4; --ncw) {
+      if (roles_ncw && ncw != roles_ncw) continue;
+      const int outmax = 64 * ncw - 2 * B2_HALO;
+      const int strips = (a.w + outmax - 1) / outmax;
+      const int out_w = ((a.w + strips - 1) / strips + 7) / 8 * 8;
+      for (int segs = 1; segs <= periods; ++segs) {
+        const int r = (periods + segs - 1) / segs * F3_ANCHOR;
+        const long long nseg = (a.h + r - 1) / r;
+        const long long wgs = (long long)strips * n_pairs * nseg;
+        const long long rounds = (wgs + ctx->num_cus - 1) / ctx->num_cus;
+        // a round costs its rows plus the 16-row prologue and the two-step pipeline tail; a 13-wave workgroup's row is
+        // 5/4 of a 10-wave one's
+        const double cost = (double)rounds * (r + 16 + 3 * FR_G) * (ncw == 5 ? 1.25 : 1.0);
+        if (cost < best * 0.999) { best = cost; best_ncw = ncw; best_out = out_w; best_rows = r; }
+      }
+    }
+    if (roles_rows >= F3_ANCHOR && roles_rows % F3_ANCHOR == 0) best_rows = roles_rows;
+    if (best_ncw && roles_env == 1) {
+      a.rows_per_seg = best_rows;
+      a.out_w = best_out;
+      const int strips = (a.w + best_out - 1) / best_out;
+      dim3 grid(strips, (a.h + best_rows - 1) / best_rows, n_pairs);
+      st_timed t(ctx, ST_K_BLUR_UPDATE);
+      const int mode = a.coarse ? FLOW_COARSE : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
+      if (best_ncw == 5) {
+        const dim3 blk(FrGeom<5>::THREADS);
+        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
+      } else {
+        const dim3 blk(FrGeom<4>::THREADS);
+        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
+      }
+      ST_HIP(ctx, hipGetLastError());
+      return ST_OK;
+    }
   }
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
   // Segment height = whole anchor periods (32 rows).  Two workgroups are resident per CU (register and
@@ -2375,9 +2982,20 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   float** d_outs = (float**)st_ws_alloc(ctx, sizeof(void*) * npairs);
   if (!gray || !img || !M[0] || !M[1] || !cflow[0] || !cflow[1] || !d_frames || !d_pairs || !d_outs || !R[levels])
     return st_set_error(ctx, ST_ERR_OOM, "farneback: scratch plan exhausted");
-  ST_HIP(ctx, hipMemcpyAsync(d_frames, frames, sizeof(void*) * nf, hipMemcpyHostToDevice, ctx->stream));
-  ST_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, ctx->stream));
-  ST_HIP(ctx, hipMemcpyAsync(d_outs, outs, sizeof(void*) * npairs, hipMemcpyHostToDevice, ctx->stream));
+  if (nf <= kTabMax && npairs <= kTabMax) {
+    TablesArg ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.d_frames = d_frames; ta.d_outs = d_outs; ta.d_pairs = d_pairs; ta.nf = nf; ta.npairs = npairs;
+    for (int i = 0; i < nf; ++i) ta.frames[i] = frames[i];
+    for (int i = 0; i < npairs; ++i) { ta.outs[i] = outs[i]; ta.pairs[2 * i] = pairs[2 * i]; ta.pairs[2 * i + 1] = pairs[2 * i + 1]; }
+    static_assert(kTabMax <= 64, "one thread per table entry");
+    hipLaunchKernelGGL(k_set_tables, dim3(1), dim3(64), 0, ctx->stream, ta);
+    ST_HIP(ctx, hipGetLastError());
+  } else {
+    ST_HIP(ctx, hipMemcpyAsync(d_frames, frames, sizeof(void*) * nf, hipMemcpyHostToDevice, ctx->stream));
+    ST_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, ctx->stream));
+    ST_HIP(ctx, hipMemcpyAsync(d_outs, outs, sizeof(void*) * npairs, hipMemcpyHostToDevice, ctx->stream));
+  }
 
   // per-frame stages: each distinct frame once
   bool aligned4 = true;
@@ -2394,10 +3012,16 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   // on a second stream meanwhile; each level's first iteration waits for its expansion.
   // (ST_NO_OVERLAP=1 keeps everything on one stream.)
   static const bool no_overlap = getenv("ST_NO_OVERLAP") != nullptr;
-  const bool overlap = pyr1 && fused && levels >= 1 && levels < 7 && npairs <= 16 && !no_overlap;
+  const bool overlap = pyr1 && fused && levels >= 1 && levels <= 4 && npairs <= 16 && !no_overlap;
   if (overlap) {
+    // level 0 (three quarters of the expansion work) on the second stream, which has the LOWEST priority so that its
+    // workgroups fill the compute units the coarse levels' iterations leave idle instead of queueing ahead of them
+    // (a level-3 iteration of 8 pairs measured 98 us instead of 27 behind the level-0 expansion of equal priority);
+    // the coarse levels' expansions in ONE launch on the main stream, largest level first.
     if (!ctx->aux_stream) {
-      ST_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+      int lo = 0, hi = 0;
+      ST_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = least urgent
+      ST_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
       for (auto& e : ctx->aux_events) ST_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     hipEvent_t pyr_done = ctx->aux_events[7];
@@ -2405,14 +3029,13 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     ST_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, pyr_done, 0));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->aux_stream;  // launch helpers (and their timing brackets) use ctx->stream
-    int st = ST_OK;
-    for (int k = levels - 1; k >= 0 && st == ST_OK; --k) {
-      st = launch_polyexp(ctx, imgs[k], nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]);
-      if (st == ST_OK && hipEventRecord(ctx->aux_events[k], ctx->aux_stream) != hipSuccess) st = ST_ERR_HIP;
-    }
+    int st = launch_polyexp(ctx, imgs[0], nf, geom[0].lh, geom[0].lw, p.poly_n, p.poly_sigma, R[0]);
+    if (st == ST_OK && hipEventRecord(ctx->aux_events[0], ctx->aux_stream) != hipSuccess) st = ST_ERR_HIP;
     ctx->stream = main_stream;
     if (st != ST_OK) return st == ST_ERR_HIP ? st_set_error(ctx, ST_ERR_HIP, "farneback: second-stream launch failed") : st;
-    ST_TRY(launch_polyexp(ctx, imgs[levels], nf, geom[levels].lh, geom[levels].lw, p.poly_n, p.poly_sigma, R[levels]));
+    int ks[4], nk = 0;
+    for (int k = 1; k <= levels; ++k) ks[nk++] = k;
+    ST_TRY(launch_polyexp_ml(ctx, imgs, geom.data(), R.data(), ks, nk, nf, p.poly_n, p.poly_sigma));
   } else {
     for (int k = levels; k >= 0; --k) {
       if (!pyr1) ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
@@ -2427,7 +3050,7 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
     for (int k = levels; k >= 0; --k) {
       const int lh = geom[k].lh, lw = geom[k].lw;
-      if (overlap && k < levels) ST_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_events[k], 0));
+      if (overlap && k == 0) ST_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_events[0], 0));
       for (int it = 0; it < p.num_iters; ++it) {
         const bool last = it == p.num_iters - 1;
         IterArgs q;

@@ -31,6 +31,9 @@ struct st_ctx {
   int tile_mode = -1;
   long long tile_px = 600000;
   bool fold_gray = false;  // ST_PYR_FOLD_GRAY=1: luma conversion inside the one-pass pyramid (slower; A/B switch)
+  // role-split kernels (scheduling switches like tile_mode, read when the context is created; results do not depend on them):
+  // ST_ITER_ROLES / ST_PYR_ROLES: -1 by launch size (default), 0 never, 1 always; ST_ROLES_NCW: 0 = by cost, 4 or 5 column waves
+  int roles_mode = -1, roles_ncw = 0, roles_rows = 0, pyr_roles = -1;
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_events[8] = {};
   // bump-allocated scratch

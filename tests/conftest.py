@@ -39,7 +39,11 @@ def hip_ctx():
 # flow-iteration scheduling modes (the environment is read when a context is created):
 #   default  kernel by launch size       march  marching kernel (k_flow_iter3) everywhere
 #   tile     tile kernel everywhere
-FLOW_MODES = {"default": {}, "march": {"ST_ITER_TILE": "0"}, "tile": {"ST_ITER_TILE": "1"},
+#   roles4 / roles5  role-split marching kernel (k_flow_iter_roles) with 4 / 5 column waves wherever a launch marches,
+#                    and the role-split one-pass pyramid
+FLOW_MODES = {"default": {}, "march": {"ST_ITER_TILE": "0", "ST_ITER_ROLES": "0", "ST_PYR_ROLES": "0"}, "tile": {"ST_ITER_TILE": "1"},
+              "roles4": {"ST_ITER_TILE": "0", "ST_ITER_ROLES": "1", "ST_ROLES_NCW": "4", "ST_PYR_ROLES": "1"},
+              "roles5": {"ST_ITER_TILE": "0", "ST_ITER_ROLES": "1", "ST_ROLES_NCW": "5", "ST_PYR_ROLES": "1"},
               # the luma conversion folded into the one-pass pyramid instead of the separate gray pass
               "foldgray": {"ST_PYR_FOLD_GRAY": "1"}}
 
@@ -48,7 +52,7 @@ def make_mode_ctx(mode, **kw):
     """A HipContext created under the environment of one scheduling mode."""
     from scannertools_amd.hip import HipContext
     env = FLOW_MODES[mode]
-    keys = ("ST_ITER_TILE", "ST_PYR_FOLD_GRAY")
+    keys = ("ST_ITER_TILE", "ST_PYR_FOLD_GRAY", "ST_ITER_ROLES", "ST_ROLES_NCW", "ST_ROLES_ROWS", "ST_PYR_ROLES")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:

@@ -215,17 +215,18 @@ def _iteration_cases(h, w):
 @pytest.mark.parametrize("h,w", ITER_SIZES)
 def test_flow_iteration_parity(mode_ctxs, h, w):
     """One fused iteration == UpdateMatrices followed by UpdateFlow_Blur, for the three flow sources,
-    under the marching kernel (k_flow_iter3) and the tile kernel (k_flow_iter_tile) alike; and the two
-    kernels agree bit for bit."""
+    under the marching kernel (k_flow_iter3), the tile kernel (k_flow_iter_tile) and the role-split marching kernel
+    (k_flow_iter_roles, 4 and 5 column waves) alike; and all of them agree bit for bit."""
     R0, R1, cases = _iteration_cases(h, w)
     r0, r1 = cu(R0), cu(R1)
     for name, (kw, ref) in cases.items():
         outs = {}
-        for mode in ("march", "tile"):
+        for mode in ("march", "tile", "roles4", "roles5"):
             got = mode_ctxs[mode].flow_iteration(r0, r1, **{k: (cu(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
             outs[mode] = got.cpu().numpy()
             assert np.abs(outs[mode] - ref).max() <= 1e-4, (name, mode, np.abs(outs[mode] - ref).max())
-        np.testing.assert_array_equal(outs["march"], outs["tile"], err_msg=name)
+        for mode in ("tile", "roles4", "roles5"):
+            np.testing.assert_array_equal(outs["march"], outs[mode], err_msg="%s %s" % (name, mode))
 
 
 # ---------------------------------------------------------------- A3 end to end
@@ -304,7 +305,7 @@ def test_schedules_agree_bitwise(mode_ctxs):
     for (h, w, n) in ((135, 240, 3), (203, 317, 4), (544, 960, 5), (256, 1032, 2)):
         d = cu(texture_stream(h, n, h, w)[0])
         ref = mode_ctxs["march"].optical_flow(d).cpu().numpy()
-        for mode in ("default", "tile", "foldgray"):
+        for mode in ("default", "tile", "foldgray", "roles4", "roles5"):
             np.testing.assert_array_equal(mode_ctxs[mode].optical_flow(d).cpu().numpy(), ref, err_msg="%s %dx%d" % (mode, h, w))
 
 
