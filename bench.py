@@ -91,6 +91,18 @@ def iter_model_bytes(h, w, pairs):
     return (248 * sum_p + 8 * (sum_p - p0)) * pairs, 284 * sum_p
 
 
+def iter_as_built_bytes(h, w, pairs):
+    """Compulsory HBM bytes of the flow-iteration launches AS BUILT, per step of `pairs` pairs: every
+    launch reads R0 (20 B/px) and gathers R1 (20 B/px) and writes a flow field (8 B/px); it reads the previous
+    iteration's field (8 B/px) on iterations 2 and 3, the coarser level's field (8 B per coarse pixel) on the first
+    iteration of a finer level, nothing on the coarsest level's first.  M is never in memory, so it is not priced.
+    3 iterations per level: sum_k (3*48 + 2*8) P_k + 8 (sum P - P_0)."""
+    geom = fb_geometry(h, w)
+    sum_p = sum(lh * lw for lh, lw in geom)
+    p0 = geom[0][0] * geom[0][1]
+    return (160 * sum_p + 8 * (sum_p - p0)) * pairs
+
+
 def host_threads():
     """Threads the CPU baseline may use: the cores this process may run on, bounded so that the
     oracle instances (about 0.2 GB each at 1080p) stay inside half of the available memory."""
@@ -158,9 +170,11 @@ def timed_flow_hist(torch, ctx, _native, batches, B, bins, steps, warmup, barrie
     for i in range(warmup):
         step(i)
     barrier()
-    # (ST_BENCH_NO_KERNEL_TIMING=1: experiments on small batches, where the HIP-event brackets around every
-    # flow-iteration launch cost more than the launch boundary itself)
-    ctx.timing_enable([] if os.environ.get("ST_BENCH_NO_KERNEL_TIMING") else [_native.K_BLUR_UPDATE])
+    # The HIP-event brackets around every flow-iteration launch cost ~8 us each on the stream (two barrier packets): below
+    # 32 pairs per step that is a tenth to a quarter of the step (1 pair: 500 us with, 395 us without), so small steps run
+    # without them and carry no kernel roofline (ST_BENCH_NO_KERNEL_TIMING=1 forces that for any size).
+    kernel_timing = B >= 32 and not os.environ.get("ST_BENCH_NO_KERNEL_TIMING")
+    ctx.timing_enable([_native.K_BLUR_UPDATE] if kernel_timing else [])
     ctx.timing_reset()
     barrier()
     t0 = time.perf_counter()
@@ -198,6 +212,52 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                                   "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / max(n, 1)}
     out["histogram_small_batches"] = small
 
+    # (iv) OpticalFlow at the batch sizes a drop-in graph uses: the reference creates the op with no batch= (one pair per
+    # execute(): tests/test_all.py:166, old/histograms.py:70-72).  Two ways of calling, no HIP-event brackets in either:
+    #   stream        the C ABI back to back on one stream, one sync at the end (how bench.py's own step calls it), Histogram
+    #                 on the same frames in the step as in the headline
+    #   kernel_class  sc.ops.OpticalFlow(frame, device=GPU[, batch=b]) through the Scanner kernel class: every execute()
+    #                 ends with st_ctx_sync, the rate is rows / seconds inside the execute() calls after the first
+    try:
+        from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+        small_flow = {}
+        nfr = 65
+        sc1 = Client(device_id=device.index)
+        sc1.ingest_frames("sb", batches[0][:nfr])
+        frame1 = sc1.io.Input([NamedVideoStream(sc1, "sb")])
+        for b in (1, 2, 4, 8):
+            if b > args.batch:
+                continue
+            fr, fo, ho = batches[0][:b + 1], torch.empty((b, h, w, 2), dtype=torch.float32, device=device), hist_out[:b]
+            reps = max(8, 96 // b)
+            for k in range(reps + 3):
+                if k == 3:
+                    sync()
+                    t0 = time.perf_counter()
+                ctx.histogram(fr[:b], bins, out=ho)
+                ctx.optical_flow(fr, out=fo)
+            sync()
+            dt_s = time.perf_counter() - t0
+            rec = {"stream_frames_per_s": b * reps / dt_s, "stream_ms_per_call": dt_s / reps * 1e3}
+            o = NamedStream(sc1, "sb_out_%d" % b)
+            sc1.execute_seconds, sc1.steady_seconds, sc1.steady_rows = 0.0, 0.0, 0
+            sc1.run(sc1.io.Output(sc1.ops.OpticalFlow(frame=frame1, device=DeviceType.GPU, **({} if b == 1 else {"batch": b})), [o]),
+                    PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+            if sc1.steady_rows:
+                rec["kernel_class_frames_per_s"] = sc1.steady_rows / sc1.steady_seconds
+                rec["kernel_class_ms_per_execute"] = sc1.steady_seconds / (sc1.steady_rows / b) * 1e3
+            small_flow["pairs_per_call_%d" % b] = rec
+            del fo
+        out["optical_flow_small_batches"] = {
+            "what": "1080p device frames, b pairs per call: 'stream' = st_farneback_pairs + st_hist back to back on one stream "
+                    "(no sync between calls); 'kernel_class' = OpticalFlowKernelHIP::execute (sync per call), %d-frame stream; "
+                    "b = 1 is the reference's own calling pattern (no batch= on the op)" % nfr, **small_flow}
+        del sc1
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+    except Exception as e:  # auxiliary record
+        out["optical_flow_small_batches"] = {"error": repr(e)}
+
     try:
         # (i) config 4: OpticalFlow at 4K, batch 32 (BASELINE.json configs[3])
         if not args.no_4k:
@@ -207,12 +267,14 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
             ho4 = torch.empty((B4, 3, bins), dtype=torch.int32, device=device)
             dt, launches, ms = timed_flow_hist(torch, ctx, _native, fr4, B4, bins, 4, 1, sync, fo4, ho4)
             it_bytes, frame_bytes = iter_model_bytes(H4, W4, B4)
-            gbs = it_bytes * 4 / (ms * 1e-3) / 1e9
+            gbs_8d = it_bytes * 4 / (ms * 1e-3) / 1e9
+            gbs = iter_as_built_bytes(H4, W4, B4) * 4 / (ms * 1e-3) / 1e9
             out["config4_4k_batch32"] = {
                 "workload": "OpticalFlow + %d-bin Histogram, 3840x2160, 32 pairs per call (33 resident frames)" % bins,
                 "frames_per_s": B4 * 4 / dt, "ms_per_step": dt / 4 * 1e3, "steps": 4,
                 "roofline": {"kernel": "k_flow_iter3", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": gbs / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": ms / max(launches, 1)},
+                             "frac": gbs / HBM_PEAK_GBS, "frac_model_8d": gbs_8d / HBM_PEAK_GBS, "launches": launches,
+                             "avg_launch_ms": ms / max(launches, 1)},
                 "flow_whole_path_frac_of_peak": B4 * 4 / dt * frame_bytes / 1e9 / HBM_PEAK_GBS}
             del fr4, fo4, ho4
             ctx.release_workspace()
@@ -374,7 +436,11 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
     # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
     try:
         from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+        # config 1 of BASELINE.json: 1000 host-resident 1080p frames through the Histogram op (the frames of the three
+        # resident batches, repeated); OpticalFlow keeps 192 frames (its 16.6 MB flow fields come back to the host)
         n = 192
+        nh = 1000 if (h, w) == (1080, 1920) and args.batch >= 192 else n
+        host_all = torch.cat([b_[:-1].cpu() for b_ in batches] * (nh // (len(batches) * (args.batch)) + 1))[:nh].pin_memory() if nh > n else None
         host = batches[0][:n].cpu().pin_memory()
         # measured H2D rate of this host for the same bytes (pinned -> device)
         dst = torch.empty_like(batches[0][:n])
@@ -388,9 +454,13 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         sc = Client(device_id=device.index)
         sc.ingest_frames("v", host.numpy())
         frame = sc.io.Input([NamedVideoStream(sc, "v")])
-        fed = {"h2d_GBs_pinned_copy": h2d, "frames": n}
-        for name, mk, nrep in (("Histogram", lambda: sc.ops.Histogram(frame=frame, device=DeviceType.CPU, batch=64, bins=bins), 3),
-                               ("OpticalFlow", lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.CPU, batch=32), 2)):
+        frame_h = frame
+        if host_all is not None:
+            sc.ingest_frames("vh", host_all.numpy())
+            frame_h = sc.io.Input([NamedVideoStream(sc, "vh")])
+        fed = {"h2d_GBs_pinned_copy": h2d, "frames": n, "histogram_frames": nh}
+        for name, mk, nrep, n in (("Histogram", lambda: sc.ops.Histogram(frame=frame_h, device=DeviceType.CPU, batch=64, bins=bins), 3, nh),
+                                  ("OpticalFlow", lambda: sc.ops.OpticalFlow(frame=frame, device=DeviceType.CPU, batch=32), 2, n)):
             best, steady = None, 0.0
             for _ in range(nrep):
                 o = NamedStream(sc, "hf_" + name)
@@ -406,6 +476,8 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                          "steady_frac_of_h2d": steady * 3 * h * w / 1e9 / h2d}
         # the same Histogram graph fed from PAGEABLE host memory (the kernel bounces it through its
         # page-locked ring)
+        n = 192
+        del host_all
         sc.ingest_frames("vp", np.array(host.numpy(), copy=True))
         framep = sc.io.Input([NamedVideoStream(sc, "vp")])
         best = None
@@ -441,15 +513,29 @@ def run_rank(args):
         for _ in range(args.steps):
             time.sleep(0.001 * (rank + 1))
         dt = time.perf_counter() - t0
+        my_ms = dt / max(args.steps, 1) * 1e3
+        coll_world, devices, rank_ms = 1, ["cpu:0"], [my_ms]
         if world > 1:
             dist.barrier()
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            # the same evidence fields as the real line: the collective's own count of ranks, one device per rank, every
+            # rank's time
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (rank, "cpu:%d" % rank, my_ms))
+            gathered.sort()
+            devices, rank_ms = [g_[1] for g_ in gathered], [g_[2] for g_ in gathered]
+            one = torch.ones(1, dtype=torch.int32)
+            ones = [torch.zeros_like(one) for _ in range(world)]
+            dist.all_gather(ones, one)
+            coll_world = int(sum(int(o_.item()) for o_ in ones))
         if rank == 0:
             print(json.dumps({"metric": "dry run (launcher self-test, no kernels)", "dry_run": True, "value": 0.0,
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": dt / max(args.steps, 1) * 1e3}), flush=True)
+                              "ms_per_step": dt / max(args.steps, 1) * 1e3, "rccl_world_size": coll_world,
+                              "collective_backend": "gloo (dry run)", "devices": devices, "distinct_devices": len(set(devices)),
+                              "ms_per_step_by_rank": rank_ms}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -488,6 +574,7 @@ def run_rank(args):
 
     dt, blur_launches, blur_ms = timed_flow_hist(torch, ctx, _native, batches, B, args.bins, args.steps, args.warmup,
                                                  barrier, flow_out, hist_out)
+    dt_rank = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -498,6 +585,28 @@ def run_rank(args):
 
     blur_bytes_per_step, flow_model_bytes = iter_model_bytes(h, w, B)
     blur_gbs = blur_bytes_per_step * args.steps / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
+    built_bytes_per_step = iter_as_built_bytes(h, w, B)
+    built_gbs = built_bytes_per_step * args.steps / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
+
+    # multi-GPU evidence: what the collective library itself saw (an all_gather of one int per rank), the PCI bus id of
+    # every rank's device, and every rank's own time per step
+    def device_id_string(dev):
+        pr = torch.cuda.get_device_properties(dev)
+        bus = getattr(pr, "pci_bus_id", None)
+        if bus is not None:
+            return "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), bus, getattr(pr, "pci_device_id", 0))
+        return str(getattr(pr, "uuid", dev))
+    my_dev, my_ms = device_id_string(device), dt_rank / args.steps * 1e3
+    rccl_world, devices, rank_ms = 1, [my_dev], [my_ms]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, my_dev, my_ms))
+        gathered.sort()
+        devices, rank_ms = [g_[1] for g_ in gathered], [g_[2] for g_ in gathered]
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if share else device)
+        ones = [torch.zeros_like(one) for _ in range(world)]
+        dist.all_gather(ones, one)
+        rccl_world = int(sum(int(o_.item()) for o_ in ones))
 
     # Histogram kernel alone (same data), its own timed loop
     hist_steps = max(args.steps, 10)
@@ -568,7 +677,14 @@ def run_rank(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (u8 in; f64 running sums)",
+            "dtype": "f32 (u8 frames in; the box filter's running sums in f64, re-anchored every 32 rows / 8 columns, column sums "
+                     "handed to the row pass as f32)",
+            "rccl_world_size": rccl_world,
+            "collective_backend": ("gloo (ranks share GPUs: self-test)" if share else "nccl (RCCL)") if world > 1 else "none (1 rank)",
+            "devices": devices,
+            "distinct_devices": len(set(devices)),
+            "ms_per_step_by_rank": rank_ms,
+            "flow_whole_path_frac_of_peak": fps / world * flow_model_bytes / 1e9 / HBM_PEAK_GBS,
             "data": "synthetic",
             "config": {
                 "workload": "Farneback OpticalFlow op (3,0.5,false,15,3,5,1.2,0), %dx%d pair stream, stencil {0,1}, "
@@ -580,14 +696,20 @@ def run_rank(args):
             "roofline": {
                 "kernel": "k_flow_iter3",
                 "bound": "hbm",
-                "achieved": blur_gbs,
-                "achieved_is": "algorithmic bytes of the covered stages (SURVEY 8d model: M priced as if materialised) / measured launch time",
+                "achieved": built_gbs,
+                "achieved_is": "compulsory bytes of the launches as built (R0 20 + R1 20 + flow out 8 B/px per launch, flow in 8 B/px "
+                               "on iterations 2-3, 8 B per coarse pixel at level transitions; M is never in memory) / HIP-event time "
+                               "of the launches on their own stream",
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": blur_gbs / HBM_PEAK_GBS,
-                "frac_is": "algorithmic (model) bytes / time / peak as the bench contract defines it -- NOT HBM utilisation: the "
-                           "kernel never materialises M, so it moves fewer bytes than the model prices; frac_traffic is the "
-                           "utilisation figure",
+                "frac": built_gbs / HBM_PEAK_GBS,
+                "frac_is": "as-built bytes / launch time / 8 TB/s: at most 1 by construction.  frac_model_8d prices the stages the launch "
+                           "replaces with SURVEY 8d's stage-by-stage model (M written and re-read), which this kernel does not move "
+                           "and which can therefore exceed 1; frac_traffic is what the PMC counters saw (L2 serves the expansion two "
+                           "consecutive pairs share)",
+                "as_built_bytes_per_launch": built_bytes_per_step * args.steps / max(blur_launches, 1),
+                "achieved_model_8d": blur_gbs,
+                "frac_model_8d": blur_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_GBs": traffic_gbs,
                 "frac_traffic": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,

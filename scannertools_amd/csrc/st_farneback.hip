@@ -2125,23 +2125,24 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
 // horizontal sums double-buffered: 129 KB (NCW = 4), 158 KB (NCW = 5).
 // ---------------------------------------------------------------------------------------------
 constexpr int FR_G = 4;
-template <int NCW>
+template <int NCW, int NMS>
 struct FrGeom {
   static constexpr int COLS = 64 * NCW, OUTMAX = COLS - 2 * B2_HALO, PADW = COLS + COLS / 8;
   static constexpr int NSEGMAX = OUTMAX / F3_SW;
-  static constexpr int THREADS = 3 * COLS;
+  static constexpr int THREADS = (2 + NMS) * COLS;  // NMS sets of maker waves (each takes every NMS-th 2-row batch)
   static_assert(FR_G * 2 * NSEGMAX <= COLS, "one solver thread per (row, half segment)");
+  static_assert(THREADS <= 1024 && (NMS == 1 || NMS == 2), "workgroup size");
 };
 
-template <int NCW, int MODE>
-__global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterArgs a) {
-  typedef FrGeom<NCW> G;
+template <int NCW, int NMS, int MODE>
+__global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles(IterArgs a) {
+  typedef FrGeom<NCW, NMS> G;
   constexpr int M = 7, W = 15, RB = 2;
   __shared__ float Mb[2][FR_G][5][G::COLS];
   __shared__ float Vs[3][FR_G][5][G::PADW];
   __shared__ double Ts[2][FR_G][2 * G::NSEGMAX][5];
   const int tid = threadIdx.x;
-  const int role = tid < G::COLS ? 0 : (tid < 2 * G::COLS ? 1 : 2);  // wave-uniform
+  const int role = tid < NMS * G::COLS ? 0 : (tid < (NMS + 1) * G::COLS ? 1 : 2);  // wave-uniform
   const int h = a.h, w = a.w;
   const int np = h * w;
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -2155,7 +2156,8 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
 
   if (role == 0) {
     // ---------------- makers ----------------
-    const int t = tid;
+    const int mset = NMS == 1 ? 0 : tid / G::COLS;  // this wave's maker set
+    const int t = tid - mset * G::COLS;
     const int x = (int)bx * a.out_w - B2_HALO + t;
     const int xc = d_clamp(x, 0, w - 1);
     const float* __restrict__ R0;
@@ -2170,21 +2172,25 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
     const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
     const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
     const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
+    // This set's n-th batch is rows k = KS n + RB mset + r, r < RB: with two sets a step's four rows are one batch of
+    // each set (twice the gathers in flight per compute unit: the makers are what a step waits for).
+    constexpr int KS = RB * NMS, NB = FR_G / KS;  // batch stride in rows, batches per step and set
     auto rowk = [&](int k) { return d_clamp(y0 - 8 + k, 0, h - 1); };
-    // software pipeline over batches of RB rows (as k_flow_iter3): gathers of the next batch in flight while this one
-    // is finished, flows one batch further ahead, their loads one more
+    const int kb = RB * mset;
+    // software pipeline over the batches (as k_flow_iter3): gathers of the next batch in flight while this one is
+    // finished, flows one batch further ahead, their loads one more
     float2 fcur[RB], fnext[RB];
     UmLoads L[RB];
     FlowRaw raw[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      fcur[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(r));
-      um_issue(R0, R1, np, h, w, xc, rowk(r), fcur[r], L[r]);
+      fcur[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(kb + r));
+      um_issue(R0, R1, np, h, w, xc, rowk(kb + r), fcur[r], L[r]);
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) fnext[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(RB + r));
+    for (int r = 0; r < RB; ++r) fnext[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(kb + KS + r));
 #pragma unroll
-    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(2 * RB + r), raw[r]);
+    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(kb + 2 * KS + r), raw[r]);
     for (int sb = 0; sb < T; sb += 2) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -2192,21 +2198,22 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
         if (s < T) {
           if (s < SM) {
 #pragma unroll
-            for (int bb = 0; bb < FR_G / RB; ++bb) {
-              const int k0 = FR_G * s + bb * RB;
+            for (int bb = 0; bb < NB; ++bb) {
+              const int k0 = FR_G * s + bb * KS + kb;   // first row of this batch
+              const int i0 = (NMS == 1 ? bb * RB : kb);  // its row within the step
 #pragma unroll
               for (int r = 0; r < RB; ++r) {
                 float m[5];
                 um_finish(L[r], h, w, xc, rowk(k0 + r), fcur[r], m);
 #pragma unroll
-                for (int c = 0; c < 5; ++c) Mb[u][bb * RB + r][c][t] = m[c];
+                for (int c = 0; c < 5; ++c) Mb[u][i0 + r][c][t] = m[c];
                 fcur[r] = fnext[r];
-                um_issue(R0, R1, np, h, w, xc, rowk(k0 + RB + r), fcur[r], L[r]);
+                um_issue(R0, R1, np, h, w, xc, rowk(k0 + KS + r), fcur[r], L[r]);
               }
 #pragma unroll
-              for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, rowk(k0 + 2 * RB + r), raw[r]);
+              for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, rowk(k0 + 2 * KS + r), raw[r]);
 #pragma unroll
-              for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(k0 + 3 * RB + r), raw[r]);
+              for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(k0 + 3 * KS + r), raw[r]);
             }
           }
           __syncthreads();
@@ -2215,7 +2222,7 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
     }
   } else if (role == 1) {
     // ---------------- summers ----------------
-    const int t = tid - G::COLS;
+    const int t = tid - NMS * G::COLS;
     const int vpos = f3_pos(t);
     float ring[F3_RING][5];
     double vs[5];
@@ -2225,7 +2232,18 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
       for (int c = 0; c < 5; ++c) ring[s2][c] = 0.f;
 #pragma unroll
     for (int c = 0; c < 5; ++c) vs[c] = 0;
-    const int nitem = FR_G * nseg * 5;  // horizontal-sum items of a step: (row, segment, channel), segment fastest
+    // horizontal-sum items of a step: (row, segment, channel), segment fastest; a thread's items are the same in every
+    // step, so their LDS offsets are formed once (the division by the run-time segment count is ~25 instructions)
+    const int nitem = FR_G * nseg * 5;
+    constexpr int NR = (FR_G * G::NSEGMAX * 5 + G::COLS - 1) / G::COLS;
+    int it_off[NR];  // low 16 bits: float offset of f3_pos(8 + 8 sg) within a generation of Vs; high: double offset within a buffer of Ts
+    static_assert(FR_G * 5 * G::PADW < 65536 && FR_G * 2 * G::NSEGMAX * 5 < 32768, "packed item offsets");
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int e = t + G::COLS * j;
+      const int sg = e % nseg, rc = e / nseg, c = rc % 5, r = rc / 5;
+      it_off[j] = e < nitem ? (((r * 5 + c) * G::PADW + 9 + 9 * sg) | (((r * 2 * G::NSEGMAX + 2 * sg) * 5 + c) << 16)) : -1;
+    }
     int vgen = 0;  // generation (mod 3) of Vs this step's column sums go to
     for (int sb = 0; sb < T; sb += 4) {
 #pragma unroll
@@ -2297,16 +2315,21 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
           // channel) the fresh 15-term sum at the segment's first column, then the four slides to its fifth
           if (s >= 6 && s <= SM + 1) {
             const int pg = vgen == 0 ? 2 : vgen - 1;
-            for (int e = t; e < nitem; e += G::COLS) {
-              const int sg = e % nseg, rc = e / nseg, c = rc % 5, r = rc / 5;
-              const float* __restrict__ vp = &Vs[pg][r][c][9 + 9 * sg];  // f3_pos(8 + 8 sg)
-              double acc = vp[-8];
+            const float* __restrict__ vbase = &Vs[pg][0][0][0];
+            double* __restrict__ tbase = &Ts[u & 1][0][0][0];
 #pragma unroll
-              for (int k = -6; k <= 7; ++k) acc += (double)vp[k < 0 ? k - 1 : k];
-              Ts[u & 1][r][2 * sg][c] = acc;
+            for (int j = 0; j < NR; ++j) {
+              if (it_off[j] >= 0) {
+                const float* __restrict__ vp = vbase + (it_off[j] & 0xffff);
+                double* __restrict__ tp = tbase + (it_off[j] >> 16);
+                double acc = vp[-8];
 #pragma unroll
-              for (int i = 1; i <= 4; ++i) acc += (double)vp[8 + i] - (double)vp[i - 9];
-              Ts[u & 1][r][2 * sg + 1][c] = acc;
+                for (int k = -6; k <= 7; ++k) acc += (double)vp[k < 0 ? k - 1 : k];
+                tp[0] = acc;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) acc += (double)vp[8 + i] - (double)vp[i - 9];
+                tp[5] = acc;
+              }
             }
           }
           if (s >= 5 && s <= SM) vgen = vgen == 2 ? 0 : vgen + 1;
@@ -2316,7 +2339,7 @@ __global__ __launch_bounds__(FrGeom<NCW>::THREADS) void k_flow_iter_roles(IterAr
     }
   } else {
     // ---------------- solvers ----------------
-    const int t = tid - 2 * G::COLS;
+    const int t = tid - (NMS + 1) * G::COLS;
     const int nq = 2 * nseg;
     const int r = t / nq, q = t - r * nq;
     const int sg = q >> 1, hf = q & 1;
@@ -2832,52 +2855,6 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
-  // Role-split marching kernel (k_flow_iter_roles, one 10- or 13-wave workgroup per compute unit): ST_ITER_ROLES=1
-  // always, 0 never; default: by predicted time against k_flow_iter3's two 4-wave workgroups per unit (below).
-  const int roles_env = ctx->roles_mode, roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
-  if (roles_env != 0) {
-    const int periods = (a.h + F3_ANCHOR - 1) / F3_ANCHOR;
-    int best_ncw = 0, best_out = 0, best_rows = 0;
-    double best = 1e300;
-    for (int ncw = 5; ncw >= 4; --ncw) {
-      if (roles_ncw && ncw != roles_ncw) continue;
-      const int outmax = 64 * ncw - 2 * B2_HALO;
-      const int strips = (a.w + outmax - 1) / outmax;
-      const int out_w = ((a.w + strips - 1) / strips + 7) / 8 * 8;
-      for (int segs = 1; segs <= periods; ++segs) {
-        const int r = (periods + segs - 1) / segs * F3_ANCHOR;
-        const long long nseg = (a.h + r - 1) / r;
-        const long long wgs = (long long)strips * n_pairs * nseg;
-        const long long rounds = (wgs + ctx->num_cus - 1) / ctx->num_cus;
-        // a round costs its rows plus the 16-row prologue and the two-step pipeline tail; a 13-wave workgroup's row is
-        // 5/4 of a 10-wave one's
-        const double cost = (double)rounds * (r + 16 + 3 * FR_G) * (ncw == 5 ? 1.25 : 1.0);
-        if (cost < best * 0.999) { best = cost; best_ncw = ncw; best_out = out_w; best_rows = r; }
-      }
-    }
-    if (roles_rows >= F3_ANCHOR && roles_rows % F3_ANCHOR == 0) best_rows = roles_rows;
-    if (best_ncw && roles_env == 1) {
-      a.rows_per_seg = best_rows;
-      a.out_w = best_out;
-      const int strips = (a.w + best_out - 1) / best_out;
-      dim3 grid(strips, (a.h + best_rows - 1) / best_rows, n_pairs);
-      st_timed t(ctx, ST_K_BLUR_UPDATE);
-      const int mode = a.coarse ? FLOW_COARSE : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-      if (best_ncw == 5) {
-        const dim3 blk(FrGeom<5>::THREADS);
-        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
-        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_flow_iter_roles<5, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
-      } else {
-        const dim3 blk(FrGeom<4>::THREADS);
-        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
-        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_flow_iter_roles<4, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
-      }
-      ST_HIP(ctx, hipGetLastError());
-      return ST_OK;
-    }
-  }
   const int strips = (a.w + B2_OUT - 1) / B2_OUT;
   // Segment height = whole anchor periods (32 rows).  Two workgroups are resident per CU (register and
   // LDS budget), so a launch runs in rounds of resident workgroups that each cost their rows plus
@@ -2887,6 +2864,7 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   const long long resident = (long long)ctx->num_cus * 2;
   const int periods = (a.h + F3_ANCHOR - 1) / F3_ANCHOR;
   int rows = periods * F3_ANCHOR;
+  long long rounds3 = 1, wgs3 = 1;
   double best = 1e300;
   for (int segs = 1; segs <= periods; ++segs) {
     const int r = (periods + segs - 1) / segs * F3_ANCHOR;
@@ -2894,7 +2872,61 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
     const long long wgs = (long long)strips * n_pairs * nseg;
     const long long rounds = (wgs + resident - 1) / resident;
     const double cost = (double)rounds * (r + 15);
-    if (cost < best * 0.999) { best = cost; rows = r; }
+    if (cost < best * 0.999) { best = cost; rows = r; rounds3 = rounds; wgs3 = wgs; }
+  }
+  // Role-split marching kernel (k_flow_iter_roles, one workgroup of 12 or 15 waves per compute unit) for launches that
+  // cannot give k_flow_iter3 its two workgroups per unit: measured at 1080p (frames/s through both ops, k_flow_iter3 ->
+  // roles): 1 pair per call 2 790 -> 3 100, 2: 3 690 -> 4 240, 4: 4 990 -> 5 200, 8: 6 190 -> 6 640, 16: 7 750 -> 7 690,
+  // 32: 8 570 -> 8 360, 64: 9 150 -> 8 610.  ST_ITER_ROLES=1 always, 0 never (read at st_ctx_create).
+  const int roles_env = ctx->roles_mode, roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
+  if (roles_env == 1 || (roles_env != 0 && rounds3 == 1 && wgs3 * 100 < resident * 95)) {
+    int best_ncw = 0, best_out = 0, best_rows = 0;
+    double bestr = 1e300;
+    for (int ncw = 5; ncw >= 4; --ncw) {
+      if (roles_ncw && ncw != roles_ncw) continue;
+      const int outmax = 64 * ncw - 2 * B2_HALO;
+      const int rstrips = (a.w + outmax - 1) / outmax;
+      const int out_w = ((a.w + rstrips - 1) / rstrips + 7) / 8 * 8;
+      for (int segs = 1; segs <= periods; ++segs) {
+        const int r = (periods + segs - 1) / segs * F3_ANCHOR;
+        const long long nseg = (a.h + r - 1) / r;
+        const long long wgs = (long long)rstrips * n_pairs * nseg;
+        const long long rounds = (wgs + ctx->num_cus - 1) / ctx->num_cus;
+        // a round costs its rows plus the 16-row prologue and the three-step pipeline tail; the 15-wave instance's
+        // step is ~1.3 of the 12-wave one's when both fill the chip (it pays when it saves a round: 1920 columns are
+        // 7 strips instead of 8, 238 instead of 272 workgroups for one 1080p pair)
+        const double cost = (double)rounds * (r + 16 + 3 * FR_G) * (ncw == 5 ? 1.3 : 1.0);
+        if (cost < bestr * 0.999) { bestr = cost; best_ncw = ncw; best_out = out_w; best_rows = r; }
+      }
+    }
+    if (roles_rows >= F3_ANCHOR && roles_rows % F3_ANCHOR == 0) best_rows = roles_rows;
+    if (best_ncw) {
+      a.rows_per_seg = best_rows;
+      a.out_w = best_out;
+      const int rstrips = (a.w + best_out - 1) / best_out;
+      dim3 grid(rstrips, (a.h + best_rows - 1) / best_rows, n_pairs);
+      st_timed t(ctx, ST_K_BLUR_UPDATE);
+      const int mode = a.coarse ? FLOW_COARSE : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
+      static const int nms_env = getenv("ST_ROLES_NMS") ? atoi(getenv("ST_ROLES_NMS")) : 1;  // maker sets of the 4-wave instance (2: measured slower, 6.8 against 5.2 ms per 256-pair level-0 launch)
+      if (best_ncw == 5) {
+        const dim3 blk(FrGeom<5, 1>::THREADS);
+        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
+      } else if (nms_env == 2) {
+        const dim3 blk(FrGeom<4, 2>::THREADS);
+        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
+      } else {
+        const dim3 blk(FrGeom<4, 1>::THREADS);
+        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
+      }
+      ST_HIP(ctx, hipGetLastError());
+      return ST_OK;
+    }
   }
   static const int force_rows = getenv("ST_ITER_ROWS") ? atoi(getenv("ST_ITER_ROWS")) : 0;  // experiments
   if (force_rows >= F3_ANCHOR && force_rows % F3_ANCHOR == 0 && force_rows < rows) rows = force_rows;

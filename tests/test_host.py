@@ -126,6 +126,54 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
 
 
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+
+
+def _check_eight_rank_line(line):
+    assert line["n_gpus"] == 8 and line["dry_run"] is True
+    assert line["rccl_world_size"] == 8 and line["distinct_devices"] == 8 and len(line["devices"]) == 8
+    assert len(line["ms_per_step_by_rank"]) == 8
+    assert line["ms_per_step"] >= max(line["ms_per_step_by_rank"]) * 0.999   # the slowest rank sets the time
+    assert line["ms_per_step_by_rank"][7] >= 8.0                             # rank r sleeps r + 1 ms per dummy step
+
+
+def test_bench_eight_ranks_both_launchers():
+    """The line the driver reads at N = 8, from both ways of starting the ranks (bench.py's own spawn and
+    torch.distributed.run as the driver does it), on CPU with --dry-run: eight gloo ranks, the collective's own
+    count of ranks, one device entry per rank, every rank's time, max over ranks as the step time."""
+    import json
+    import socket
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    _check_eight_rank_line(json.loads(lines[0]))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    _check_eight_rank_line(json.loads(lines[0]))
+
+
+def test_shot_pipeline_eight_ranks():
+    """Config 3's sharding at the size BASELINE.json names (8 ranks): contiguous shards, halo-free histograms, gather on
+    rank 0, one ShotBoundaries pass over the whole stream (dry run: numpy bincount stands in for the kernel)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shot_pipeline.py"), "--gpus", "8", "--dry-run",
+                        "--frames", "2003", "--height", "16", "--width", "24", "--cuts", "5"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 8 and line["frames"] == 2003 and line["planted_found"] is True
+
+
 def test_shot_pipeline_starts_its_own_ranks():
     """scripts/shot_pipeline.py --gpus 2 --dry-run: two gloo ranks, CPU histograms of a tiny stream
     (numpy bincount standing in for the kernel in the dry run only), gather on rank 0, ShotBoundaries."""
