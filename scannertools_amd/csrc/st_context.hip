@@ -77,11 +77,6 @@ ST_EXPORT int st_ctx_destroy(st_ctx* ctx) {
     for (auto e : t.stops) (void)hipEventDestroy(e);
   }
   if (ctx->ws) (void)hipFree(ctx->ws);
-  if (ctx->aux_stream) {
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->aux_stream);
-  }
-  for (auto e : ctx->aux_events) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ST_OK;

@@ -2420,11 +2420,12 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
 constexpr int FT_T = 32, FT_M = 7, FT_S = FT_T + 2 * FT_M;  // tile side, window radius, tile + apron
 static_assert(FT_T == F3_ANCHOR && FT_T % F3_SW == 0 && B2_OUT % F3_SW == 0, "tile anchors must coincide with k_flow_iter3's");
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_flow_iter_tile(IterArgs a) {
   constexpr int W = 2 * FT_M + 1;
-  __shared__ float Mt[5][FT_S][FT_S];
-  __shared__ float Vt[5][FT_T][FT_S];
+  constexpr int NSEG = FT_T / F3_SW;  // 8-pixel segments per tile row
+  __shared__ float Mt[5][FT_S][FT_S];            // M on the tile + apron; rows 0 .. 31 become the column sums in place
+  __shared__ double Tt[FT_T][2 * NSEG][5];       // horizontal sums at the first and the fifth pixel of every segment
   const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
   const int np = h * w;
@@ -2443,17 +2444,16 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? st_gl(a.flow_ptrs[pr]) : a.flow_out + (size_t)pr * 2 * (size_t)np;
 
-  // ---- phase 1: M on the tile + apron (Mt row j = source row Y0 - 7 + j, clamped).  A thread has up to NI = 9 of the
-  // 46 x 46 pixels.  Their flow vectors are requested together, then the expansions in chunks of three pixels: four memory
-  // round trips per tile instead of the eighteen of a pixel-by-pixel loop (flow, then the gather it addresses, nine
-  // times) -- these launches are latency-bound, so that is most of their time.
-  constexpr int NI = (FT_S * FT_S + 255) / 256;
+  // ---- phase 1: M on the tile + apron (Mt row j = source row Y0 - 7 + j, clamped).  A thread has up to NI of the
+  // 46 x 46 pixels.  Their flow vectors are requested together, then the expansions in chunks of up to three pixels: a few
+  // memory round trips per tile instead of two per pixel -- these launches are latency-bound, so that is most of their time.
+  constexpr int NI = (FT_S * FT_S + NT - 1) / NT;
   int px[NI], py[NI];
   FlowRaw raw[NI];
   CoarseX cxs[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    const int i = min(tid + 256 * k, FT_S * FT_S - 1);  // the last, partial round recomputes the final pixel: harmless
+    const int i = min(tid + NT * k, FT_S * FT_S - 1);  // the last, partial round recomputes the final pixel: harmless
     const int ty = i / FT_S, tx = i - ty * FT_S;
     px[k] = d_clamp(X0 - FT_M + tx, 0, w - 1);
     py[k] = d_clamp(Y0 - FT_M + ty, 0, h - 1);
@@ -2465,25 +2465,30 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
   for (int k = 0; k < NI; ++k) fl[k] = flow_finish<MODE>(a, fin, C, cxs[k], py[k], raw[k]);
 #pragma unroll
   for (int k0 = 0; k0 < NI; k0 += 3) {
-    UmLoads L[3];
+    constexpr int CH = 3;
+    UmLoads L[CH];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) um_issue(R0, R1, np, h, w, px[k0 + j], py[k0 + j], fl[k0 + j], L[j]);
+    for (int j = 0; j < CH; ++j)
+      if (k0 + j < NI) um_issue(R0, R1, np, h, w, px[k0 + j], py[k0 + j], fl[k0 + j], L[j]);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float m[5];
-      um_finish(L[j], h, w, px[k0 + j], py[k0 + j], fl[k0 + j], m);
-      const int i = tid + 256 * (k0 + j);
-      if (i < FT_S * FT_S) {
-        const int ty = i / FT_S, tx = i - ty * FT_S;
+    for (int j = 0; j < CH; ++j) {
+      if (k0 + j < NI) {
+        float m[5];
+        um_finish(L[j], h, w, px[k0 + j], py[k0 + j], fl[k0 + j], m);
+        const int i = tid + NT * (k0 + j);
+        if (i < FT_S * FT_S) {
+          const int ty = i / FT_S, tx = i - ty * FT_S;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
+          for (int c = 0; c < 5; ++c) Mt[c][ty][tx] = m[c];
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);  // one chunk of gathers in flight at a time
   }
   __syncthreads();
-  // ---- phase 2: column sums of the tile's 32 rows from the anchor at its first row; item = (channel, column)
-  for (int i = tid; i < 5 * FT_S; i += 256) {
+  // ---- phase 2: column sums of the tile's 32 rows from the anchor at its first row; item = (channel, column).  The sum of
+  // row j replaces M of row j (its last reader is this very step of this very thread).
+  for (int i = tid; i < 5 * FT_S; i += NT) {
     const int c = i / FT_S, col = i - c * FT_S;
     double vs;
     if (Y0 == 0) {
@@ -2500,39 +2505,48 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(IterArgs a) {
     }
 #pragma unroll 4
     for (int j = 0; j < FT_T; ++j) {
-      Vt[c][j][col] = (float)vs;
+      const float lo = Mt[c][j][col];
+      Mt[c][j][col] = (float)vs;
       if (j + 1 < FT_T) {
-        const float d = Mt[c][j + W][col] - Mt[c][j][col];
+        const float d = Mt[c][j + W][col] - lo;
         vs += d;
       }
     }
   }
   __syncthreads();
-  // ---- phase 3: row sums + solve; item = (row, 8-pixel group), groups start at x = 8 i
-  for (int i = tid; i < FT_T * (FT_T / F3_SW); i += 256) {
-    const int r = i / (FT_T / F3_SW), g = i - r * (FT_T / F3_SW);
+  // ---- phase 3a: horizontal sums; item = (row, 8-pixel segment, channel), segments start at x = 8 i: the fresh 15-term sum
+  // at the segment's first pixel and the four slides to its fifth (the longest serial chain of the tile, cut in two)
+  for (int i = tid; i < FT_T * NSEG * 5; i += NT) {
+    const int g = i % NSEG, rc = i / NSEG, c = rc % 5, r = rc / 5;
+    const float* __restrict__ vp = &Mt[c][r][F3_SW * g];  // column j0 - 7 of the segment, j0 = FT_M + 8 g
+    double acc = vp[0];
+#pragma unroll
+    for (int k = 1; k < W; ++k) acc += (double)vp[k];
+    Tt[r][2 * g][c] = acc;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) acc += (double)vp[k + 2 * FT_M] - (double)vp[k - 1];
+    Tt[r][2 * g + 1][c] = acc;
+  }
+  __syncthreads();
+  // ---- phase 3b: item = (row, half segment): three more slides, four solves
+  for (int i = tid; i < FT_T * 2 * NSEG; i += NT) {
+    const int r = i / (2 * NSEG), q = i - r * (2 * NSEG);
     const int y = Y0 + r;
     if (y >= h) continue;
-    const int j0 = FT_M + F3_SW * g;  // Vt column of the group's first pixel
+    const int j0 = FT_M + 4 * q;  // Mt column of this item's first pixel
     double t[5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const float* vp = &Vt[c][r][j0 - FT_M];
-      double acc = vp[0];
+    for (int c = 0; c < 5; ++c) t[c] = Tt[r][q][c];
 #pragma unroll
-      for (int k = 1; k < W; ++k) acc += (double)vp[k];
-      t[c] = acc;
-    }
-#pragma unroll
-    for (int k = 0; k < F3_SW; ++k) {
+    for (int k = 0; k < 4; ++k) {
       if (k > 0) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) t[c] += (double)Vt[c][r][j0 + k + FT_M] - (double)Vt[c][r][j0 + k - FT_M - 1];
+        for (int c = 0; c < 5; ++c) t[c] += (double)Mt[c][r][j0 + k + FT_M] - (double)Mt[c][r][j0 + k - FT_M - 1];
       }
       const double g11 = t[0] * a.scale, g12 = t[1] * a.scale, g22 = t[2] * a.scale;
       const double h1 = t[3] * a.scale, h2 = t[4] * a.scale;
       const double idet = d_rcp_pos(g11 * g22 - g12 * g12 + 1e-3);
-      const int x = X0 + F3_SW * g + k;
+      const int x = X0 + 4 * q + k;
       if (x < w)
         *reinterpret_cast<float2*>(fout + 2 * ((size_t)y * w + x)) =
             make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
@@ -2849,9 +2863,16 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   if (tile && (a.h + FT_T - 1) / FT_T <= 65535) {
     dim3 grid((a.w + FT_T - 1) / FT_T, (a.h + FT_T - 1) / FT_T, n_pairs);
     st_timed t(ctx, ST_K_BLUR_UPDATE);
-    if (a.coarse) hipLaunchKernelGGL(k_flow_iter_tile<FLOW_COARSE>, grid, dim3(256), 0, ctx->stream, a);
-    else if (a.flow_in) hipLaunchKernelGGL(k_flow_iter_tile<FLOW_FIELD>, grid, dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_flow_iter_tile<FLOW_ZERO>, grid, dim3(256), 0, ctx->stream, a);
+    static const int tile_nt = getenv("ST_TILE_NT") ? atoi(getenv("ST_TILE_NT")) : 512;  // threads per tile (256: A/B runs)
+    if (tile_nt == 256) {
+      if (a.coarse) hipLaunchKernelGGL((k_flow_iter_tile<FLOW_COARSE, 256>), grid, dim3(256), 0, ctx->stream, a);
+      else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter_tile<FLOW_FIELD, 256>), grid, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_flow_iter_tile<FLOW_ZERO, 256>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+      if (a.coarse) hipLaunchKernelGGL((k_flow_iter_tile<FLOW_COARSE, 512>), grid, dim3(512), 0, ctx->stream, a);
+      else if (a.flow_in) hipLaunchKernelGGL((k_flow_iter_tile<FLOW_FIELD, 512>), grid, dim3(512), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_flow_iter_tile<FLOW_ZERO, 512>), grid, dim3(512), 0, ctx->stream, a);
+    }
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
@@ -3039,34 +3060,17 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   const bool pyr_rgb = pyr1 && aligned4 && ctx->fold_gray;
   if (!pyr_rgb) ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
   if (pyr1) ST_TRY(launch_pyr_fused(ctx, pyr_rgb ? nullptr : gray, d_frames, nf, h, w, p, imgs));
-  // Small batches: the flow iterations of the coarse levels are latency-bound launches of a few
-  // dozen workgroups, so the polynomial expansions of the finer levels (independent of them) run
-  // on a second stream meanwhile; each level's first iteration waits for its expansion.
-  // (ST_NO_OVERLAP=1 keeps everything on one stream.)
-  static const bool no_overlap = getenv("ST_NO_OVERLAP") != nullptr;
-  const bool overlap = pyr1 && fused && levels >= 1 && levels <= 4 && npairs <= 16 && !no_overlap;
-  if (overlap) {
-    // level 0 (three quarters of the expansion work) on the second stream, which has the LOWEST priority so that its
-    // workgroups fill the compute units the coarse levels' iterations leave idle instead of queueing ahead of them
-    // (a level-3 iteration of 8 pairs measured 98 us instead of 27 behind the level-0 expansion of equal priority);
-    // the coarse levels' expansions in ONE launch on the main stream, largest level first.
-    if (!ctx->aux_stream) {
-      int lo = 0, hi = 0;
-      ST_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = least urgent
-      ST_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
-      for (auto& e : ctx->aux_events) ST_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    hipEvent_t pyr_done = ctx->aux_events[7];
-    ST_HIP(ctx, hipEventRecord(pyr_done, ctx->stream));
-    ST_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, pyr_done, 0));
-    hipStream_t main_stream = ctx->stream;
-    ctx->stream = ctx->aux_stream;  // launch helpers (and their timing brackets) use ctx->stream
-    int st = launch_polyexp(ctx, imgs[0], nf, geom[0].lh, geom[0].lw, p.poly_n, p.poly_sigma, R[0]);
-    if (st == ST_OK && hipEventRecord(ctx->aux_events[0], ctx->aux_stream) != hipSuccess) st = ST_ERR_HIP;
-    ctx->stream = main_stream;
-    if (st != ST_OK) return st == ST_ERR_HIP ? st_set_error(ctx, ST_ERR_HIP, "farneback: second-stream launch failed") : st;
+  // Small batches: the expansions of all levels in ONE launch (level 0 first, the coarse levels fill its tail).  Measured
+  // against the former arrangement -- level 0 on a second, low-priority stream beside the coarse levels' iterations --
+  // at 1 / 2 / 4 / 8 pairs of 1080p per call: 292 / 444 / 731 / 1193 us per step against 308 / 458 / 744 / 1197: the
+  // event record and wait of the second stream cost a launch's worth each, and the coarse iterations it overlapped with ran
+  // two to four times slower beside the level-0 expansion whatever the stream priority.  (ST_POLY_SINGLE_MAX: pairs up to
+  // which the single launch is used.)
+  static const int single_max = getenv("ST_POLY_SINGLE_MAX") ? atoi(getenv("ST_POLY_SINGLE_MAX")) : 16;
+  const bool single = pyr1 && levels >= 1 && levels <= 3 && npairs <= single_max;
+  if (single) {
     int ks[4], nk = 0;
-    for (int k = 1; k <= levels; ++k) ks[nk++] = k;
+    for (int k = 0; k <= levels; ++k) ks[nk++] = k;
     ST_TRY(launch_polyexp_ml(ctx, imgs, geom.data(), R.data(), ks, nk, nf, p.poly_n, p.poly_sigma));
   } else {
     for (int k = levels; k >= 0; --k) {
@@ -3082,7 +3086,6 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     int cur = 0;  // cflow[cur] holds the previous (coarser) level's flow
     for (int k = levels; k >= 0; --k) {
       const int lh = geom[k].lh, lw = geom[k].lw;
-      if (overlap && k == 0) ST_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_events[0], 0));
       for (int it = 0; it < p.num_iters; ++it) {
         const bool last = it == p.num_iters - 1;
         IterArgs q;

@@ -24,7 +24,6 @@ struct st_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  // second stream + events for overlapping independent stages of small batches (created lazily)
   // flow-iteration kernel choice for small launches (ST_ITER_TILE, read when the context is created):
   // -1 by total size (default), 0 never the tile kernel, 1 always.  The two kernels agree bit for
   // bit, so this is a scheduling switch only.
@@ -34,8 +33,6 @@ struct st_ctx {
   // role-split kernels (scheduling switches like tile_mode, read when the context is created; results do not depend on them):
   // ST_ITER_ROLES / ST_PYR_ROLES: -1 by launch size (default), 0 never, 1 always; ST_ROLES_NCW: 0 = by cost, 4 or 5 column waves
   int roles_mode = -1, roles_ncw = 0, roles_rows = 0, pyr_roles = -1;
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t aux_events[8] = {};
   // bump-allocated scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
