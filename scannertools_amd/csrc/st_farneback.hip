@@ -2729,7 +2729,10 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   a.strip_w = ((w + strips - 1) / strips + 7) / 8 * 8;
   // each segment re-reads 16 rows of context, but the launch needs a few rounds of workgroups per
   // CU to balance (3 resident per CU): 8 per CU measured best at 257 frames of 1080p
-  long long segs = ((long long)ctx->num_cus * 8 + (long long)strips * n - 1) / ((long long)strips * n);
+  // (the role-split instance keeps two 12-wave workgroups per unit: 14 per CU measured best -- 257 frames of 1080p:
+  // 1.71 / 1.43 / 1.30 / 1.23 / 1.27 ms at 1 / 2 / 4 / 7 / 9 segments)
+  const bool roles_on = gray && ctx->pyr_roles != 0;
+  long long segs = ((long long)ctx->num_cus * (roles_on ? 14 : 8) + (long long)strips * n - 1) / ((long long)strips * n);
   int rows = (int)((h + segs - 1) / segs);
   rows = (rows + 7) / 8 * 8;
   // (a few frames only: down to 16-row segments -- twice the rows are read, but the launch is
@@ -2737,13 +2740,13 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   static const int env_min = getenv("ST_PYR_MINROWS") ? atoi(getenv("ST_PYR_MINROWS")) : 0;
   const int min_rows = (long long)strips * n * ((h + 63) / 64) >= 2LL * ctx->num_cus ? 64 : (env_min > 0 ? (env_min + 7) / 8 * 8 : 16);
   if (rows < min_rows) rows = h < min_rows ? h : min_rows;
+  static const int force_rows = getenv("ST_PYR_SEGROWS") ? atoi(getenv("ST_PYR_SEGROWS")) : 0;  // experiments
+  if (force_rows >= 8) rows = (force_rows + 7) / 8 * 8;
   a.rows_per_seg = rows;
   st_timed t(ctx, ST_K_PYR);
-  // role-split instance (k_pyr_roles): ST_PYR_ROLES=0 never, 1 always, default by launch size (experiments below)
+  // role-split instance (k_pyr_roles) unless ST_PYR_ROLES=0 (read at st_ctx_create): 257 frames 1.23 against 1.50 ms, two frames 25 against 43 us
   const int roles_env = ctx->pyr_roles;
-  static const long long roles_max = getenv("ST_PYR_ROLES_MAX") ? atoll(getenv("ST_PYR_ROLES_MAX")) : 4096;
-  const long long wgs = (long long)strips * ((h + rows - 1) / rows) * n;
-  const bool roles = gray && (roles_env == 1 || (roles_env != 0 && wgs <= roles_max));
+  const bool roles = gray && roles_env != 0;
   if (roles) hipLaunchKernelGGL(k_pyr_roles, dim3(strips, (h + rows - 1) / rows, n), dim3(768), 0, ctx->stream, a);
   else if (gray) hipLaunchKernelGGL(k_pyr_fused<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_pyr_fused<true>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);

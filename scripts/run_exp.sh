@@ -1,4 +1,5 @@
 cd "$GRAFT_REPO_ROOT"
-source scripts/exp_small2.sh
-BATCHES="1 2 4 8" run single0 ST_POLY_SINGLE_MAX=0
-BATCHES="1 2 4 8" run single8 ST_POLY_SINGLE_MAX=8
+export ST_BENCH_NO_KERNEL_TIMING=1 ST_PYR_ROLES=1
+for r in 216 184 160 136 120 96 64; do
+  ST_PYR_SEGROWS=$r bash scripts/trace_small.sh 256 3 > /dev/null; echo "rows $r: $(grep k_pyr gpurun_out/ts_256/timeline.txt)"
+done

@@ -1,0 +1,115 @@
+"""GPU: parity at the BASELINE.json configurations THEMSELVES (not only at their resolutions): the batch sizes, frame
+counts and network geometry the configurations name, each against the oracle (or torch float arithmetic on the CPU for
+the pose network, whose parity target it is: DESIGN.md 4.11) on a sample, plus the size-independent properties.
+
+  config 1  Histogram, 256 bins, 1000 host-resident 1080p frames through the DeviceType::CPU registration
+  config 2  (the headline: covered by bench.py's own `parity` block and tests/test_flow_gpu.py's 1080p cases)
+  config 3  (10 000-frame shot pipeline: tests/test_shots_gpu.py, tests/test_engine_gpu.py)
+  config 4  OpticalFlow at 3840x2160, 32 pairs (33 frames) in ONE call
+  config 5  the pose network at its real 368x656 input: one convolution per distinct (map size, kernel size) of the
+            92-layer list in both arithmetics, and the whole network on a batch of 2
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from scannertools_amd import pose_net
+from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+from test_flow_gpu import _check_flow, _torch_stream
+from test_pose_net_gpu import MATH, _conv
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- config 1
+def test_config1_histogram_1000_host_frames():
+    """1000 x 1080p frames in host memory -> sc.ops.Histogram(device=CPU, bins=256, batch=64) (the staged kernel class:
+    uploads on a copy stream, histograms on the compute stream) -> every 97th row against the oracle, every row's
+    bins summing to the pixel count."""
+    n, h, w = 1000, 1080, 1920
+    g = torch.Generator(device="cuda").manual_seed(11)
+    host = torch.empty((n, h, w, 3), dtype=torch.uint8)
+    for i in range(0, n, 50):   # distinct frames: a noise field per chunk, brightness ramp and roll per frame
+        base = torch.randint(0, 256, (h, w, 3), dtype=torch.int16, device="cuda", generator=g)
+        chunk = torch.stack([((torch.roll(base, (3 * j, 5 * j), (0, 1)) * (50 + (i + j) % 150)) // 200).clamp_(0, 255).to(torch.uint8)
+                             for j in range(50)])
+        host[i:i + 50] = chunk.cpu()
+    frames = host.numpy()
+    sc = Client()
+    sc.ingest_frames("c1", frames)
+    out = NamedStream(sc, "c1_hist")
+    sc.run(sc.io.Output(sc.ops.Histogram(frame=sc.io.Input([NamedVideoStream(sc, "c1")]), device=DeviceType.CPU, batch=64, bins=256), [out]),
+           PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    rows = list(out.load())
+    assert len(rows) == n
+    for i, r in enumerate(rows):
+        r = np.stack(r)
+        assert r.shape == (3, 256) and r.dtype == np.int32
+        assert (r.sum(axis=1) == h * w).all(), i
+        if i % 97 == 0 or i == n - 1:
+            np.testing.assert_array_equal(r, oracle.hist_u8c3(frames[i], 256), err_msg="frame %d" % i)
+
+
+# ---------------------------------------------------------------- config 4
+def test_config4_4k_batch32_in_one_call(hip_ctx):
+    """33 frames of 3840x2160 -> 32 flow fields in one st_farneback_pairs call (what `batch=32` on the op hands the
+    kernel): pairs 0, 15 and 31 against the oracle, pair 15 computed alone equal to its field in the batch bit for bit,
+    every field finite and moving by the planted step in its interior."""
+    h, w, n = 2160, 3840, 33
+    d = _torch_stream(n, h, w, 23, step=2)
+    got = hip_ctx.optical_flow(d)
+    assert tuple(got.shape) == (32, h, w, 2)
+    assert bool(torch.isfinite(got).all())
+    # _torch_stream shifts the texture window by (-step) columns and (+1) row per frame: next(x + 2, y - 1) = prev(x, y)
+    med = got[:, 400:-400, 400:-400].reshape(32, -1, 2).median(dim=1).values.cpu().numpy()
+    assert np.abs(med[:, 0] - 2).max() < 0.1 and np.abs(med[:, 1] + 1).max() < 0.1, med
+    fr = {i: d[i].cpu().numpy() for i in (0, 1, 15, 16, 31, 32)}
+    for i in (0, 15, 31):
+        _check_flow(got[i].cpu().numpy(), oracle.optical_flow_rgb(fr[i], fr[i + 1]))
+    single = hip_ctx.optical_flow(d[15:17])
+    assert torch.equal(single[0], got[15])
+
+
+# ---------------------------------------------------------------- config 5
+# (n, h, w, ci, co, k): one layer of every distinct (map size, kernel size) of the 368x656 network (pose_net.all_layers):
+# conv1_1 / conv1_2 at the input size, conv2 at 1/2, conv3 at 1/4, conv4 + the stage layers at 1/8 (46x82: 943 blocks of 128
+# pixels per 32 frames, the tile-quantisation edge the small-map tests do not reach)
+NET_SHAPES = [(1, 368, 656, 3, 64, 3), (1, 368, 656, 64, 64, 3), (1, 184, 328, 64, 128, 3), (1, 92, 164, 128, 256, 3),
+              (2, 46, 82, 256, 512, 3), (2, 46, 82, 185, 128, 7), (2, 46, 82, 128, 128, 7), (2, 46, 82, 128, 512, 1),
+              (2, 46, 82, 512, 38, 1), (2, 46, 82, 128, 19, 1)]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,k", NET_SHAPES)
+@pytest.mark.parametrize("math", MATH)
+def test_config5_layers_at_network_geometry(hip_ctx, n, h, w, ci, co, k, math):
+    g = torch.Generator().manual_seed(h + ci + co + k)
+    x = torch.randn((n, ci, h, w), generator=g)
+    wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))
+    b = torch.randn((co,), generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=k // 2))
+    cip = (ci + 15) // 16 * 16
+    xn = torch.zeros((n, h, w, cip))
+    xn[..., :ci] = x.permute(0, 2, 3, 1)
+    y = _conv(hip_ctx, xn.cuda(), cip, 0, wt, b, 1, math=math)
+    got = y[..., :co].permute(0, 3, 1, 2).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (float((got - ref).abs().max()), scale)
+    assert float((got - ref).norm() / ref.norm()) <= 2e-6
+    assert (y[..., co:] == -7.0).all()
+
+
+@pytest.mark.parametrize("math", MATH)
+def test_config5_network_at_368x656(hip_ctx, math):
+    """All 92 convolutions + 3 poolings at the network's real input (a 1080p frame at scale 368/1080: 368x656), batch 2,
+    against the float32 torch network on the CPU."""
+    net = pose_net.PoseNet(hip_ctx, seed=5, math=math)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand((2, 3, 368, 656), generator=g) - 0.5
+    got = net.forward(x.cuda()).permute(0, 3, 1, 2).cpu()
+    ref = net.reference_forward(x, device="cpu")
+    assert got.shape == ref.shape == (2, 57, 46, 82)
+    scale = float(ref.abs().max())
+    assert scale > 1e-3
+    assert float((got - ref).abs().max()) <= 1e-3 * scale, (float((got - ref).abs().max()), scale)
+    assert float((got - ref).norm() / ref.norm()) <= 1e-4
