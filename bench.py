@@ -650,13 +650,15 @@ def run_rank(args):
             tj = tj_all.get("k_flow_iter3") or tj_all["k_flow_iter"]
             # the counters belong to the kernel source they were taken with: a profile of an older kernel is not
             # divided by this run's launch time
-            want = tj_all.get("_meta", {}).get("source_sha256", {}).get("st_farneback.hip")
-            have = hashlib.sha256(open(os.path.join(ROOT, "scannertools_amd", "csrc", "st_farneback.hip"), "rb").read()).hexdigest()
+            # (the kernel's own file, the shared header that sets its address spaces, and the compiler flags)
+            guard = ("st_farneback.hip", "st_internal.h", "Makefile")
+            want = [tj_all.get("_meta", {}).get("source_sha256", {}).get(f) for f in guard]
+            have = [hashlib.sha256(open(os.path.join(ROOT, "scannertools_amd", "csrc", f), "rb").read()).hexdigest() for f in guard]
             if want == have:
                 traffic = float(tj["hbm_bytes_per_launch"])
                 l2_hit = tj.get("L2_hit_rate")
             else:
-                traffic_note = ("profiles/traffic.json was taken with another version of st_farneback.hip: traffic withheld "
+                traffic_note = ("profiles/traffic.json was taken with another version of st_farneback.hip / st_internal.h / the Makefile: traffic withheld "
                                 "(re-run scripts/profile_round.sh)")
         except Exception:
             traffic = None

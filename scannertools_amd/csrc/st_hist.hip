@@ -349,27 +349,61 @@ int hist_check(st_ctx* ctx, int n, int h, int w, int bins, const void* out) {
 // the flags against the golden lists produced by importing the reference, and against the host op on random streams.
 // One thread per frame (a window is <= 2 W values read three times, L1/L2-resident): 10 000 frames in ~40 us.
 // ---------------------------------------------------------------------------------------------------------------
+// a block of at most 128 values: numpy's unrolled loop
 template <class F>
-__device__ double np_pairwise(const F& f, int lo, int n) {
+__device__ __forceinline__ double np_pairwise_leaf(const F& f, int lo, int n) {
   if (n < 8) {
     double r = 0.;
     for (int i = 0; i < n; ++i) r += f(lo + i);
     return r;
   }
-  if (n <= 128) {
-    double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3), r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-      r0 += f(lo + i); r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
-      r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += f(lo + i);
-    return res;
+  double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3), r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 += f(lo + i); r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
+    r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
   }
-  int n2 = n / 2;
-  n2 -= n2 % 8;
-  return np_pairwise(f, lo, n2) + np_pairwise(f, lo + n2, n - n2);
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res += f(lo + i);
+  return res;
+}
+
+// numpy's recursion (n > 128: pairwise(left half rounded down to a multiple of 8) + pairwise(rest)) evaluated with an
+// explicit stack in the same post-order, so that the depth a thread needs is a compile-time bound instead of a device
+// call stack: a range halves down to <= 128 values in at most 24 levels for n < 2^31.
+template <class F>
+__device__ double np_pairwise(const F& f, int lo, int n) {
+  if (n <= 128) return np_pairwise_leaf(f, lo, n);
+  constexpr int kDepth = 32;
+  int s_lo[kDepth], s_n[kDepth], s_state[kDepth];
+  double s_left[kDepth];
+  int sp = 0;
+  s_lo[0] = lo; s_n[0] = n; s_state[0] = 0; s_left[0] = 0.;
+  double result = 0.;
+  while (sp >= 0) {
+    const int cn = s_n[sp], clo = s_lo[sp];
+    if (cn <= 128) {
+      result = np_pairwise_leaf(f, clo, cn);
+      --sp;
+      continue;
+    }
+    int n2 = cn / 2;
+    n2 -= n2 % 8;
+    if (s_state[sp] == 0) {          // descend into the left part
+      s_state[sp] = 1;
+      ++sp;
+      s_lo[sp] = clo; s_n[sp] = n2; s_state[sp] = 0;
+    } else if (s_state[sp] == 1) {   // left part done: keep it, descend into the right part
+      s_left[sp] = result;
+      s_state[sp] = 2;
+      ++sp;
+      s_lo[sp] = clo + n2; s_n[sp] = cn - n2; s_state[sp] = 0;
+    } else {                         // both done
+      result = s_left[sp] + result;
+      --sp;
+    }
+  }
+  return result;
 }
 
 // diffs[0] = 0; diffs[i] = mean over the 3 channels of max_b |h[i-1][c][b] - h[i][c][b]| (shot_detection.py:14-18:
@@ -413,6 +447,8 @@ ST_EXPORT int st_shot_boundaries(st_ctx* ctx, const int32_t* hist_dev, int n, in
   if (n < 0 || bins < 1 || bins > 65536 || window < 1 || (n > 0 && (!hist_dev || !flags_dev)))
     return st_set_error(ctx, ST_ERR_INVALID, "shot boundaries: bad arguments (n=%d bins=%d window=%d)", n, bins, window);
   if (n == 0) return ST_OK;
+  // a window of more than n frames on either side is the whole stream for every frame (and i + window must stay an int)
+  if (window > n) window = n;
   double* d = diffs_dev;
   if (!d) {
     ST_TRY(st_ws_reserve(ctx, st_align_up(sizeof(double) * (size_t)n)));

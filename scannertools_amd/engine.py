@@ -451,6 +451,8 @@ class _PyOpNode(_Node):
 
     def rows(self, idx):
         n = self.parent.length()
+        if n == 0:
+            return []   # an op over an empty stream is never called
         elements = [self.deserialize(e) for e in self.parent.rows(list(range(n)))]
         res = self.fn(None, elements)
         if len(res) != n:
@@ -669,6 +671,8 @@ class _Ops:
             def on_device(config, elements):
                 import torch
                 from .hip import HipContext
+                if not elements:
+                    return _shot.shot_boundaries(config, elements)   # empty stream: no device work, the host op's answer
                 h = torch.from_numpy(np.ascontiguousarray(np.stack([np.stack(e) for e in elements]).astype(np.int32))).to("cuda:%d" % sc.device_id)
                 with HipContext(sc.device_id) as ctx:
                     return _shot.shot_boundaries_device(ctx, h)

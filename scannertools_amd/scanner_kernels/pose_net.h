@@ -185,13 +185,21 @@ class Net {
   // default float32 instruction.  The reference's op arguments (CPM2Args / OpenPoseArgs) have no field for it.
   Net() {
     const char* m = getenv("SCANNERTOOLS_POSE_MATH");
-    bf16x3_ = m && std::string(m) == "bf16x3";
+    const std::string v = m ? m : "";
+    bf16x3_ = v == "bf16x3";
+    // anything but the two arithmetics is a configuration error, reported by load() (kernel validation): it must not
+    // silently select float32
+    if (!(v.empty() || v == "f32" || v == "bf16x3")) bad_math_ = v;
   }
   ~Net() { release(); }
   bool bf16x3() const { return bf16x3_; }
 
   // Loads the weights, packs them as [cout_pad][k][k][cin_pad] and uploads them to the current device.
   bool load(const std::string& caffemodel, std::string* err) try {
+    if (!bad_math_.empty()) {
+      *err = "SCANNERTOOLS_POSE_MATH=" + bad_math_ + " is not an arithmetic of this build (f32, bf16x3)";
+      return false;
+    }
     std::map<std::string, Blobs> blobs;
     if (!read_caffemodel(caffemodel, &blobs, err)) return false;
     for (auto& l : all_layers()) {
@@ -297,9 +305,14 @@ class Net {
   int conv(st_ctx* ctx, const float* x, int n, int h, int w, int cin, int xs, int xoff, Packed& p, const LayerSpec& l, float* y, int ys, int yoff) {
     if (!bf16x3_) return st_conv2d_nhwc_f32(ctx, x, n, h, w, cin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
     if (!p.w3) {
-      if (hipMalloc(&p.w3, (size_t)p.cout_pad * l.k * l.k * p.cin_pad * 6) != hipSuccess) return ST_ERR_HIP;
-      const int st = st_conv_pack_weights_bf16x3(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, p.w3);
-      if (st != ST_OK) return st;
+      void* w3 = nullptr;
+      if (hipMalloc(&w3, (size_t)p.cout_pad * l.k * l.k * p.cin_pad * 6) != hipSuccess) return ST_ERR_HIP;
+      const int st = st_conv_pack_weights_bf16x3(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, w3);
+      if (st != ST_OK) {  // an unpacked buffer must never be mistaken for packed weights by the next call
+        (void)hipFree(w3);
+        return st;
+      }
+      p.w3 = w3;
     }
     return st_conv2d_nhwc_bf16x3(ctx, x, n, h, w, cin, xs, xoff, p.w3, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
   }
@@ -360,6 +373,7 @@ class Net {
 
   std::map<std::string, Packed> packed_;
   bool bf16x3_ = false;
+  std::string bad_math_;
   static constexpr int kMaxSlots = 8;
   struct Slot {
     float* cat[2] = {nullptr, nullptr};

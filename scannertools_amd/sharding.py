@@ -58,9 +58,13 @@ def spawn_ranks(script, argv, n, port=0, timeout=None, grace=5.0):
         raise _Stop("signal %d" % signum)
 
     in_main = threading.current_thread() is threading.main_thread()
-    saved = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)} if in_main else {}
+    saved = {}
+    late = []   # signals that arrive while the ranks are being stopped: recorded, never raised out of the clean-up
     reader, why = None, None
     try:
+        if in_main:   # installed inside the try: a signal between installation and the loop is caught like any other
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                saved[sig] = signal.signal(sig, on_signal)
         for r in range(n):
             env = dict(os.environ)
             env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
@@ -85,9 +89,15 @@ def spawn_ranks(script, argv, n, port=0, timeout=None, grace=5.0):
     except _Stop as e:
         why = str(e)
     finally:
-        stop_all()
-        for sig, h in saved.items():
-            signal.signal(sig, h)
+        try:
+            for sig in saved:   # a second Ctrl-C during the grace wait must not skip the kill escalation below
+                signal.signal(sig, lambda signum, frame: late.append(signum))
+            stop_all()
+        finally:
+            for sig, h in saved.items():
+                signal.signal(sig, h)
+        if late and not why:
+            why = "signal %d" % late[0]
     if reader is not None:
         reader.join(grace)
     out0 = "".join(c for c in chunks if c)

@@ -83,5 +83,5 @@ def shot_boundaries_device(ctx, histograms) -> Sequence[Any]:
     back to the host op."""
     n = int(histograms.shape[0])
     if n == 0:
-        return []
+        return [[]]   # what the host op returns for an empty stream ([boundaries] + [None] * -1)
     return [ctx.shot_boundaries(histograms, WINDOW_SIZE, 2.5)] + [None for _ in range(n - 1)]

@@ -47,6 +47,7 @@ for k in sorted(acc):
 # which kernel sources the counters belong to: bench.py reports `traffic` only while they still match
 import hashlib
 src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scannertools_amd", "csrc")
+# (st_internal.h and the Makefile shape the kernels' code generation too: st_gl's address spaces, -fno-slp-vectorize)
 res["_meta"] = {"source_sha256": {f: hashlib.sha256(open(os.path.join(src, f), "rb").read()).hexdigest()
-                                  for f in ("st_farneback.hip", "st_hist.hip")}}
+                                  for f in ("st_farneback.hip", "st_hist.hip", "st_internal.h", "Makefile")}}
 print(json.dumps(res, indent=1))

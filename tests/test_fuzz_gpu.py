@@ -53,14 +53,30 @@ def test_fuzz_integer_ops(hip_ctx, seed):
             np.testing.assert_array_equal(got[i], oracle.draw_flow(frames[i], flows[i]), err_msg="draw_flow %dx%d" % (h, w))
 
 
-# seeds >= 100: the pairs of the round-3 campaigns (300 + 1 500 seeds) that need tiers 2 / 3 of util.assert_flow_close
+# seeds >= 100: the pairs of the round-3 campaigns (300 + 1 500 seeds) that need tiers 2 / 3 of util.assert_flow_close.
+# EXPECTED_TIERS pins what each seed is allowed: the tier of every one of its flow fields, in order (the results are the
+# same bits under every scheduling mode, so one list per seed).  A field that needs a HIGHER tier than recorded fails --
+# seeds 0, 1, 2 are plain-bounds seeds and must stay so -- and a field that needs a lower one is reported, so that the list
+# is tightened rather than left to rot.
+EXPECTED_TIERS = {}
+EXPECTED_TIERS_FILE = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "flow_fuzz_tiers.json")
+
+
+def _expected_tiers():
+    if not EXPECTED_TIERS:
+        import json
+        EXPECTED_TIERS.update({int(k): v for k, v in json.load(open(EXPECTED_TIERS_FILE)).items()})
+    return EXPECTED_TIERS
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 103, 121, 268, 520, 976, 1420, 2876, 4079])
 def test_fuzz_optical_flow(flow_ctx, seed):
     """Random frame sizes (including ones smaller than the window and ones that change the number of
     pyramid levels) and random pair lists; every flow field against the oracle, under every
-    scheduling mode of the flow iteration."""
+    scheduling mode of the flow iteration, each at the tolerance tier recorded for it."""
     hip_ctx = flow_ctx
     rng = np.random.default_rng(77 + seed)
+    tiers = []
     for _ in range(4):
         h, w = int(rng.integers(2, 150)), int(rng.integers(2, 200))
         nf = int(rng.integers(2, 5))
@@ -70,7 +86,19 @@ def test_fuzz_optical_flow(flow_ctx, seed):
         got = hip_ctx.optical_flow(_cu(frames), pairs=pairs).cpu().numpy()
         for i, (a, b) in enumerate(pairs):
             ref = oracle.optical_flow_rgb(frames[a], frames[b])
-            FLOW_TIERS[assert_flow_close(got[i], ref, frames[a], frames[b], (h, w, a, b))] += 1
+            tier = assert_flow_close(got[i], ref, frames[a], frames[b], (h, w, a, b))
+            FLOW_TIERS[tier] += 1
+            tiers.append(tier)
+    import os
+    if os.environ.get("ST_RECORD_FLOW_TIERS"):   # (re)generate tests/golden/flow_fuzz_tiers.json: see scripts/record_flow_tiers.sh
+        print("FLOW_TIERS_RECORD %d %s" % (seed, tiers))
+        return
+    want = _expected_tiers()[seed]
+    assert len(tiers) == len(want), (seed, tiers, want)
+    worse = [(i, t, e) for i, (t, e) in enumerate(zip(tiers, want)) if t > e]
+    assert not worse, "seed %d: flow fields needing a higher tolerance tier than recorded (field, needed, recorded): %s" % (seed, worse)
+    if seed in (0, 1, 2):
+        assert max(tiers) == 1, (seed, tiers)
 
 
 @pytest.mark.parametrize("seed", range(4))

@@ -225,6 +225,15 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, model_dir, tmp_path):
             np.testing.assert_array_equal(j, joints3[i].cpu().numpy())
     finally:
         del os.environ["SCANNERTOOLS_POSE_MATH"]
+    # a value that names no arithmetic of the build is a validation error of the kernel instance, not a silent float32
+    os.environ["SCANNERTOOLS_POSE_MATH"] = "fp8"
+    try:
+        with pytest.raises(RuntimeError, match="SCANNERTOOLS_POSE_MATH"):
+            sc = Client()
+            m_col, _ = sc.ops.CPM2(cpm2_input=_Rows([x[0]]), weights=path, device=DeviceType.GPU)
+            sc.run(sc.io.Output(m_col, [NamedStream(sc, "m_bad")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    finally:
+        del os.environ["SCANNERTOOLS_POSE_MATH"]
 
     cut = tmp_path / "cut.caffemodel"
     with open(path, "rb") as fh:

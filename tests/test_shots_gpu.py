@@ -108,8 +108,33 @@ def test_device_shot_boundaries_extremes(hip_ctx):
     got = hip_ctx.shot_boundaries(torch.from_numpy(h).cuda())
     assert got == shot_detection.shot_boundaries(None, list(h))[0] and len(got) > 10
     short = torch.from_numpy(h[:40]).cuda()
-    assert hip_ctx.shot_boundaries(short, window=5000) == [i for i in range(1, 40) if
-                                                            (lambda d: d[i] - np.mean(d) > 2.5 * np.std(d))(shot_detection.histogram_diffs(h[:40]))]
+    whole = [i for i in range(1, 40) if (lambda d: d[i] - np.mean(d) > 2.5 * np.std(d))(shot_detection.histogram_diffs(h[:40]))]
+    assert hip_ctx.shot_boundaries(short, window=5000) == whole
+    assert hip_ctx.shot_boundaries(short, window=2 ** 31 - 1) == whole      # i + window must not overflow an int
+    # a window of a whole 30 000-frame stream: every frame sums all of it (numpy's recursion 8 levels deep, evaluated with the
+    # kernel's explicit stack; the work is quadratic in the stream, hence not the 200 000 frames), against numpy itself
+    m = 30000
+    d = shot_detection.histogram_diffs(h[:m])
+    got = set(hip_ctx.shot_boundaries(torch.from_numpy(h[:m]).cuda(), window=m))
+    want = set(int(i) for i in np.nonzero(d - np.mean(d) > 2.5 * np.std(d))[0] if i > 0)
+    assert got == want and len(got) > 2
+
+
+@pytest.mark.gpu
+def test_shot_boundaries_of_an_empty_stream(hip_ctx):
+    """No frames: the device function answers like the host op ([[]]), and the op on the GPU through the engine yields no rows."""
+    import torch
+    from scannertools_amd import shot_detection
+    from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+    assert shot_detection.shot_boundaries(None, []) == [[]]
+    assert shot_detection.shot_boundaries_device(hip_ctx, torch.zeros((0, 3, 16), dtype=torch.int32, device="cuda")) == [[]]
+    sc = Client()
+    sc.ingest_frames("empty", np.zeros((0, 8, 8, 3), np.uint8))
+    hist = sc.ops.Histogram(frame=sc.io.Input([NamedVideoStream(sc, "empty")]), device=DeviceType.CPU)
+    for dev in (DeviceType.CPU, DeviceType.GPU):
+        out = NamedStream(sc, "empty_sb_%d" % dev)
+        sc.run(sc.io.Output(sc.ops.ShotBoundaries(histograms=hist, device=dev), [out]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+        assert list(out.load()) == []
 
 
 @pytest.mark.gpu

@@ -131,8 +131,9 @@ def assert_flow_close(got, ref, frame_a, frame_b, what=""):
     When tier 1 fails, the independent float64 derivation (tests/ref_farneback_np.py) arbitrates:
       tier 2 (noise): every pixel within max(5e-3, 2 x the oracle's own distance from exact arithmetic + 1e-3), at most
               0.5 % of the field needing that, and relative L2 <= 1e-4 (or RMS <= 5e-4 px where the whole flow is noise,
-              as for identical frames) over the pixels where the oracle is within 1e-3 px of exact arithmetic -- or,
-              field-wide, the kernel within half again of the oracle's own distance from exact arithmetic (max and L2);
+              as for identical frames) over the pixels where the oracle is within 1e-3 px of exact arithmetic -- or
+              the kernel within half again of the oracle's own distance from exact arithmetic: every pixel against the
+              oracle's worst distance within its 45 x 45 neighbourhood, and in L2 over the field;
       tier 3 (branch flip): the pixels beyond 5e-3 are at most 0.75 % of the field (or two 15 x 15 box windows, whichever is
               more: one flipped pixel moves its whole window), each lies within 24 px of the frame
               border or where the float64 normal equations have det + 1e-3 <= 0.05 (textured 8-bit images: 1e2..1e4),
@@ -159,9 +160,14 @@ def assert_flow_close(got, ref, frame_a, frame_b, what=""):
 
     if (d <= np.maximum(5e-3, 2.0 * noise + 1e-3)).all() and out.mean() <= 5e-3 and rel_or_rms(noise <= 1e-3):
         return 2
-    # ... or, field-wide: the kernel is as close to exact arithmetic as the oracle is (within half again)
-    eg = np.abs(got - f64)
-    if eg.max() <= 1.5 * noise.max() + 5e-3 and np.linalg.norm(eg) <= 1.5 * np.linalg.norm(ref - f64) + 1e-4 * np.linalg.norm(f64) + 1e-6:
+    # ... or: the kernel is as close to exact arithmetic as the oracle is (within half again) -- pixel by pixel against the
+    # oracle's own distance in the pixel's neighbourhood (45 x 45: three iterations of the 15 x 15 box filter carry one pixel's
+    # rounding residue that far), not against the worst pixel of the field, so that one noisy pixel in a corner cannot excuse
+    # an error somewhere else
+    from scipy import ndimage as _ndi
+    eg = np.abs(got - f64).max(-1)
+    local = _ndi.maximum_filter(noise, size=45, mode="nearest")
+    if (eg <= 1.5 * local + 5e-3).all() and np.linalg.norm(got - f64) <= 1.5 * np.linalg.norm(ref - f64) + 1e-4 * np.linalg.norm(f64) + 1e-6:
         return 2
     # tier 3: where are the outliers?
     # one flipped pixel moves its whole 15 x 15 box window: on frames of a few thousand pixels two windows are more than 0.75 %
