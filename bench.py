@@ -432,6 +432,46 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
     except Exception as e:  # an auxiliary record must not take the headline down
         out['config5_pose_conv_stack'] = {"error": repr(e)}
 
+    # (v) the pipeline the reference's authors ran, at its own geometry (old/histograms.py:63-78): Resize(426x240) -> OpticalFlow
+    # -> FlowHistogram, device-resident through the C ABI and host-fed through the kernel classes; Farneback at 640x480
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_legacy", os.path.join(ROOT, "scripts", "bench_legacy.py"))
+        bl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bl)
+        nl = min(args.batch, 256)
+        rec = bl.measure(torch, ctx, device, batches[0][:nl + 1], batches=tuple(b for b in (64, 256) if b <= nl), steps=6)
+        from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
+        nh = min(args.batch, 192)
+        host = batches[0][:nh].cpu().pin_memory()
+        scl = Client(device_id=device.index)
+        scl.ingest_frames("lv", host.numpy())
+        fed = {"frames": nh}
+
+        def run_op(node, name):
+            o = NamedStream(scl, "legacy_" + name)
+            scl.execute_seconds, scl.steady_seconds, scl.steady_rows = 0.0, 0.0, 0
+            scl.run(scl.io.Output(node, [o]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+            return o, (scl.steady_rows / scl.steady_seconds if scl.steady_rows else nh / scl.execute_seconds)
+
+        small_s, r_resize = run_op(scl.ops.Resize(frame=scl.io.Input([NamedVideoStream(scl, "lv")]), width=426, height=240,
+                                                  device=DeviceType.CPU, batch=64), "resize")
+        scl.ingest_frames("lsmall", np.stack(list(small_s.load())))
+        flow_s, r_flow = run_op(scl.ops.OpticalFlow(frame=scl.io.Input([NamedVideoStream(scl, "lsmall")]), device=DeviceType.CPU, batch=64), "flow")
+        fed.update({"Resize_frames_per_s": r_resize, "Resize_input_GBs": r_resize * 3 * h * w / 1e9,
+                    "OpticalFlow_426x240_frames_per_s": r_flow,
+                    "pipelined_frames_per_s": min(r_resize, r_flow),
+                    "what": "DeviceType::CPU registrations (host frames in, host results out), batch 64, rows / seconds inside the execute() "
+                            "calls after the first; the stages run as separate graph ops, the pipelined rate is the slowest stage's: the "
+                            "1080p upload of Resize (6.2 MB per frame in, 0.3 MB out), i.e. the H2D bound"})
+        rec["host_fed"] = fed
+        out["legacy_flow_hist"] = rec
+        del scl, host
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+    except Exception as e:  # auxiliary record
+        out["legacy_flow_hist"] = {"error": repr(e)}
+
     # (ii) host-fed: frames in (page-locked) host memory -> results in host memory through the
     # DeviceType::CPU-registered kernel classes; time inside execute() (PCIe-inclusive)
     try:

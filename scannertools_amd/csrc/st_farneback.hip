@@ -362,9 +362,12 @@ __global__ __launch_bounds__(256) void k_pyr(PyrArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Level 0 of the pyramid (no resize, 3x3 kernel): a pure u8 -> f32 stream.  Each thread owns
-// four adjacent columns (one aligned dword of gray per row, float4 store) and marches down a
+// four adjacent columns (one dword of gray per row, one 16-byte store) and marches down a
 // segment keeping the three row-filtered rows of the column filter in registers.
-// Requires w % 4 == 0 and h >= 2; other shapes take the generic k_pyr path.
+// Any width >= 2 (rows of w % 4 != 0 start at any byte: the dword loads and the 16-byte stores are then unaligned, which
+// global memory allows; the thread that holds a row's last, partial group of columns goes bytewise) and h >= 2; 426 x 240,
+// the legacy flow-histogram pipeline's size, takes this kernel instead of the generic tile kernel (216 -> 40 us per 257
+// frames).
 // ---------------------------------------------------------------------------------------------
 struct Pyr0Args {
   const uint8_t* gray;  // n x (h*w)
@@ -374,14 +377,24 @@ struct Pyr0Args {
 };
 
 __device__ __forceinline__ void pyr0_hrow(const uint8_t* __restrict__ g, int w, int x0, float k0, float k1, float hb[4]) {
-  const unsigned q = *reinterpret_cast<const unsigned*>(g + x0);
-  const float c0 = (float)(q & 0xff), c1 = (float)((q >> 8) & 0xff), c2 = (float)((q >> 16) & 0xff), c3 = (float)(q >> 24);
-  const float l = (float)g[x0 == 0 ? 1 : x0 - 1];
-  const float r = (float)g[x0 + 4 >= w ? w - 2 : x0 + 4];
-  hb[0] = c0 * k0 + (l + c1) * k1;
-  hb[1] = c1 * k0 + (c0 + c2) * k1;
-  hb[2] = c2 * k0 + (c1 + c3) * k1;
-  hb[3] = c3 * k0 + (c2 + r) * k1;
+  if (x0 + 4 <= w) {
+    typedef unsigned u32u __attribute__((aligned(1)));
+    const unsigned q = *reinterpret_cast<const u32u*>(g + x0);
+    const float c0 = (float)(q & 0xff), c1 = (float)((q >> 8) & 0xff), c2 = (float)((q >> 16) & 0xff), c3 = (float)(q >> 24);
+    const float l = (float)g[x0 == 0 ? 1 : x0 - 1];
+    const float r = (float)g[x0 + 4 >= w ? w - 2 : x0 + 4];
+    hb[0] = c0 * k0 + (l + c1) * k1;
+    hb[1] = c1 * k0 + (c0 + c2) * k1;
+    hb[2] = c2 * k0 + (c1 + c3) * k1;
+    hb[3] = c3 * k0 + (c2 + r) * k1;
+  } else {
+    // the row's last group holds 1-3 columns: byte loads with the reflected neighbours, the missing columns unused
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = x0 + j;
+      hb[j] = c < w ? (float)g[c] * k0 + ((float)g[d_reflect101(c - 1, w)] + (float)g[d_reflect101(c + 1, w)]) * k1 : 0.f;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_pyr0(Pyr0Args a) {
@@ -393,17 +406,26 @@ __global__ __launch_bounds__(256) void k_pyr0(Pyr0Args a) {
   float* __restrict__ o = a.img + (size_t)blockIdx.z * np;
   const int y0 = blockIdx.y * a.rows_per_seg;
   const int y1 = min(h, y0 + a.rows_per_seg);
+  const bool full = x0 + 4 <= w;
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   float hm[4], hc[4], hp[4];
   pyr0_hrow(g + (size_t)d_reflect101(y0 - 1, h) * w, w, x0, a.k0, a.k1, hm);
   pyr0_hrow(g + (size_t)y0 * w, w, x0, a.k0, a.k1, hc);
   for (int y = y0; y < y1; ++y) {
     pyr0_hrow(g + (size_t)d_reflect101(y + 1, h) * w, w, x0, a.k0, a.k1, hp);
-    float4 v;
+    f4u v;
     v.x = (hm[0] + hp[0]) * a.k1 + hc[0] * a.k0;
     v.y = (hm[1] + hp[1]) * a.k1 + hc[1] * a.k0;
     v.z = (hm[2] + hp[2]) * a.k1 + hc[2] * a.k0;
     v.w = (hm[3] + hp[3]) * a.k1 + hc[3] * a.k0;
-    *reinterpret_cast<float4*>(o + (size_t)y * w + x0) = v;
+    float* dst = o + (size_t)y * w + x0;
+    if (full) {
+      *reinterpret_cast<f4u*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (x0 + 1 < w) dst[1] = v.y;
+      if (x0 + 2 < w) dst[2] = v.z;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { hm[i] = hc[i]; hc[i] = hp[i]; }
   }
@@ -2635,10 +2657,10 @@ int launch_pyr(st_ctx* ctx, const uint8_t* gray, int n, int h, int w, const Leve
   gaussian_kernel(g.ksize, g.sigma, a.taps);
   const double inv_sx = (double)g.lw / w, inv_sy = (double)g.lh / h;
   a.scale_x = 1. / inv_sx; a.scale_y = 1. / inv_sy;
-  if (g.lh == h && g.lw == w && g.ksize == 3 && w % 4 == 0 && h >= 2 && w >= 8 && !getenv("ST_PYR_GENERIC")) {
+  if (g.lh == h && g.lw == w && g.ksize == 3 && h >= 2 && w >= 8 && !getenv("ST_PYR_GENERIC")) {
     Pyr0Args z;
     z.gray = gray; z.img = img; z.h = h; z.w = w; z.k0 = a.taps[1]; z.k1 = a.taps[2];
-    const int bx = (w / 4 + 255) / 256;
+    const int bx = ((w + 3) / 4 + 255) / 256;
     long long segs = ((long long)ctx->num_cus * 8 + (long long)bx * n - 1) / ((long long)bx * n);
     int rows = (int)((h + segs - 1) / segs);
     if (rows < 32) rows = h < 32 ? h : 32;

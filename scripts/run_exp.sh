@@ -1,5 +1,5 @@
 cd "$GRAFT_REPO_ROOT"
-export ST_BENCH_NO_KERNEL_TIMING=1 ST_PYR_ROLES=1
-for r in 216 184 160 136 120 96 64; do
-  ST_PYR_SEGROWS=$r bash scripts/trace_small.sh 256 3 > /dev/null; echo "rows $r: $(grep k_pyr gpurun_out/ts_256/timeline.txt)"
-done
+export ST_BENCH_NO_KERNEL_TIMING=1
+bash scripts/trace_small.sh 256 4 > /dev/null; echo "== default"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt
+ST_ITER_ROLES=1 ST_ROLES_NCW=4 bash scripts/trace_small.sh 256 4 > /dev/null; echo "== roles4"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt
+ST_ITER_ROLES=1 ST_ROLES_NCW=5 bash scripts/trace_small.sh 256 4 > /dev/null; echo "== roles5"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt

@@ -61,7 +61,9 @@ def test_gray_known_answers(hip_ctx):
 
 
 # ---------------------------------------------------------------- pyramid
-@pytest.mark.parametrize("h,w", [(240, 320), (203, 317), (270, 480), (135, 241)])
+# (240, 426): the legacy flow-histogram pipeline's frame (old/histograms.py:66-67) -- three levels, rows that start at any
+# byte; widths of every residue mod 4 take the streaming level-0 kernel, the last of them with a one-column tail group
+@pytest.mark.parametrize("h,w", [(240, 320), (203, 317), (270, 480), (135, 241), (240, 426), (61, 1027), (40, 1030), (33, 9)])
 def test_pyramid_levels_bit_exact(hip_ctx, h, w):
     gray = (smooth_texture(h + w, h, w) + np.random.default_rng(1).integers(0, 8, (h, w))).clip(0, 255).astype(np.uint8)
     p = default_params()

@@ -422,3 +422,80 @@ def test_cvt_color_xyz_and_layout_family_known_answers():
     assert oracle.cvt_color(f, 0)[..., 3].min() == 255 and np.array_equal(oracle.cvt_color(f, 2)[..., :3], f[..., ::-1])
     g = f[..., :1].copy()
     np.testing.assert_array_equal(oracle.cvt_color(g, 30), oracle.cvt_color(np.repeat(g, 3, axis=2), 22))
+
+
+def test_oracle_against_opencv_golden():
+    """Every tests/golden/opencv_<version>.npz present (written by tests/golden/make_opencv_golden.py on a machine with
+    OpenCV) pins the oracle against REAL OpenCV output: bit-exact for the integer routines, the stated tolerances for the
+    float ones.  None is committed yet -- no OpenCV in the authoring container or on the GPU pool -- so this skips, and the
+    OpenCV-backed rows of DESIGN.md section 2 stay "parity unpinned" until one run elsewhere adds the file."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "opencv_*.npz")))
+    if not files:
+        pytest.skip("no tests/golden/opencv_*.npz: run tests/golden/make_opencv_golden.py where cv2 is importable")
+    for path in files:
+        _check_opencv_golden(path)
+
+
+def _check_opencv_golden(path):
+    if True:
+        z = np.load(path)
+        f = z["hist_in"]
+        for bins in (16, 256):
+            np.testing.assert_array_equal(oracle.hist_u8c3(f, bins), z["hist_%d" % bins])
+        px = np.array([[[1, 2, 255]]], np.uint8)
+        bits = next(b for b in (15, 14) if (oracle.cvt_color(f, oracle.COLOR_BGR2GRAY, gray_bits=b)[..., 0] == z["gray_bgr2gray"]).all())
+        np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_RGB2GRAY, bits)[..., 0], z["gray_rgb2gray"])
+        for key in z.files:
+            if key.startswith("cvt_"):
+                np.testing.assert_array_equal(oracle.cvt_color(f, getattr(oracle, key[4:])), z[key], err_msg=key)
+            if key.startswith("resize_") and key != "resize_in":
+                size, mode = key[7:].split("_", 1)
+                dw, dh = (int(v) for v in size.split("x"))
+                np.testing.assert_array_equal(oracle.resize_u8(z["resize_in"], dw, dh, getattr(oracle, mode)), z[key], err_msg=key)
+        omag, odeg = oracle.cart_to_polar_deg(z["polar_in"])
+        assert np.abs(omag - z["polar_mag"]).max() <= 1e-5 and np.abs(odeg - z["polar_deg"]).max() <= 1e-3
+        got = oracle.flow_hist(z["polar_in"])
+        assert np.abs(got[0] - z["flowhist_mag"]).sum() <= 4 and np.abs(got[1] - z["flowhist_deg"]).sum() <= 4
+        for key in [k[3:-5] for k in z.files if k.startswith("fb_") and k.endswith("_flow")]:
+            f0, f1, ref = z["fb_%s_f0" % key], z["fb_%s_f1" % key], z["fb_%s_flow" % key]
+            got = oracle.optical_flow_rgb(f0, f1, oracle.default_params(gray_bits=bits))
+            rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            assert rel <= 1e-3 and np.abs(got - ref).max() <= 1e-2, (path, key, rel, float(np.abs(got - ref).max()))
+            g0 = oracle.cvt_color(f0, oracle.COLOR_BGR2GRAY, bits)[..., 0].astype(np.float32)
+            assert np.abs(oracle.gaussian_blur(g0, 9, 1.5) - z["fb_%s_blur9" % key]).max() <= 1e-3
+
+
+def test_opencv_golden_checker_reads_the_dump_format(tmp_path):
+    """The checker above against a file in the dump script's format whose "OpenCV" arrays come from the oracle itself: proves
+    that every key the dump writes is found and compared (so that the first real file cannot silently be skipped over)."""
+    from util import texture_stream
+    f = random_frames(0, 1, 97, 131)[0]
+    out = {"cv2_version": np.array("self"), "hist_in": f}
+    for bins in (16, 256):
+        out["hist_%d" % bins] = oracle.hist_u8c3(f, bins)
+    out["gray_bgr2gray"] = oracle.cvt_color(f, oracle.COLOR_BGR2GRAY, 15)[..., 0]
+    out["gray_rgb2gray"] = oracle.cvt_color(f, oracle.COLOR_RGB2GRAY, 15)[..., 0]
+    for name in ("COLOR_BGR2HSV", "COLOR_YCrCb2BGR", "COLOR_BGR2XYZ", "COLOR_HSV2BGR_FULL"):
+        out["cvt_" + name] = oracle.cvt_color(f, getattr(oracle, name))
+    rs = random_frames(1, 1, 97, 131)[0]
+    out["resize_in"] = rs
+    for mname in ("INTER_NEAREST", "INTER_LINEAR", "INTER_CUBIC", "INTER_AREA", "INTER_LANCZOS4"):
+        out["resize_65x48_%s" % mname] = oracle.resize_u8(rs, 65, 48, getattr(oracle, mname))
+    fl = (np.random.default_rng(2).standard_normal((60, 80, 2)) * 9).astype(np.float32)
+    out["polar_in"] = fl
+    out["polar_mag"], out["polar_deg"] = oracle.cart_to_polar_deg(fl)
+    h = oracle.flow_hist(fl)
+    out["flowhist_mag"], out["flowhist_deg"] = h[0], h[1]
+    f0, f1 = translated_rgb_pair(3, 97, 131, 1, -1)
+    out["fb_97x131_f0"], out["fb_97x131_f1"] = f0, f1
+    out["fb_97x131_flow"] = oracle.optical_flow_rgb(f0, f1)
+    out["fb_97x131_blur9"] = oracle.gaussian_blur(oracle.cvt_color(f0, oracle.COLOR_BGR2GRAY, 15)[..., 0].astype(np.float32), 9, 1.5)
+    path = tmp_path / "opencv_self.npz"
+    np.savez_compressed(path, **out)
+    _check_opencv_golden(str(path))
+    out["fb_97x131_flow"] = out["fb_97x131_flow"] + np.float32(0.05)     # and it does compare: a shifted field fails
+    np.savez_compressed(path, **out)
+    with pytest.raises(AssertionError):
+        _check_opencv_golden(str(path))
