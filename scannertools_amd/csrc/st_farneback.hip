@@ -2156,10 +2156,11 @@ struct FrGeom {
   static_assert(THREADS <= 1024 && (NMS == 1 || NMS == 2), "workgroup size");
 };
 
-template <int NCW, int NMS, int MODE>
+template <int NCW, int NMS, int MODE, int RB = 2>
 __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles(IterArgs a) {
   typedef FrGeom<NCW, NMS> G;
-  constexpr int M = 7, W = 15, RB = 2;
+  constexpr int M = 7, W = 15;
+  static_assert(FR_G % (RB * NMS) == 0, "a step is a whole number of batches per maker set");
   __shared__ float Mb[2][FR_G][5][G::COLS];
   __shared__ float Vs[3][FR_G][5][G::PADW];
   __shared__ double Ts[2][FR_G][2 * G::NSEGMAX][5];
@@ -2203,7 +2204,8 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
     // finished, flows one batch further ahead, their loads one more
     float2 fcur[RB], fnext[RB];
     UmLoads L[RB];
-    FlowRaw raw[RB];
+    FlowRaw raw[MODE == FLOW_COARSE2 ? 1 : RB];
+    FlowRawN<RB> rawn;  // FLOW_COARSE2 (coarse level exactly half as tall): the batch's rows share three coarse rows
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       fcur[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(kb + r));
@@ -2211,8 +2213,12 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) fnext[r] = iter_flow_at<MODE>(a, fin, C, cx, xc, rowk(kb + KS + r));
+    if (MODE == FLOW_COARSE2) {
+      coarseN_issue<RB>(a, C, cx, rowk(kb + 2 * KS), rawn);
+    } else {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(kb + 2 * KS + r), raw[r]);
+      for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(kb + 2 * KS + r), raw[r]);
+    }
     for (int sb = 0; sb < T; sb += 2) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -2232,10 +2238,16 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
                 fcur[r] = fnext[r];
                 um_issue(R0, R1, np, h, w, xc, rowk(k0 + KS + r), fcur[r], L[r]);
               }
+              if (MODE == FLOW_COARSE2) {
 #pragma unroll
-              for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, rowk(k0 + 2 * KS + r), raw[r]);
+                for (int r = 0; r < RB; ++r) fnext[r] = coarseN_finish<RB>(a, cx, rowk(k0 + 2 * KS), rowk(k0 + 2 * KS + r), rawn);
+                coarseN_issue<RB>(a, C, cx, rowk(k0 + 3 * KS), rawn);
+              } else {
 #pragma unroll
-              for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(k0 + 3 * KS + r), raw[r]);
+                for (int r = 0; r < RB; ++r) fnext[r] = flow_finish<MODE>(a, fin, C, cx, rowk(k0 + 2 * KS + r), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) flow_issue<MODE>(a, fin, C, cx, xc, rowk(k0 + 3 * KS + r), raw[MODE == FLOW_COARSE2 ? 0 : r]);
+              }
             }
           }
           __syncthreads();
@@ -2952,21 +2964,20 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
       const int rstrips = (a.w + best_out - 1) / best_out;
       dim3 grid(rstrips, (a.h + best_rows - 1) / best_rows, n_pairs);
       st_timed t(ctx, ST_K_BLUR_UPDATE);
-      const int mode = a.coarse ? FLOW_COARSE : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
-      static const int nms_env = getenv("ST_ROLES_NMS") ? atoi(getenv("ST_ROLES_NMS")) : 1;  // maker sets of the 4-wave instance (2: measured slower, 6.8 against 5.2 ms per 256-pair level-0 launch)
+      const int mode = a.coarse ? (a.h == 2 * a.ch ? FLOW_COARSE2 : FLOW_COARSE) : (a.flow_in ? FLOW_FIELD : FLOW_ZERO);
+      // One maker set, two rows of gathers in flight per maker wave.  Measured and not kept (the template parameters remain):
+      // two maker sets of the 4-column-wave instance (16 waves: 6.8 against 5.2 ms per 256-pair level-0 launch), four rows
+      // in flight (163 registers; 8 pairs per call 1.37 against 1.23 ms).
       if (best_ncw == 5) {
         const dim3 blk(FrGeom<5, 1>::THREADS);
-        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_COARSE2>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
         else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_flow_iter_roles<5, 1, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
-      } else if (nms_env == 2) {
-        const dim3 blk(FrGeom<4, 2>::THREADS);
-        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
-        else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_flow_iter_roles<4, 2, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
       } else {
         const dim3 blk(FrGeom<4, 1>::THREADS);
-        if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
+        if (mode == FLOW_COARSE2) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_COARSE2>), grid, blk, 0, ctx->stream, a);
+        else if (mode == FLOW_COARSE) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_COARSE>), grid, blk, 0, ctx->stream, a);
         else if (mode == FLOW_FIELD) hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_FIELD>), grid, blk, 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_flow_iter_roles<4, 1, FLOW_ZERO>), grid, blk, 0, ctx->stream, a);
       }

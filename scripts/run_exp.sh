@@ -1,5 +1,6 @@
 cd "$GRAFT_REPO_ROOT"
-export ST_BENCH_NO_KERNEL_TIMING=1
-bash scripts/trace_small.sh 256 4 > /dev/null; echo "== default"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt
-ST_ITER_ROLES=1 ST_ROLES_NCW=4 bash scripts/trace_small.sh 256 4 > /dev/null; echo "== roles4"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt
-ST_ITER_ROLES=1 ST_ROLES_NCW=5 bash scripts/trace_small.sh 256 4 > /dev/null; echo "== roles5"; grep "k_flow_iter\|step" gpurun_out/ts_256/timeline.txt
+source scripts/exp_small2.sh
+BATCHES="2 4 8 16" run rb2 ST_ROLES_NMS=1
+BATCHES="2 4 8 16" run rb4 ST_ROLES_NMS=14
+export ST_BENCH_NO_KERNEL_TIMING=1 ST_ROLES_NMS=14; bash scripts/trace_small.sh 8 20 > /dev/null; grep "roles" gpurun_out/ts_8/timeline.txt
+ST_ROLES_NMS=14 timeout 600 python -m pytest tests/test_flow_gpu.py -x -q -m gpu -k "schedules or iteration_parity" 2>&1 | tail -3
