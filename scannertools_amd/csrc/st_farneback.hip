@@ -210,6 +210,70 @@ __global__ __launch_bounds__(256) void k_gray4(GrayArgs a) {
   }
 }
 
+// The three pointer / index tables of a pass (frames, pair indices, output frames).  Large batches upload them with three
+// copies; a call of a few pairs is a chain of short dependent launches in which three pageable host-to-device copies cost
+// 5 us each on the stream, so there the values travel in the ARGUMENTS of the first kernel of the pass (k_gray_tab: the luma
+// conversion reads its frame pointers straight from its arguments and its first workgroup writes the tables the later
+// kernels read) -- no copy and no extra launch.
+constexpr int kTabMax = 40;
+struct TablesArg {
+  const uint8_t** d_frames;
+  float** d_outs;
+  int* d_pairs;
+  int nf, npairs;
+  const uint8_t* frames[kTabMax];
+  float* outs[kTabMax];
+  int pairs[2 * kTabMax];
+};
+
+__device__ __forceinline__ void gray4_body(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n4, const GrayArgs& a) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    typedef unsigned u3nt __attribute__((ext_vector_type(3), aligned(4)));
+    const u3nt wv = __builtin_nontemporal_load(reinterpret_cast<const u3nt*>(src + 3 * (size_t)i));
+    const unsigned w0 = wv.x, w1 = wv.y, w2 = wv.z;
+    const int g0 = (int)((w0 & 0xff) * a.cb + ((w0 >> 8) & 0xff) * a.cg + ((w0 >> 16) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g1 = (int)((w0 >> 24) * a.cb + (w1 & 0xff) * a.cg + ((w1 >> 8) & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g2 = (int)(((w1 >> 16) & 0xff) * a.cb + (w1 >> 24) * a.cg + (w2 & 0xff) * a.cr + a.rnd) >> a.shift;
+    const int g3 = (int)(((w2 >> 8) & 0xff) * a.cb + ((w2 >> 16) & 0xff) * a.cg + (w2 >> 24) * a.cr + a.rnd) >> a.shift;
+    dst[i] = (unsigned)g0 | ((unsigned)g1 << 8) | ((unsigned)g2 << 16) | ((unsigned)g3 << 24);
+  }
+}
+
+// VEC: four pixels per thread (k_gray4's arithmetic and requirements) or one (k_gray's)
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_gray_tab(GrayArgs a, TablesArg t) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    const int i = threadIdx.x;
+    if (i < t.nf) t.d_frames[i] = t.frames[i];
+    if (i < t.npairs) {
+      t.d_outs[i] = t.outs[i];
+      t.d_pairs[2 * i] = t.pairs[2 * i];
+      t.d_pairs[2 * i + 1] = t.pairs[2 * i + 1];
+    }
+  }
+  const uint8_t* __restrict__ frame = st_gl(t.frames[blockIdx.y]);
+  uint8_t* __restrict__ out = a.gray + (size_t)blockIdx.y * a.npix;
+  if (VEC) {
+    gray4_body(reinterpret_cast<const unsigned*>(frame), reinterpret_cast<unsigned*>(out), a.npix >> 2, a);
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.npix; i += gridDim.x * blockDim.x) {
+      int c0 = frame[3 * (size_t)i], c1 = frame[3 * (size_t)i + 1], c2 = frame[3 * (size_t)i + 2];
+      out[i] = (uint8_t)((c0 * a.cb + c1 * a.cg + c2 * a.cr + a.rnd) >> a.shift);
+    }
+  }
+}
+
+// (a pass that skips the luma kernel -- ST_PYR_FOLD_GRAY -- writes its tables with this one)
+__global__ __launch_bounds__(64) void k_set_tables(TablesArg a) {
+  const int t = threadIdx.x;
+  if (t < a.nf) a.d_frames[t] = a.frames[t];
+  if (t < a.npairs) {
+    a.d_outs[t] = a.outs[t];
+    a.d_pairs[2 * t] = a.pairs[2 * t];
+    a.d_pairs[2 * t + 1] = a.pairs[2 * t + 1];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pyramid image of level k: float(gray) -> GaussianBlur(ks, sigma) at FULL resolution ->
 // resize to (dh, dw).  Only the blurred samples the resize reads are computed: per 32x8
@@ -2642,7 +2706,7 @@ int polyexp_rows(st_ctx* ctx, int h, int strips, int n, int poly_n) {
 }
 
 int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int h, int w, int bits, uint8_t* gray,
-                bool frames_aligned4) {
+                bool frames_aligned4, const TablesArg* tables = nullptr) {
   GrayArgs a;
   a.frames = frames_table_dev;
   a.gray = gray;
@@ -2655,7 +2719,9 @@ int launch_gray(st_ctx* ctx, const uint8_t* const* frames_table_dev, int n, int 
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
   st_timed t(ctx, ST_K_GRAY);
-  if (vec) hipLaunchKernelGGL(k_gray4, dim3(bx, n), dim3(256), 0, ctx->stream, a);
+  if (tables && vec) hipLaunchKernelGGL(k_gray_tab<true>, dim3(bx, n), dim3(256), 0, ctx->stream, a, *tables);
+  else if (tables) hipLaunchKernelGGL(k_gray_tab<false>, dim3(bx, n), dim3(256), 0, ctx->stream, a, *tables);
+  else if (vec) hipLaunchKernelGGL(k_gray4, dim3(bx, n), dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_gray, dim3(bx, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
@@ -2828,29 +2894,6 @@ int launch_polyexp_ml(st_ctx* ctx, float* const* imgs, const LevelGeom* geom, fl
   return ST_OK;
 }
 
-// The three pointer / index tables of a pass, written by ONE small launch whose arguments carry the values (a call
-// of a few pairs is a chain of short dependent launches: three pageable host-to-device copies ahead of it cost 5 us
-// each on the stream).  Larger tables take the copies.
-constexpr int kTabMax = 40;
-struct TablesArg {
-  const uint8_t** d_frames;
-  float** d_outs;
-  int* d_pairs;
-  int nf, npairs;
-  const uint8_t* frames[kTabMax];
-  float* outs[kTabMax];
-  int pairs[2 * kTabMax];
-};
-__global__ __launch_bounds__(64) void k_set_tables(TablesArg a) {
-  const int t = threadIdx.x;
-  if (t < a.nf) a.d_frames[t] = a.frames[t];
-  if (t < a.npairs) {
-    a.d_outs[t] = a.outs[t];
-    a.d_pairs[2 * t] = a.pairs[2 * t];
-    a.d_pairs[2 * t + 1] = a.pairs[2 * t + 1];
-  }
-}
-
 int launch_update_matrices(st_ctx* ctx, UMArgs a, int n_pairs) {
   const size_t np = (size_t)a.h * a.w;
   int bx = (int)((np + 255) / 256);
@@ -2937,7 +2980,11 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   // roles): 1 pair per call 2 790 -> 3 100, 2: 3 690 -> 4 240, 4: 4 990 -> 5 200, 8: 6 190 -> 6 640, 16: 7 750 -> 7 690,
   // 32: 8 570 -> 8 360, 64: 9 150 -> 8 610.  ST_ITER_ROLES=1 always, 0 never (read at st_ctx_create).
   const int roles_env = ctx->roles_mode, roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
-  if (roles_env == 1 || (roles_env != 0 && rounds3 == 1 && wgs3 * 100 < resident * 95)) {
+  // (the first iteration of a level -- coarse-flow source, expansions not yet in any cache -- is where the role kernel's single
+  // maker wave per SIMD is weakest: 8 pairs, level 0: 264 us against k_flow_iter3's 226, while its field-source launches
+  // win 183 : 195; it takes those launches only when k_flow_iter3 would leave more than a third of its slots empty)
+  const long long roles_limit = a.coarse ? resident * 62 / 100 : resident * 95 / 100;
+  if (roles_env == 1 || (roles_env != 0 && rounds3 == 1 && wgs3 < roles_limit)) {
     int best_ncw = 0, best_out = 0, best_rows = 0;
     double bestr = 1e300;
     for (int ncw = 5; ncw >= 4; --ncw) {
@@ -3071,15 +3118,14 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   float** d_outs = (float**)st_ws_alloc(ctx, sizeof(void*) * npairs);
   if (!gray || !img || !M[0] || !M[1] || !cflow[0] || !cflow[1] || !d_frames || !d_pairs || !d_outs || !R[levels])
     return st_set_error(ctx, ST_ERR_OOM, "farneback: scratch plan exhausted");
-  if (nf <= kTabMax && npairs <= kTabMax) {
-    TablesArg ta;
+  TablesArg ta;
+  const bool small_tables = nf <= kTabMax && npairs <= kTabMax;
+  if (small_tables) {
     memset(&ta, 0, sizeof(ta));
     ta.d_frames = d_frames; ta.d_outs = d_outs; ta.d_pairs = d_pairs; ta.nf = nf; ta.npairs = npairs;
     for (int i = 0; i < nf; ++i) ta.frames[i] = frames[i];
     for (int i = 0; i < npairs; ++i) { ta.outs[i] = outs[i]; ta.pairs[2 * i] = pairs[2 * i]; ta.pairs[2 * i + 1] = pairs[2 * i + 1]; }
     static_assert(kTabMax <= 64, "one thread per table entry");
-    hipLaunchKernelGGL(k_set_tables, dim3(1), dim3(64), 0, ctx->stream, ta);
-    ST_HIP(ctx, hipGetLastError());
   } else {
     ST_HIP(ctx, hipMemcpyAsync(d_frames, frames, sizeof(void*) * nf, hipMemcpyHostToDevice, ctx->stream));
     ST_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int) * 2 * npairs, hipMemcpyHostToDevice, ctx->stream));
@@ -3094,7 +3140,12 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   // bytes per lane at a 12-byte lane stride, three loads per row instead of one, on a kernel that is
   // already VALU-bound), so the separate k_gray4 pass stays the default.
   const bool pyr_rgb = pyr1 && aligned4 && ctx->fold_gray;
-  if (!pyr_rgb) ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4));
+  if (!pyr_rgb) {
+    ST_TRY(launch_gray(ctx, d_frames, nf, h, w, p.gray_bits, gray, aligned4, small_tables ? &ta : nullptr));
+  } else if (small_tables) {
+    hipLaunchKernelGGL(k_set_tables, dim3(1), dim3(64), 0, ctx->stream, ta);
+    ST_HIP(ctx, hipGetLastError());
+  }
   if (pyr1) ST_TRY(launch_pyr_fused(ctx, pyr_rgb ? nullptr : gray, d_frames, nf, h, w, p, imgs));
   // Small batches: the expansions of all levels in ONE launch (level 0 first, the coarse levels fill its tail).  Measured
   // against the former arrangement -- level 0 on a second, low-priority stream beside the coarse levels' iterations --

@@ -626,14 +626,16 @@ class _Ops:
         from . import _proto
         return _CppOpNode(self.sc, "CPM2Input", frame, device, batch, None, _proto.encode([(2, "float", float(scale))]))
 
-    def CPM2(self, cpm2_input, weights=None, seed=0, batch=8, max_peaks=64, nms_threshold=0.05, device=None):
+    def CPM2(self, cpm2_input, weights=None, seed=0, batch=8, max_peaks=64, nms_threshold=0.05, device=None, prototxt=None):
         """sc.ops.CPM2(cpm2_input=...) (cpm2_kernel.cpp:46-52): returns the columns (cpm2_resized_map, cpm2_joints).
         `weights`: path of the model's caffemodel -> the registered C++ kernel class (CPM2KernelHIP, the drop-in; args
         CPM2Args{caffe_args{net_descriptor{model_weights_path}}}); None -> the same layer sequence driven from Python
         (PoseNet) with random weights from `seed`, for exercising the architecture without a model file."""
         if weights is not None:
             from . import _proto
-            args = _proto.message(1, _proto.message(1, _proto.encode([(2, "string", str(weights))])))
+            # CaffeArgs.net_descriptor: model_path = 1 (the deploy prototxt, optional here), model_weights_path = 2
+            nd = ([(1, "string", str(prototxt))] if prototxt else []) + [(2, "string", str(weights))]
+            args = _proto.message(1, _proto.message(1, _proto.encode(nd)))
             node = _CppOpNode(self.sc, "CPM2", cpm2_input, device, batch, None, args)
             return _CppOpColumn(node, 0), _CppOpColumn(node, 1)
         op = _PoseNetOp(self.sc, cpm2_input, weights, seed, batch, max_peaks, nms_threshold)

@@ -80,6 +80,155 @@ def caffe_layer_names():
     return out
 
 
+# ---- prototxt (the network DESCRIPTION the reference hands Caffe next to the weights: cpm2_kernel.cpp:8-52 through
+# CaffeArgs.net_descriptor.model_path; OpenPose reads <model_directory>/pose/coco/pose_deploy_linevec.prototxt) -------------
+def parse_prototxt(text):
+    """Protobuf text format -> nested {field: [values]} (every field a list: repeated fields are the rule in a NetParameter)."""
+    import re
+    tok = re.findall(r'#[^\n]*|"(?:[^"\\]|\\.)*"|\'(?:[^\'\\]|\\.)*\'|[{}:]|[^\s{}:#"\']+', text)
+    tok = [t for t in tok if not t.startswith("#")]
+    pos = 0
+
+    def message(closing):
+        nonlocal pos
+        out = {}
+        while pos < len(tok):
+            t = tok[pos]
+            if t == "}":
+                if not closing:
+                    raise ValueError("prototxt: unbalanced '}'")
+                pos += 1
+                return out
+            name = t
+            pos += 1
+            if pos < len(tok) and tok[pos] == ":":
+                pos += 1
+            if pos >= len(tok):
+                raise ValueError("prototxt: field %r has no value" % name)
+            if tok[pos] == "{":
+                pos += 1
+                val = message(True)
+            else:
+                val = tok[pos]
+                pos += 1
+                if val[0] in "\"'":
+                    val = val[1:-1]
+            out.setdefault(name, []).append(val)
+        if closing:
+            raise ValueError("prototxt: missing '}'")
+        return out
+
+    return message(False)
+
+
+def layers_from_prototxt(path):
+    """The convolutions a deploy prototxt describes, in file order, with the input channel count of each inferred by
+    walking the blobs (input_dim / input_shape, Convolution, Pooling, ReLU, Concat; the fork's trailing `resize` / `nms`
+    layers and anything after them are ignored): [(name, cin, cout, kernel, relu, bottom blob, top blob)], plus the names
+    of the pooling layers' bottoms (where the trunk pools)."""
+    net = parse_prototxt(open(path).read())
+    chans = {}
+    if "input" in net:
+        dims = [int(d) for d in net.get("input_dim", [])]
+        if not dims and "input_shape" in net:
+            dims = [int(d) for d in net["input_shape"][0].get("dim", [])]
+        if len(dims) >= 2:
+            chans[net["input"][0]] = dims[1]
+    convs, pools = [], []
+    for layer in net.get("layer", []) + net.get("layers", []):
+        typ = str(layer.get("type", [""])[0])
+        name = str(layer.get("name", [""])[0])
+        bottoms, tops = layer.get("bottom", []), layer.get("top", [])
+        if typ in ("Input",):
+            shape = layer.get("input_param", [{}])[0].get("shape", [{}])[0].get("dim", [])
+            if tops and len(shape) >= 2:
+                chans[tops[0]] = int(shape[1])
+        elif typ in ("Convolution", "CONVOLUTION"):
+            cp = layer.get("convolution_param", [{}])[0]
+            cout = int(cp["num_output"][0])
+            k = int(cp.get("kernel_size", cp.get("kernel_h", [1]))[0])
+            pad = int(cp.get("pad", [0])[0])
+            if 2 * pad + 1 != k or int(cp.get("stride", [1])[0]) != 1:
+                raise ValueError("prototxt layer %s: only stride-1 'same' convolutions are implemented (kernel %d, pad %d)" % (name, k, pad))
+            if bottoms[0] not in chans:
+                raise ValueError("prototxt layer %s reads blob %r, which nothing produced" % (name, bottoms[0]))
+            convs.append([name, chans[bottoms[0]], cout, k, 0, bottoms[0], tops[0]])
+            chans[tops[0]] = cout
+        elif typ in ("ReLU", "RELU"):
+            for c in convs[::-1]:
+                if c[6] == bottoms[0]:
+                    c[4] = 1
+                    break
+            chans[tops[0]] = chans.get(bottoms[0], 0)
+        elif typ in ("Pooling", "POOLING"):
+            pools.append(bottoms[0])
+            chans[tops[0]] = chans.get(bottoms[0], 0)
+        elif typ in ("Concat", "CONCAT"):
+            chans[tops[0]] = sum(chans.get(b, 0) for b in bottoms)
+    return [tuple(c) for c in convs], pools
+
+
+def names_from_prototxt(path):
+    """Checks that the prototxt describes the network the kernels implement -- the same 92 convolutions in the same order
+    with the same channel counts, kernel sizes and activations, pooling after conv1_2 / conv2_2 / conv3_4, stage inputs
+    concat(L1, L2, features) -- and returns its layer names in all_layers() order (a model with other layer NAMES and
+    the same structure is usable).  Raises ValueError naming the first difference."""
+    convs, pools = layers_from_prototxt(path)
+    arch = all_layers()
+    if len(convs) != len(arch):
+        raise ValueError("prototxt %s describes %d convolutions, the kernels implement %d" % (path, len(convs), len(arch)))
+    for (pname, ci, co, k, relu, _, _), (aname, aci, aco, ak, arelu) in zip(convs, arch):
+        if (ci, co, k, relu) != (aci, aco, ak, arelu):
+            raise ValueError("prototxt layer %s is a %dx%d convolution %d -> %d (relu %d); the kernels implement %s as %dx%d %d -> %d (relu %d)"
+                             % (pname, k, k, ci, co, relu, aname, ak, ak, aci, aco, arelu))
+    if len(pools) != 3:
+        raise ValueError("prototxt %s has %d pooling layers, the kernels implement 3" % (path, len(pools)))
+    return [c[0] for c in convs]
+
+
+def write_prototxt(path, names=None):
+    """The deploy description of the built-in architecture in the published model's naming (pose_deploy_linevec.prototxt, [EXT])
+    -- input, trunk with ReLU and pooling layers, six two-branch stages with their concatenations; used by tests and the
+    benchmark next to write_caffemodel."""
+    names = names or caffe_layer_names()
+    it = iter(names)
+    out = ['name: "pose"', 'input: "image"', "input_dim: 1", "input_dim: 3", "input_dim: 368", "input_dim: 656"]
+
+    def conv(name, bottom, top, co, k, relu):
+        out.append('layer { name: "%s" type: "Convolution" bottom: "%s" top: "%s" convolution_param { num_output: %d pad: %d kernel_size: %d } }'
+                   % (name, bottom, top, co, k // 2, k))
+        if relu:
+            out.append('layer { name: "relu_%s" type: "ReLU" bottom: "%s" top: "%s" }' % (name, top, top))
+
+    cur, npool = "image", 0
+    for l in TRUNK:
+        if l == "pool":
+            npool += 1
+            out.append('layer { name: "pool%d_stage1" type: "Pooling" bottom: "%s" top: "pool%d" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }'
+                       % (npool, cur, npool))
+            cur = "pool%d" % npool
+        else:
+            name = next(it)
+            conv(name, cur, name, l[2], l[3], l[4])
+            cur = name
+    feat = cur
+    for st in range(1, 7):
+        src = feat if st == 1 else "concat_stage%d" % st
+        ends = []
+        for br, n in (("L1", N_PAF), ("L2", N_HEAT)):
+            cur = src
+            for (ci, co, k, r) in branch_layers(st, n):
+                name = next(it)
+                conv(name, cur, name, co, k, r)
+                cur = name
+            ends.append(cur)
+        if st < 6:
+            out.append('layer { name: "concat_stage%d" type: "Concat" bottom: "%s" bottom: "%s" bottom: "%s" top: "concat_stage%d" concat_param { axis: 1 } }'
+                       % (st + 1, ends[0], ends[1], feat, st + 1))
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+
+
 def read_caffemodel(path):
     """Weights of a Caffe model file: {layer name: [blob, ...]} with every blob a float32 array of its stored
     shape.  Reads the NetParameter wire format directly (caffe.proto, [EXT]: NetParameter.layer = 100 and the V1
@@ -136,10 +285,13 @@ def read_caffemodel(path):
     return out
 
 
-def write_caffemodel(path, weights):
+def write_caffemodel(path, weights, names=None, order=None, extra_layers=()):
     """Writes {architecture layer name: (weight (cout, cin, k, k), bias)} (PoseNet.weights) as a caffemodel file with the
     published layer names: NetParameter{name, layer{name, type, blobs{shape, data}}}.  Used by tests and the benchmark
-    to hand the kernel classes a model file when only random weights exist."""
+    to hand the kernel classes a model file when only random weights exist.  names: other layer names (all_layers() order);
+    order: a permutation of range(92), the order the layers are written in (readers find layers by NAME, a trained file
+    also holds its layers in whatever order the training graph had); extra_layers: names of blob-less layers (ReLU,
+    Pooling, Concat ...) interleaved as a real file has them."""
     from . import _proto
 
     def blob(arr):
@@ -148,12 +300,17 @@ def write_caffemodel(path, weights):
 
     with open(path, "wb") as fh:
         fh.write(_proto.message(1, b"pose"))
-        for (name, *_), cname in zip(all_layers(), caffe_layer_names()):
+        entries = list(zip(all_layers(), names or caffe_layer_names()))
+        extra = list(extra_layers)
+        for i in (order if order is not None else range(len(entries))):
+            (name, *_), cname = entries[i]
             wt, b = weights[name]
             wt = wt.numpy() if hasattr(wt, "numpy") else wt
             b = b.numpy() if hasattr(b, "numpy") else b
             fh.write(_proto.message(100, _proto.message(1, cname.encode()) + _proto.message(2, b"Convolution") +
                                     _proto.message(7, blob(wt)) + _proto.message(7, blob(b))))
+            if extra:
+                fh.write(_proto.message(100, _proto.message(1, extra.pop(0).encode()) + _proto.message(2, b"ReLU")))
 
 
 def check_caffemodel(path):
@@ -170,6 +327,20 @@ def check_caffemodel(path):
     return n
 
 
+def check_prototxt(prototxt, caffemodel=None):
+    """92 when the op library's own reader (scannertools_caffe_check_prototxt; no GPU needed) accepts the deploy description --
+    and, with `caffemodel`, finds the weights of every layer the description names.  Raises ValueError with its message."""
+    from . import engine
+    L = engine._caffe()
+    L.scannertools_caffe_check_prototxt.restype = ctypes.c_int
+    L.scannertools_caffe_check_prototxt.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    err = ctypes.create_string_buffer(512)
+    n = L.scannertools_caffe_check_prototxt(str(prototxt).encode(), str(caffemodel).encode() if caffemodel else None, err, 512)
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return n
+
+
 def _pad16(c):
     return (c + 15) // 16 * 16
 
@@ -181,9 +352,11 @@ def _pad64(c):
 class PoseNet:
     """Random-weight instance of the network on one GPU."""
 
-    def __init__(self, ctx, seed=0, caffemodel=None, math="f32"):
+    def __init__(self, ctx, seed=0, caffemodel=None, math="f32", prototxt=None):
         """caffemodel: path of the model's weights (pose_iter_440000.caffemodel of the COCO body model); None =
         random weights from `seed` (He initialisation).
+        prototxt: the model's deploy description: checked against the architecture the kernels implement
+        (names_from_prototxt) and the source of the layer names the weights are looked up by; None = the published names.
         math: "f32" (default; the float32 matrix instruction, what the reference's Caffe pass computes in) or "bf16x3"
         (opt-in: every operand split into three bf16 terms on the bf16 matrix pipe -- float32-grade accuracy at a
         multiple of the float32 matrix rate, not bit-identical to "f32")."""
@@ -197,7 +370,7 @@ class PoseNet:
         blobs = read_caffemodel(caffemodel) if caffemodel else None
         self.weights = {}   # name -> (torch weight (cout, cin, k, k), bias (cout,)) float32 on the CPU
         self.packed = {}    # name -> (w [cout_pad][k][k][cin_pad], bias [cout_pad]) on the device
-        for (name, ci, co, k, _), cname in zip(all_layers(), caffe_layer_names()):
+        for (name, ci, co, k, _), cname in zip(all_layers(), names_from_prototxt(prototxt) if prototxt else caffe_layer_names()):
             if blobs is not None:
                 if cname not in blobs or len(blobs[cname]) < 2:
                     raise ValueError("caffemodel %s has no weights for layer %s" % (caffemodel, cname))

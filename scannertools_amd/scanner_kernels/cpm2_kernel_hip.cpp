@@ -28,16 +28,18 @@ namespace {
 constexpr int kMaxPeaks = 64;           // cpm2_output_kernel_cpu.cpp:760-761 (max_peaks_)
 constexpr float kNmsThreshold = 0.05f;  // the model's nms_param ([EXT] pose_deploy_linevec.prototxt)
 
-// CPM2Args.caffe_args.net_descriptor.model_weights_path
-bool parse_weights_path(const std::vector<u8>& args, std::string* path) {
+// CPM2Args.caffe_args.net_descriptor.model_weights_path (and .model_path, the deploy prototxt, when given)
+bool parse_weights_path(const std::vector<u8>& args, std::string* path, std::string* prototxt) {
   std::vector<proto_lite::Field> top, caffe, net;
   if (!proto_lite::parse(args.data(), args.size(), &top)) return false;
   for (auto& f : top)
     if (f.number == 1 && f.wire == 2 && !proto_lite::parse((const uint8_t*)f.bytes.data(), f.bytes.size(), &caffe)) return false;
   for (auto& f : caffe)
     if (f.number == 1 && f.wire == 2 && !proto_lite::parse((const uint8_t*)f.bytes.data(), f.bytes.size(), &net)) return false;
-  for (auto& f : net)
+  for (auto& f : net) {
     if (f.number == 2 && f.wire == 2) *path = f.bytes;
+    if (f.number == 1 && f.wire == 2) *prototxt = f.bytes;
+  }
   return true;
 }
 }  // namespace
@@ -48,8 +50,8 @@ class CPM2KernelHIPImpl : public BatchedKernel, public VideoKernel {
   CPM2KernelHIPImpl(const KernelConfig& config)
     : BatchedKernel(config), device_(config.devices[0]), gpu_(STAGED ? staging_device_id() : config.devices[0].id),
       stage_(gpu_) {
-    std::string path;
-    if (!parse_weights_path(config.args, &path)) {
+    std::string path, prototxt;
+    if (!parse_weights_path(config.args, &path, &prototxt)) {
       RESULT_ERROR(&valid_, "Could not parse CPM2Args");
       return;
     }
@@ -71,7 +73,7 @@ class CPM2KernelHIPImpl : public BatchedKernel, public VideoKernel {
       return;
     }
     std::string err;
-    if (!net_.load(path, &err)) RESULT_ERROR(&valid_, "CPM2: %s", err.c_str());
+    if (!net_.load(path, &err, prototxt)) RESULT_ERROR(&valid_, "CPM2: %s", err.c_str());
     for (int c = 0; c < 57; ++c) chan_[c] = c < pose::kHeat ? pose::kOffHeat + c : pose::kOffPaf + (c - pose::kHeat);
   }
   ~CPM2KernelHIPImpl() {
@@ -159,6 +161,44 @@ extern "C" __attribute__((visibility("default"))) int scannertools_caffe_check_m
   if (!caffemodel) msg = "null path";
   if (err && err_len) { strncpy(err, msg.c_str(), err_len - 1); err[err_len - 1] = 0; }
   return ok ? matched : -1;
+}
+
+// Deploy-description check without a GPU: 92 when the prototxt describes the network the kernels implement and, if
+// `caffemodel` is given, the weights of every one of ITS layer names are in that file with the architecture's sizes;
+// -1 with the reason in `err`.
+extern "C" __attribute__((visibility("default"))) int scannertools_caffe_check_prototxt(const char* prototxt, const char* caffemodel, char* err,
+                                                                                        size_t err_len) {
+  std::string msg;
+  int matched = -1;
+  try {
+    std::vector<std::string> names;
+    if (!prototxt) {
+      msg = "null path";
+    } else if (scanner::pose::prototxt_layer_names(prototxt, &names, &msg)) {
+      matched = (int)names.size();
+      if (caffemodel) {
+        std::map<std::string, scanner::pose::Blobs> blobs;
+        const auto arch = scanner::pose::all_layers();
+        if (!scanner::pose::read_caffemodel(caffemodel, &blobs, &msg)) {
+          matched = -1;
+        } else {
+          for (size_t i = 0; i < arch.size() && matched >= 0; ++i) {
+            auto it = blobs.find(names[i]);
+            if (it == blobs.end() || it->second.w.size() != (size_t)arch[i].cout * arch[i].cin * arch[i].k * arch[i].k ||
+                it->second.b.size() != (size_t)arch[i].cout) {
+              msg = "caffemodel has no weights of the right size for prototxt layer " + names[i];
+              matched = -1;
+            }
+          }
+        }
+      }
+    }
+  } catch (const std::exception& e) {
+    msg = e.what();
+    matched = -1;
+  }
+  if (err && err_len) { strncpy(err, msg.c_str(), err_len - 1); err[err_len - 1] = 0; }
+  return matched;
 }
 
 namespace scanner {

@@ -93,7 +93,10 @@ class OpenPoseKernelHIPImpl : public BatchedKernel, public VideoKernel {
       return;
     }
     std::string err;
-    if (!net_.load(args_.model_directory + "/pose/coco/pose_iter_440000.caffemodel", &err)) RESULT_ERROR(&valid_, "OpenPose: %s", err.c_str());
+    // the deploy description beside the weights (OpenPose's own file layout), when the directory holds it
+    std::string proto = args_.model_directory + "/pose/coco/pose_deploy_linevec.prototxt", probe;
+    if (!pose::read_file(proto, &probe)) proto.clear();
+    if (!net_.load(args_.model_directory + "/pose/coco/pose_iter_440000.caffemodel", &err, proto)) RESULT_ERROR(&valid_, "OpenPose: %s", err.c_str());
     for (int c = 0; c < 57; ++c) chan_[c] = c < pose::kHeat ? pose::kOffHeat + c : pose::kOffPaf + (c - pose::kHeat);
   }
   ~OpenPoseKernelHIPImpl() {

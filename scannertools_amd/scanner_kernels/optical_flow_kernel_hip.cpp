@@ -119,6 +119,7 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
     : StenciledBatchedKernel(config), device_(config.devices[0]), gpu_(staging_device_id()) {
     st_fb_params_default(&params_);
     const char* e = getenv("SCANNERTOOLS_FLOW_SUBBATCH");
+    sub_fixed_ = e != nullptr;
     sub_ = e ? atoi(e) : 8;
     if (sub_ < 1) sub_ = 1;
     for (int l = 0; l < 2 && valid_.success(); ++l) {
@@ -166,9 +167,20 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
     std::vector<Frame*> output_frames = new_frames(device_, out_info, input_count);
     HIP_CHECK(hipSetDevice(gpu_));
 
+    // Sub-batch size: SCANNERTOOLS_FLOW_SUBBATCH when set; otherwise by bytes -- about 64 MB of frames + flow fields per
+    // sub-batch, at least 8 rows (1080p: 8 rows = 180 MB), so that small frames (the legacy pipeline's 426x240: 1.1 MB per
+    // row) are not cut into pieces whose fixed costs (two synchronisations, a dozen launches, two copies) outweigh them:
+    // 64 rows of 426x240 went from 7.0 k to the rate printed by bench.py's legacy_flow_hist record.  Even split.
+    i32 sub = sub_;
+    if (!sub_fixed_) {
+      const size_t per_row = frame_bytes + out_bytes;
+      sub = (i32)std::min<size_t>(64, std::max<size_t>(8, ((size_t)64 << 20) / std::max<size_t>(per_row, 1)));
+      const i32 pieces = (input_count + sub - 1) / sub;
+      sub = (input_count + pieces - 1) / pieces;
+    }
     int lane_idx = 0;
-    for (i32 r0 = 0; r0 < input_count; r0 += sub_, lane_idx ^= 1) {
-      const i32 nb = std::min(sub_, input_count - r0);
+    for (i32 r0 = 0; r0 < input_count; r0 += sub, lane_idx ^= 1) {
+      const i32 nb = std::min(sub, input_count - r0);
       Lane& L = lanes_[lane_idx];
       // the lane's previous sub-batch (compute + copy-back) must be done before its buffers are reused
       LOG_IF(FATAL, st_ctx_sync(L.ctx) != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(L.ctx);
@@ -225,6 +237,7 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
   DeviceHandle device_;
   int gpu_;
   int sub_ = 8;
+  bool sub_fixed_ = false;
   Lane lanes_[2];
   Result valid_;
   st_fb_params params_;

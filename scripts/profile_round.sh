@@ -30,4 +30,16 @@ python3 scripts/pmc_traffic.py $out > $out/summary/pmc_traffic.json
 cp $out/bench.json $out/summary/bench.json
 python3 scripts/pmc_summary.py $out > $out/summary/pmc_by_launch.txt
 rm -rf $out/trace $out/fetch $out/write $out/rdreq $out/wrreq $out/sq $out/tcp $out/ta $out/valu
+# small-batch calls (what a drop-in graph without batch= gets): kernel timeline of one step at 1 and 8 pairs per call,
+# no event brackets
+for b in 1 8; do
+  ST_BENCH_NO_KERNEL_TIMING=1 bash scripts/trace_small.sh $b 30 > /dev/null 2>&1
+  cp gpurun_out/ts_$b/timeline.txt $out/summary/small_${b}_timeline.txt
+  cp gpurun_out/ts_$b/stats.txt $out/summary/small_${b}_kernel_stats.txt
+done
+# the legacy flow-histogram pipeline at 426x240 (old/histograms.py:63-78), 256 pairs per call
+rocprofv3 --kernel-trace --stats -d $out/ltrace -o trace -- python3 scripts/bench_legacy.py --batches 256 --steps 4 > $out/summary/legacy.json 2> $out/legacy.err
+python3 scripts/rocpd_stats.py $out/ltrace/trace_results.db | grep -v "at::native\|rocclr\|distribution\|elementwise\|vectorized" > $out/summary/legacy_kernel_stats.txt
+python3 scripts/rocpd_timeline.py $out/ltrace/trace_results.db k_resize_linear 3 > $out/summary/legacy_timeline.txt
+rm -rf $out/ltrace
 cat $out/bench.json

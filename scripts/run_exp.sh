@@ -1,6 +1,10 @@
 cd "$GRAFT_REPO_ROOT"
-source scripts/exp_small2.sh
-BATCHES="2 4 8 16" run rb2 ST_ROLES_NMS=1
-BATCHES="2 4 8 16" run rb4 ST_ROLES_NMS=14
-export ST_BENCH_NO_KERNEL_TIMING=1 ST_ROLES_NMS=14; bash scripts/trace_small.sh 8 20 > /dev/null; grep "roles" gpurun_out/ts_8/timeline.txt
-ST_ROLES_NMS=14 timeout 600 python -m pytest tests/test_flow_gpu.py -x -q -m gpu -k "schedules or iteration_parity" 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_flow_gpu.py tests/test_fuzz_gpu.py tests/test_engine_gpu.py -x -q -m gpu 2>&1 | tail -3
+python bench.py --no-cpu-baseline --no-4k --no-pose --no-shots --steps 4 > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -2 gpurun_out/bench_now.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/bench_now.json"))
+e=d["extra"]
+for k,v in e["optical_flow_small_batches"].items():
+    if isinstance(v,dict): print(k, {a:round(b,1) for a,b in v.items()})
+PY

@@ -469,3 +469,60 @@ def test_pose_entry_points_reject_bad_arguments_and_accept_empty_batches(hip_ctx
     # the context still works
     got = hip_ctx.cpm2_resize_maps(torch.ones((1, 4, 4, 8), dtype=f32, device="cuda"), 8, 8)
     assert float((got - 1).abs().max()) < 1e-6
+
+
+def test_prototxt_is_read_and_checked(tmp_path):
+    """The deploy description: the Python reader walks the blobs (channel counts through Concat, ReLU attribution, pooling
+    positions) and the op library's reader lists the convolutions; both accept the published architecture, both take the
+    layer NAMES from the file (a renamed model with the same structure is usable, its weights found under the new names in
+    a caffemodel whose layers are stored in another order, between blob-less layers), both name the first difference of a
+    description of another network."""
+    from scannertools_amd import pose_net
+    proto = tmp_path / "pose_deploy_linevec.prototxt"
+    pose_net.write_prototxt(proto)
+    assert pose_net.names_from_prototxt(proto) == pose_net.caffe_layer_names()
+    convs, pools = pose_net.layers_from_prototxt(proto)
+    assert len(convs) == 92 and pools == ["conv1_2", "conv2_2", "conv3_4"]
+    assert [c[1:5] for c in convs] == [l[1:] for l in pose_net.all_layers()]     # cin (185 behind the Concat layers), cout, k, relu
+    assert pose_net.check_prototxt(proto) == 92
+    # renamed layers, written in reverse order with ReLU entries in between: found by the names of the description
+    renamed = ["L%02d_%s" % (i, n) for i, n in enumerate(pose_net.caffe_layer_names())]
+    proto2 = tmp_path / "renamed.prototxt"
+    pose_net.write_prototxt(proto2, names=renamed)
+    assert pose_net.names_from_prototxt(proto2) == renamed
+    layers = [(cn, ci, co, k) for (_, ci, co, k, _), cn in zip(pose_net.all_layers(), renamed)]
+    model = tmp_path / "renamed.caffemodel"
+    _write_model(model, layers[::-1])
+    assert pose_net.check_prototxt(proto2, model) == 92
+    with pytest.raises(ValueError, match="L00_conv1_1|no weights"):
+        pose_net.check_prototxt(proto, model)            # the published names are not in that file
+    # another network: one layer fewer / another kernel size / another width
+    text = proto.read_text()
+    short = tmp_path / "short.prototxt"
+    short.write_text("\n".join(ln for ln in text.splitlines() if '"Mconv7_stage6_L2"' not in ln))
+    for check in (pose_net.names_from_prototxt, pose_net.check_prototxt):
+        with pytest.raises(ValueError, match="91"):
+            check(short)
+    k5 = tmp_path / "k5.prototxt"
+    k5.write_text(text.replace('name: "Mconv2_stage3_L1" type: "Convolution" bottom: "Mconv1_stage3_L1" top: "Mconv2_stage3_L1" convolution_param { num_output: 128 pad: 3 kernel_size: 7 }',
+                               'name: "Mconv2_stage3_L1" type: "Convolution" bottom: "Mconv1_stage3_L1" top: "Mconv2_stage3_L1" convolution_param { num_output: 128 pad: 2 kernel_size: 5 }'))
+    assert k5.read_text() != text
+    for check in (pose_net.names_from_prototxt, pose_net.check_prototxt):
+        with pytest.raises(ValueError, match="Mconv2_stage3_L1"):
+            check(k5)
+    wide = tmp_path / "wide.prototxt"
+    wide.write_text(text.replace('top: "conv4_4_CPM" convolution_param { num_output: 128', 'top: "conv4_4_CPM" convolution_param { num_output: 96'))
+    with pytest.raises(ValueError, match="conv4_4_CPM"):
+        pose_net.check_prototxt(wide)
+    with pytest.raises(ValueError):
+        pose_net.names_from_prototxt(wide)
+    # text-format details: comments, the colon before a message, single quotes, V1 upper-case types
+    fancy = tmp_path / "fancy.prototxt"
+    fancy.write_text("# a comment\n" + text.replace("convolution_param {", "convolution_param: {", 3).replace('"Convolution"', "'Convolution'", 2))
+    assert pose_net.names_from_prototxt(fancy) == pose_net.caffe_layer_names() and pose_net.check_prototxt(fancy) == 92
+    broken = tmp_path / "broken.prototxt"
+    broken.write_text(text[:len(text) // 2])
+    with pytest.raises(ValueError):
+        pose_net.check_prototxt(broken)
+    with pytest.raises(ValueError, match="cannot read"):
+        pose_net.check_prototxt(tmp_path / "absent.prototxt")

@@ -246,6 +246,48 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, model_dir, tmp_path):
         sc.run(sc.io.Output(m_col, [NamedStream(sc, "m")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
 
 
+def test_model_with_other_layer_order_and_names(hip_ctx, model_dir, tmp_path):
+    """A caffemodel whose layers are stored in ANOTHER order than the compiled-in list (reversed, ReLU entries in between)
+    under OTHER names, described by its own prototxt: PoseNet and the CPM2 kernel class take the names from the
+    description, find every layer, and compute the same bits as the network built from the weights directly."""
+    from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, PerfParams
+    _, _, a = model_dir
+    renamed = ["net_%s_%02d" % (n, i) for i, n in enumerate(pose_net.caffe_layer_names())]
+    model, proto = tmp_path / "shuffled.caffemodel", tmp_path / "shuffled.prototxt"
+    order = list(range(92))[::-1]
+    pose_net.write_caffemodel(str(model), a.weights, names=renamed, order=order, extra_layers=["relu_%d" % i for i in range(40)])
+    pose_net.write_prototxt(str(proto), names=renamed)
+    assert pose_net.check_prototxt(proto, model) == 92
+    with pytest.raises(ValueError):
+        pose_net.PoseNet(hip_ctx, caffemodel=str(model))              # the published names are not in this file
+    b_net = pose_net.PoseNet(hip_ctx, caffemodel=str(model), prototxt=str(proto))
+    x = (torch.rand((2, 3, 16, 24), generator=torch.Generator().manual_seed(4)) - 0.5).cuda()
+    assert torch.equal(a.forward(x), b_net.forward(x))
+    maps, joints = a.detect(x)
+
+    class _Rows:
+        def __init__(self, rows):
+            self.rows_ = rows
+
+        def length(self):
+            return len(self.rows_)
+
+        def rows(self, idx):
+            return [self.rows_[i] for i in idx]
+
+    sc = Client()
+    m_col, j_col = sc.ops.CPM2(cpm2_input=_Rows([f for f in x]), weights=str(model), prototxt=str(proto), device=DeviceType.GPU, batch=2)
+    om, oj = NamedStream(sc, "maps_s"), NamedStream(sc, "joints_s")
+    sc.run([sc.io.Output(m_col, [om]), sc.io.Output(j_col, [oj])], PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+    for i, (m, j) in enumerate(zip(om.load(), oj.load())):
+        np.testing.assert_array_equal(m, maps[i].cpu().numpy())
+        np.testing.assert_array_equal(j, joints[i].cpu().numpy())
+    with pytest.raises(RuntimeError, match="CPM2"):                    # without the description the kernel class looks for the published names
+        sc = Client()
+        m_col, _ = sc.ops.CPM2(cpm2_input=_Rows([x[0]]), weights=str(model), device=DeviceType.GPU)
+        sc.run(sc.io.Output(m_col, [NamedStream(sc, "m_no_proto")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+
+
 @pytest.mark.parametrize("S", [1, 2, 3])
 def test_resize_merge_maps_bit_exact(hip_ctx, S):
     """The scales' maps merged on the GPU == the oracle's sum of per-scale interpolants / S; one scale == the single-scale
