@@ -4,6 +4,7 @@
 // (optical_flow_kernel_gpu.cpp:12,45-46), Kernel (blur_kernel_cpu.cpp:25,51-52);
 // REGISTER_KERNEL(...).device().batch().num_devices() (histogram_kernel_cpu.cpp:54-57).
 #pragma once
+#include "scanner/util/profiler.h"
 #include <cstring>
 #include <functional>
 #include <map>
@@ -46,7 +47,7 @@ struct KernelConfig {
   i32 node_id = 0;
 };
 
-class Profiler;  // opaque (scanner/util/profiler.h); unused on this path
+// scanner/util/profiler.h: Profiler::add_interval + now(), what the reference's kernels record their work under
 
 class BaseKernel {
  public:

@@ -205,6 +205,7 @@ struct EngineKernel {
   KernelRegistration reg;
   const OpRegistration* op = nullptr;
   DeviceHandle device;
+  Profiler profiler;  // what a Scanner worker hands every kernel instance (set_profiler)
   std::unique_ptr<BaseKernel> kernel;
 };
 
@@ -293,6 +294,7 @@ SHIM_EXPORT void* stshim_kernel_create(const char* op, int device_type, int devi
   if (args && n_args) arg_bytes.assign(args, args + n_args);
   if (!stream_args) cfg.args = arg_bytes;
   ek->kernel.reset(found->constructor(cfg));
+  ek->kernel->set_profiler(&ek->profiler);
   Result res;
   ek->kernel->validate(&res);
   if (!res.success()) {
@@ -512,6 +514,18 @@ SHIM_EXPORT void stshim_outputs_free(void* o) {
 }
 
 SHIM_EXPORT double stshim_last_execute_seconds() { return g_last_execute_seconds; }
+
+// Intervals the kernel instance has recorded under `key` through its Profiler: count, total seconds in *seconds.
+SHIM_EXPORT int stshim_profiler_intervals(void* kernel, const char* key, double* seconds) {
+  auto* ek = static_cast<EngineKernel*>(kernel);
+  int n = 0;
+  double total = 0;
+  if (ek && key)
+    for (auto& r : ek->profiler.get_records())
+      if (r.key == key) { ++n; total += (double)(r.end - r.start) * 1e-9; }
+  if (seconds) *seconds = total;
+  return n;
+}
 SHIM_EXPORT double stshim_last_steady_seconds(int* rows) {
   if (rows) *rows = g_last_steady_rows;
   return g_last_steady_seconds;

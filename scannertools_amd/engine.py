@@ -97,6 +97,8 @@ def _load_op_library(path):
         L.stshim_last_execute_seconds.restype = ctypes.c_double
         L.stshim_last_steady_seconds.restype = ctypes.c_double
         L.stshim_last_steady_seconds.argtypes = [ctypes.POINTER(ci)]
+        L.stshim_profiler_intervals.restype = ci
+        L.stshim_profiler_intervals.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         L.stshim_live_buffers.argtypes = [ci]
         _LIBS[path] = L
     return _LIBS[path]
@@ -259,6 +261,14 @@ class _CppOpNode(_Node):
                         out[r] = self._fetch(L, res, r - lo) if ncols == 1 else tuple(self._fetch(L, res, r - lo, c) for c in range(ncols))
                 finally:
                     L.stshim_outputs_free(res)
+            # what the kernel instance recorded through its Scanner Profiler (caffe_kernel.cpp:387, cpm2_input_kernel_gpu.cpp:154)
+            for key in ("cpm2_input", "caffe:net"):
+                secs = ctypes.c_double()
+                cnt = L.stshim_profiler_intervals(k, key.encode(), ctypes.byref(secs))
+                if cnt:
+                    rec = self.client.profile.setdefault(key, [0, 0.0])
+                    rec[0] += cnt
+                    rec[1] += secs.value
         finally:
             L.stshim_kernel_destroy(k)
         return [out[r] for r in idx]
@@ -691,6 +701,7 @@ class Client:
         self.execute_seconds = 0.0  # wall time spent inside kernel execute() calls (excludes Python copies)
         # the same without each run's first execute() call (scratch allocation of a fresh kernel instance) + rows covered
         self.steady_seconds, self.steady_rows = 0.0, 0
+        self.profile = {}   # Scanner Profiler intervals the kernel instances recorded: key -> [count, seconds]
         self.io, self.ops, self.streams = _IO(self), _Ops(self), _Streams()
 
     def ingest_frames(self, name, frames):

@@ -70,6 +70,7 @@ class CPM2InputKernelHIPImpl : public BatchedKernel, public VideoKernel {
     auto& frame_col = input_columns[0];
     i32 input_count = (i32)num_rows(frame_col);
     if (input_count == 0) return;
+    const auto eval_start = now();  // cpm2_input_kernel_gpu.cpp:92
     check_frame(device_, frame_col[0]);
     LOG_IF(FATAL, frame_info_.channels() != 3 || frame_info_.type != FrameType::U8)
         << "CPM2Input expects U8 frames with 3 channels";
@@ -101,6 +102,7 @@ class CPM2InputKernelHIPImpl : public BatchedKernel, public VideoKernel {
     if (STAGED)
       for (i32 i = 0; i < input_count; ++i) stage_.download(output_frames[i]->data, (const u8*)dst_[i], out_bytes);
     for (i32 i = 0; i < input_count; ++i) insert_frame(output_columns[0], output_frames[i]);
+    if (profiler_) profiler_->add_interval("cpm2_input", eval_start, now());  // cpm2_input_kernel_gpu.cpp:153-155
   }
 
  private:

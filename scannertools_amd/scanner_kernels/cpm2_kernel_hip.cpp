@@ -118,6 +118,7 @@ class CPM2KernelHIPImpl : public BatchedKernel, public VideoKernel {
       }
     }
     std::string err;
+    const auto net_start = now();  // caffe_kernel.cpp:381
     const float* final_maps = net_.forward(ctx_, src_.data(), n, H, W, &err);
     LOG_IF(FATAL, !final_maps) << "CPM2: " << err;
     int st = st_cpm2_resize_maps(ctx_, final_maps, n, H / 8, W / 8, pose::kCatPad, chan_, 57, H, W, map_ptr_.data());
@@ -127,6 +128,9 @@ class CPM2KernelHIPImpl : public BatchedKernel, public VideoKernel {
     LOG_IF(FATAL, st != ST_OK) << "st_cpm2_nms: " << st_ctx_last_error(ctx_);
     st = st_ctx_sync(ctx_);
     LOG_IF(FATAL, st != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(ctx_);
+    // the network + its resize / nms layers, complete on the device (the reference brackets net->Forward() the same way and
+    // notes that the interval is only meaningful with a synchronisation, caffe_kernel.cpp:384-387)
+    if (profiler_) profiler_->add_interval("caffe:net", net_start, now());
     if (STAGED)
       for (i32 i = 0; i < n; ++i) {
         stage_.download(maps[i]->data, (const u8*)map_ptr_[i], map_bytes);

@@ -159,6 +159,9 @@ def test_whole_pose_pipeline_through_the_engine(hip_ctx):
         np.testing.assert_array_equal(joints[i].cpu().numpy(), ref_joints)
         np.testing.assert_array_equal(got[i], oracle.cpm2_connect_limbs_coco(ref_maps, ref_joints, 135, 240))
     assert float(joints[:, :, 0, 0].max()) > 0   # the random network does produce candidates
+    # the kernel classes record their work under the keys the reference's kernels use with Scanner's Profiler
+    # (cpm2_input_kernel_gpu.cpp:153-155): one interval per execute() call, 3 rows at batch 2 = 2 calls
+    assert sc.profile["cpm2_input"][0] == 2 and 0 < sc.profile["cpm2_input"][1] < 5.0
 
 
 @pytest.fixture(scope="module")
@@ -206,6 +209,8 @@ def test_pose_net_loads_a_caffemodel(hip_ctx, model_dir, tmp_path):
         for i, (m, j) in enumerate(zip(om.load(), oj.load())):
             np.testing.assert_array_equal(m, maps[i].cpu().numpy())
             np.testing.assert_array_equal(j, joints[i].cpu().numpy())
+        # "caffe:net" intervals (caffe_kernel.cpp:381-387): one per execute() of each of the two columns' runs
+        assert sc.profile["caffe:net"][0] >= 2 and sc.profile["caffe:net"][1] > 0
 
     # the opt-in split-bf16 arithmetic: the kernel class (SCANNERTOOLS_POSE_MATH, read when the instance is created)
     # equals PoseNet(math="bf16x3") bit for bit, and the two arithmetics agree to float32 round-off over the 92 layers
