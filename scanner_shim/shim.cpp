@@ -88,12 +88,35 @@ void host_free(u8* p) {
   if (b.pinned) (void)hipHostFree(b.p); else free(b.p);
 }
 
+// Device buffers come from a pool too (Scanner's workers allocate element buffers from pooled blocks, not from the
+// driver): a hipMalloc + hipFree pair per execute() costs tens of microseconds, which is a tenth of a single-pair
+// OpticalFlow call.  Same reuse rule as the host pool; capped.
+struct DevBlock { u8* p; size_t size; int device; };
+std::vector<DevBlock> g_dev_pool;                   // free blocks
+std::map<uintptr_t, DevBlock> g_dev_live;           // blocks handed out
+size_t g_dev_pooled_bytes = 0;
+constexpr size_t kDevPoolCap = (size_t)16 << 30;
+
 u8* raw_alloc(DeviceHandle device, size_t size) {
   void* p = nullptr;
   if (size == 0) size = 1;
   if (device.type == DeviceType::GPU) {
+    {
+      std::lock_guard<std::mutex> lk(g_mem_mutex);
+      for (size_t i = 0; i < g_dev_pool.size(); ++i) {
+        if (g_dev_pool[i].device == device.id && g_dev_pool[i].size >= size && g_dev_pool[i].size <= 2 * size) {
+          DevBlock b = g_dev_pool[i];
+          g_dev_pool.erase(g_dev_pool.begin() + i);
+          g_dev_pooled_bytes -= b.size;
+          g_dev_live[(uintptr_t)b.p] = b;
+          return b.p;
+        }
+      }
+    }
     LOG_IF(FATAL, hipSetDevice(device.id) != hipSuccess) << "hipSetDevice failed";
     LOG_IF(FATAL, hipMalloc(&p, size) != hipSuccess) << "hipMalloc failed";
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    g_dev_live[(uintptr_t)p] = DevBlock{(u8*)p, size, device.id};
   } else {
     p = host_alloc(size);
   }
@@ -102,6 +125,20 @@ u8* raw_alloc(DeviceHandle device, size_t size) {
 
 void raw_free(DeviceHandle device, u8* p) {
   if (device.type == DeviceType::GPU) {
+    DevBlock b{p, 0, device.id};
+    {
+      std::lock_guard<std::mutex> lk(g_mem_mutex);
+      auto it = g_dev_live.find((uintptr_t)p);
+      if (it != g_dev_live.end()) {
+        b = it->second;
+        g_dev_live.erase(it);
+        if (g_dev_pooled_bytes + b.size <= kDevPoolCap) {
+          g_dev_pool.push_back(b);
+          g_dev_pooled_bytes += b.size;
+          return;
+        }
+      }
+    }
     (void)hipSetDevice(device.id);
     (void)hipFree(p);
   } else {

@@ -1,7 +1,11 @@
 cd "$GRAFT_REPO_ROOT"
-t() { s=$(date +%s.%N); "$@" > /dev/null 2>&1; e=$(date +%s.%N); echo "$(echo "$e - $s" | bc) s: $*"; }
-t python bench.py --no-extras --no-cpu-baseline
-t python bench.py --no-extras
-t python bench.py --no-cpu-baseline --no-4k --no-pose --no-shots
-t python bench.py --no-cpu-baseline --no-4k --no-shots
-t python bench.py
+timeout 1500 python -m pytest tests/test_engine_gpu.py tests/test_imgproc_gpu.py tests/test_flowvis_gpu.py tests/test_pose_net_gpu.py -x -q -m gpu 2>&1 | tail -3
+python bench.py --no-cpu-baseline --no-4k --no-pose --no-shots --steps 4 > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -2 gpurun_out/bench_now.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/bench_now.json"))
+e=d["extra"]
+for k,v in e["optical_flow_small_batches"].items():
+    if isinstance(v,dict): print(k, {a:round(b,1) for a,b in v.items()})
+print(json.dumps(e["host_fed"],indent=0)[:900])
+PY
