@@ -40,6 +40,6 @@ done
 # the legacy flow-histogram pipeline at 426x240 (old/histograms.py:63-78), 256 pairs per call
 rocprofv3 --kernel-trace --stats -d $out/ltrace -o trace -- python3 scripts/bench_legacy.py --batches 256 --steps 4 > $out/summary/legacy.json 2> $out/legacy.err
 python3 scripts/rocpd_stats.py $out/ltrace/trace_results.db | grep -v "at::native\|rocclr\|distribution\|elementwise\|vectorized" > $out/summary/legacy_kernel_stats.txt
-python3 scripts/rocpd_timeline.py $out/ltrace/trace_results.db k_resize_linear 3 > $out/summary/legacy_timeline.txt
+python3 scripts/rocpd_timeline.py $out/ltrace/trace_results.db k_resize_linear > $out/summary/legacy_timeline.txt
 rm -rf $out/ltrace
 cat $out/bench.json

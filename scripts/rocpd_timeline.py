@@ -2,7 +2,8 @@
 """Timeline of ONE step out of a rocprofv3 rocpd database (kernel-trace): every kernel between two consecutive launches
 of the step's first kernel, with its start relative to the step, its duration, the gap since the previous kernel's end
 and its grid -- what a per-kernel stats table hides (gaps, overlap between streams, which launch is which level).
-   python scripts/rocpd_timeline.py x_results.db [first_kernel_substring] [step_index]"""
+   python scripts/rocpd_timeline.py x_results.db [first_kernel_substring] [step_index]
+(no step index: the step of median duration)"""
 import re
 import sqlite3
 import sys
@@ -18,7 +19,10 @@ starts = [i for i, r in enumerate(rows) if first in r[idx["name"]]]
 if len(starts) < 3:
     sys.exit("fewer than 3 launches of %r" % first)
 if which is None:
-    which = len(starts) // 2
+    # the step of median duration among the steady ones (a step that met a host hiccup shows gaps that are not the kernels')
+    cand = list(range(len(starts) // 4, len(starts) - 1))
+    dur = sorted((rows[starts[i + 1]][idx["start"]] - rows[starts[i]][idx["start"]], i) for i in cand)
+    which = dur[len(dur) // 2][1]
 a, b = starts[which], starts[which + 1]
 t0 = rows[a][idx["start"]]
 prev_end = None

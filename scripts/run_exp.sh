@@ -1,11 +1,15 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests/test_engine_gpu.py tests/test_imgproc_gpu.py tests/test_flowvis_gpu.py tests/test_pose_net_gpu.py -x -q -m gpu 2>&1 | tail -3
-python bench.py --no-cpu-baseline --no-4k --no-pose --no-shots --steps 4 > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -2 gpurun_out/bench_now.err
-python - <<PY
-import json
-d=json.load(open("gpurun_out/bench_now.json"))
-e=d["extra"]
-for k,v in e["optical_flow_small_batches"].items():
-    if isinstance(v,dict): print(k, {a:round(b,1) for a,b in v.items()})
-print(json.dumps(e["host_fed"],indent=0)[:900])
-PY
+export ST_BENCH_NO_KERNEL_TIMING=1
+run() { lbl=$1; shift
+  for b in $BATCHES; do
+    env "$@" python bench.py --batch $b --steps 30 --warmup 4 --no-cpu-baseline --no-extras $SIZE 2>/dev/null | python -c "
+import json,sys
+d=json.load(sys.stdin); print('%-28s batch %3d: %7.0f frames/s  %.3f ms/step' % ('$lbl', $b, d['value'], d['ms_per_step']), flush=True)"
+  done
+}
+SIZE="--height 2160 --width 3840" BATCHES="1 2 4 8" run 4k_auto A=1
+SIZE="--height 2160 --width 3840" BATCHES="1 2 4 8" run 4k_noroles ST_ITER_ROLES=0
+SIZE="--height 720 --width 1280" BATCHES="1 4 16" run 720p_auto A=1
+SIZE="--height 720 --width 1280" BATCHES="1 4 16" run 720p_noroles ST_ITER_ROLES=0
+SIZE="--height 480 --width 640" BATCHES="1 8 32" run 480p_auto A=1
+SIZE="--height 480 --width 640" BATCHES="1 8 32" run 480p_noroles ST_ITER_ROLES=0
