@@ -4,6 +4,7 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np, torch
+os.environ["ST_RECORD_FLOW_TIERS"] = "1"   # campaign mode: every seed reports its tiers instead of being checked against the pinned list
 import test_fuzz_gpu as F
 from scannertools_amd.hip import HipContext
 ctx = HipContext(0)
