@@ -299,6 +299,8 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     if (chunks < 1) chunks = 1;
   } else if (variant == 32) {
     chunks = chunks_for(ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
+    static const int force_chunks = getenv("ST_HIST_CHUNKS") ? atoi(getenv("ST_HIST_CHUNKS")) : 0;  // experiments
+    if (force_chunks > 0) chunks = force_chunks;
   } else {
     chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
     long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread

@@ -1,3 +1,2 @@
 cd "$GRAFT_REPO_ROOT"
-source scripts/exp_small2.sh
-for r in 8 12 16 24 36 48; do BATCHES="1 2 8" STEPS=60 run pe_minrows_$r ST_PE_MINROWS=$r; done
+for n in 32 64 128; do for c in 0 1 2 4 8 16; do echo "N=$n chunks=$c: $(N=$n ST_HIST_CHUNKS=$c python scripts/bench_hist.py 2>/dev/null | grep 'bins 256' | tr '\n' '|')"; done; done
