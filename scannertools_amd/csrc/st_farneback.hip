@@ -2246,7 +2246,9 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
     const int mset = NMS == 1 ? 0 : tid / G::COLS;  // this wave's maker set
     const int t = tid - mset * G::COLS;
     const int x = (int)bx * a.out_w - B2_HALO + t;
-    const int xc = d_clamp(x, 0, w - 1);
+    // lanes beyond the strip's right halo (a strip may be narrower than the waves that march it) repeat its last column:
+    // the same cache lines, no traffic of their own
+    const int xc = d_clamp(x, 0, min(w - 1, (int)bx * a.out_w + a.out_w + B2_HALO - 1));
     const float* __restrict__ R0;
     const float* __restrict__ R1;
     if (a.pairs) {
@@ -2999,7 +3001,10 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
         const long long rounds = (wgs + ctx->num_cus - 1) / ctx->num_cus;
         // a round costs its rows plus the 16-row prologue and the three-step pipeline tail; the 15-wave instance's
         // step is ~1.3 of the 12-wave one's when both fill the chip (it pays when it saves a round: 1920 columns are
-        // 7 strips instead of 8, 238 instead of 272 workgroups for one 1080p pair)
+        // 7 strips instead of 8, 238 instead of 272 workgroups for one 1080p pair).  A step's time is mostly fixed (a
+        // barrier and a round of gathers), not proportional to the strip's width: narrower strips with taller segments
+        // -- less re-fetch per output row, 15 strips of 128 x 17 segments of 64 rows = 255 workgroups of a 9-wave
+        // instance for one 1080p pair -- measured 40 us per level-0 launch against 35.
         const double cost = (double)rounds * (r + 16 + 3 * FR_G) * (ncw == 5 ? 1.3 : 1.0);
         if (cost < bestr * 0.999) { bestr = cost; best_ncw = ncw; best_out = out_w; best_rows = r; }
       }

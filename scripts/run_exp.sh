@@ -1,2 +1,4 @@
 cd "$GRAFT_REPO_ROOT"
-for n in 32 64 128; do for c in 0 1 2 4 8 16; do echo "N=$n chunks=$c: $(N=$n ST_HIST_CHUNKS=$c python scripts/bench_hist.py 2>/dev/null | grep 'bins 256' | tr '\n' '|')"; done; done
+timeout 1200 python -m pytest tests/test_flow_gpu.py -x -q -m gpu 2>&1 | tail -2
+source scripts/exp_small2.sh
+BATCHES="1 2 4 8 16" run auto A=1
