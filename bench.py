@@ -16,22 +16,33 @@ torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of
 parent touches the GPU; the parent relays rank 0's line and fails if any rank fails); under an
 external launcher (torch.distributed.run) WORLD_SIZE must equal --gpus.
 
+With more than one rank (N > 1) the line carries the headline fields, `roofline`, `flow_whole_path`, `histogram` and the multi-GPU
+evidence fields (`rccl_world_size`, `devices`, `distinct_devices`, `ms_per_step_by_rank`) only: `cpu_baseline`, `parity` and `extra`
+are single-GPU records (rank 0 at N = 1), so that a scaling run times nothing but the sharded step.
+
 The JSON line also carries
   roofline     : for the dominant kernel (k_flow_iter3: UpdateMatrices + 15x15 box blur + 2x2
-                 solve, one launch per Farneback iteration): `achieved` = ALGORITHMIC bytes of the
-                 stages it covers (SURVEY.md 8d model) / HIP-event time measured live over the
-                 timed region on the stream the kernels run on; `traffic` = HBM bytes per launch
-                 from the PMC counters of the committed profile; `frac_traffic` = those bytes /
-                 the live launch time / peak (what the memory system really moved).
+                 solve, one launch per Farneback iteration): `achieved` = the compulsory bytes of the
+                 launches AS BUILT (iter_as_built_bytes: R0 + R1 + flow in / out; M is never in memory)
+                 / HIP-event time measured live over the timed region on the stream the kernels run
+                 on, `frac` = that / 8 TB/s (<= 1 by construction); `frac_model_8d` = SURVEY.md 8d's
+                 stage-by-stage model (M priced as if stored: can exceed 1) over the same time;
+                 `traffic` = HBM bytes per launch from the PMC counters of the committed profile,
+                 `frac_traffic` = those bytes / the live launch time / peak (what the memory system
+                 really moved).  Steps of fewer than 32 pairs run without the event brackets (they cost
+                 ~8 us per launch on the stream) and report no kernel roofline.
   parity       : the bench configuration's own output against the oracle (a 256-pair step taken
                  outside the timed region; first pairs' flows, first frames' histograms).
   histogram    : frames/s and roofline of the Histogram kernel alone (same run, own timed loop).
   cpu_baseline : the CPU oracle (oracle/oracle.c, a port of the OpenCV algorithms the reference
                  calls) on all host cores, median of >= 3 repetitions on a bounded sample.
   extra        : own timed loops after the headline: config 3 (10 000-frame shot detection on this GPU),
-                 config 4 (4K, batch 32), the host-fed
-                 (PCIe-inclusive) rates through the DeviceType::CPU kernel classes, Histogram at
-                 small batches.  None of these is `value`.
+                 config 4 (4K, batch 32), config 5 (pose network), the host-fed (PCIe-inclusive) rates
+                 through the DeviceType::CPU kernel classes (Histogram over 1000 host frames = config 1),
+                 Histogram at small batches, OpticalFlow at 1 / 2 / 4 / 8 pairs per call (the reference's
+                 unbatched calling pattern; C ABI back to back and the kernel class with its per-call
+                 synchronisation), the legacy flow-histogram pipeline at 426x240 and Farneback at 640x480.
+                 None of these is `value`.
 """
 import argparse
 import json
