@@ -1867,6 +1867,12 @@ constexpr int F3_PADW = B2_T + B2_T / 8;
 static_assert(B2_OUT % F3_SW == 0 && F3_GROUP * F3_NSEG <= B2_T && F3_ANCHOR % F3_RING == 0 && F3_RING % F3_GROUP == 0, "bad v3 geometry");
 __device__ __forceinline__ constexpr int f3_pos(int x) { return x + (x >> 3); }
 
+// Exactly half as tall (a.h == 2 a.ch, the only geometry FLOW_COARSE2 is launched for): scale_y is exactly 0.5, so
+// fy = (y + 0.5) 0.5 - 0.5 = y / 2 - 0.25 exactly -- even rows: sy = y / 2 - 1, weight 0.75; odd rows: sy = (y - 1) / 2,
+// weight 0.25 -- and the row geometry is integer arithmetic on wave-uniform values (scalar unit) instead of ~20 double /
+// float vector instructions per row.  The same numbers as the generic expressions, which are exact here.
+__device__ __forceinline__ int coarse2_row(int y) { return ((y + 1) >> 1) - 1; }
+
 // coarse rows s .. s + RB/2 + 1 cover the RB fine rows of a batch when the coarse level is exactly half as tall
 template <int RB>
 struct FlowRawN {
@@ -1875,7 +1881,7 @@ struct FlowRawN {
 template <int RB>
 __device__ __forceinline__ void coarseN_issue(const IterArgs& a, const float* __restrict__ C, const CoarseX& cx, int y0,
                                               FlowRawN<RB>& r) {
-  const int s = coarse_row0(a, y0);
+  const int s = coarse2_row(y0);  // == coarse_row0(a, y0) for the exact-half geometry this is used for
 #pragma unroll
   for (int j = 0; j < RB / 2 + 2; ++j) {
     const int yy = d_clamp(s + j, 0, a.ch - 1);
@@ -1887,6 +1893,37 @@ __device__ __forceinline__ void coarseN_issue(const IterArgs& a, const float* __
     }
   }
 }
+// A batch's RB flow vectors from its shared coarse rows: each coarse row interpolated horizontally ONCE (the generic path
+// does it per fine row), then combined vertically with the two weights; operands and operations per vector are those of
+// coarseN_finish, so the bits are.
+template <int RB>
+__device__ __forceinline__ void coarse2_finish_batch(const IterArgs& a, const CoarseX& cx, int y0, const int (&ys)[RB],
+                                                     const FlowRawN<RB>& r, float2 (&out)[RB]) {
+  const int s = coarse2_row(y0);
+  const float a1 = cx.a1, a0 = cx.a0;
+  float2 hx[RB / 2 + 2];
+#pragma unroll
+  for (int j = 0; j < RB / 2 + 2; ++j) {
+    if (cx.pair) {
+      hx[j].x = r.row[j].x * a0 + r.row[j].z * a1; hx[j].y = r.row[j].y * a0 + r.row[j].w * a1;
+    } else {
+      hx[j].x = r.row[j].x * 1.f; hx[j].y = r.row[j].y * 1.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int y = ys[i];
+    const int idx = coarse2_row(y) - s;  // 0 .. RB / 2, wave-uniform
+    const float fy = (y & 1) ? 0.25f : 0.75f;
+    const float b0 = 1.f - fy, b1 = fy;
+    float2 ta = hx[0], tb = hx[1];
+#pragma unroll
+    for (int j = 1; j <= RB / 2; ++j)
+      if (idx == j) { ta = hx[j]; tb = hx[j + 1]; }
+    out[i] = make_float2((ta.x * b0 + tb.x * b1) * a.mul, (ta.y * b0 + tb.y * b1) * a.mul);
+  }
+}
+
 template <int RB>
 __device__ __forceinline__ float2 coarseN_finish(const IterArgs& a, const CoarseX& cx, int y0, int y, const FlowRawN<RB>& r) {
   float fy = (float)((y + 0.5) * a.scale_y - 0.5);
@@ -2118,9 +2155,10 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
         // flows: the loads requested one batch ago become vectors now and the next rows are requested --
         // never a wait on loads issued in the same batch
         if (MODE == FLOW_COARSE2) {
+          int ysb[RB];
 #pragma unroll
-          for (int r = 0; r < RB; ++r)
-            fnext[r] = coarseN_finish<RB>(a, cx, d_clamp(ybb + (D + 1) * RB + M + 1, 0, h - 1), d_clamp(ybb + (D + 1) * RB + r + M + 1, 0, h - 1), rawn);
+          for (int r = 0; r < RB; ++r) ysb[r] = d_clamp(ybb + (D + 1) * RB + r + M + 1, 0, h - 1);
+          coarse2_finish_batch<RB>(a, cx, ysb[0], ysb, rawn, fnext);
           coarseN_issue<RB>(a, C, cx, d_clamp(ybb + (D + 2) * RB + M + 1, 0, h - 1), rawn);
         } else {
 #pragma unroll
@@ -2305,8 +2343,10 @@ __global__ __launch_bounds__((FrGeom<NCW, NMS>::THREADS)) void k_flow_iter_roles
                 um_issue(R0, R1, np, h, w, xc, rowk(k0 + KS + r), fcur[r], L[r]);
               }
               if (MODE == FLOW_COARSE2) {
+                int ysb[RB];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) fnext[r] = coarseN_finish<RB>(a, cx, rowk(k0 + 2 * KS), rowk(k0 + 2 * KS + r), rawn);
+                for (int r = 0; r < RB; ++r) ysb[r] = rowk(k0 + 2 * KS + r);
+                coarse2_finish_batch<RB>(a, cx, ysb[0], ysb, rawn, fnext);
                 coarseN_issue<RB>(a, C, cx, rowk(k0 + 3 * KS), rawn);
               } else {
 #pragma unroll
