@@ -2630,25 +2630,29 @@ __global__ __launch_bounds__(NT) void k_flow_iter_tile(IterArgs a) {
   // row j replaces M of row j (its last reader is this very step of this very thread).
   for (int i = tid; i < 5 * FT_S; i += NT) {
     const int c = i / FT_S, col = i - c * FT_S;
+    // the column's 46 values first (one burst of LDS reads), then the serial chain on registers: read inside the chain, every
+    // step would wait for an LDS round trip (the compiler cannot move the reads above the in-place stores)
+    float mv[FT_S];
+#pragma unroll
+    for (int j = 0; j < FT_S; ++j) mv[j] = Mt[c][j][col];
     double vs;
     if (Y0 == 0) {
       // reference initialisation order: float(M[0]*(m+2)) + sum_{1..m-1} M[y] + float(M[m] - M[0])
-      vs = (double)(Mt[c][FT_M][col] * (float)(FT_M + 2));
+      vs = (double)(mv[FT_M] * (float)(FT_M + 2));
 #pragma unroll
-      for (int yy = 1; yy < FT_M; ++yy) vs += (double)Mt[c][FT_M + yy][col];
-      const float d = Mt[c][2 * FT_M][col] - Mt[c][FT_M][col];
+      for (int yy = 1; yy < FT_M; ++yy) vs += (double)mv[FT_M + yy];
+      const float d = mv[2 * FT_M] - mv[FT_M];
       vs += d;
     } else {
       vs = 0;
 #pragma unroll
-      for (int s2 = 0; s2 < W; ++s2) vs += (double)Mt[c][s2][col];
+      for (int s2 = 0; s2 < W; ++s2) vs += (double)mv[s2];
     }
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < FT_T; ++j) {
-      const float lo = Mt[c][j][col];
       Mt[c][j][col] = (float)vs;
       if (j + 1 < FT_T) {
-        const float d = Mt[c][j + W][col] - lo;
+        const float d = mv[j + W] - mv[j];
         vs += d;
       }
     }
