@@ -13,6 +13,7 @@
 // address so that their pyramids are built once per execute().
 #include <algorithm>
 #include <memory>
+#include <string>
 #include <unordered_map>
 
 #include "scanner/api/kernel.h"
@@ -130,12 +131,25 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
         break;
       }
       if (hipStreamCreateWithFlags(&lanes_[l].stream, hipStreamNonBlocking) != hipSuccess ||
-          st_ctx_set_stream(lanes_[l].ctx, lanes_[l].stream) != ST_OK)
+          st_ctx_set_stream(lanes_[l].ctx, lanes_[l].stream) != ST_OK ||
+          hipEventCreateWithFlags(&lanes_[l].up_done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&lanes_[l].comp_done, hipEventDisableTiming) != hipSuccess)
         RESULT_ERROR(&valid_, "cannot create a HIP stream on device %d", gpu_);
     }
+    // SCANNERTOOLS_FLOW_COPIES=overlap: every lane copies on its own stream (uploads of one lane run beside the other's
+    // copy-back); default "serial": ALL copies of both lanes on one stream, so that an upload and a copy-back are never in
+    // flight together -- this host's device-to-host copies run at 57 GB/s alone and at 36-38 GB/s beside an upload, and
+    // the flow fields going back are 2.7x the frames coming in
+    const char* cm = getenv("SCANNERTOOLS_FLOW_COPIES");
+    serial_copies_ = !(cm && std::string(cm) == "overlap");
+    if (valid_.success() && hipStreamCreateWithFlags(&copy_, hipStreamNonBlocking) != hipSuccess)
+      RESULT_ERROR(&valid_, "cannot create a HIP stream on device %d", gpu_);
   }
   ~OpticalFlowKernelHIPStaged() {
+    if (copy_) { (void)hipStreamSynchronize(copy_); (void)hipStreamDestroy(copy_); }
     for (auto& l : lanes_) {
+      if (l.up_done) (void)hipEventDestroy(l.up_done);
+      if (l.comp_done) (void)hipEventDestroy(l.comp_done);
       if (l.ctx) st_ctx_destroy(l.ctx);
       if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -178,12 +192,32 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
       const i32 pieces = (input_count + sub - 1) / sub;
       sub = (input_count + pieces - 1) / pieces;
     }
+    // copy-back of the sub-batch a lane computed last (serial mode: enqueued on the shared copy stream behind the NEXT
+    // sub-batch's upload, so that uploads stay one sub-batch ahead of the compute)
+    struct Pending { bool any = false; i32 r0 = 0, nb = 0; std::vector<float*> dev_outs; };
+    Pending pending[2];
+    auto copy_back = [&](int li) {
+      Pending& P = pending[li];
+      if (!P.any) return;
+      HIP_CHECK(hipStreamWaitEvent(copy_, lanes_[li].comp_done, 0));
+      for (i32 i = 0; i < P.nb;) {
+        i32 j = i + 1;
+        while (ostride == out_bytes && j < P.nb && output_frames[P.r0 + j]->data == output_frames[P.r0 + j - 1]->data + out_bytes) ++j;
+        HIP_CHECK(hipMemcpyAsync(output_frames[P.r0 + i]->data, P.dev_outs[i], out_bytes * (size_t)(j - i), hipMemcpyDeviceToHost, copy_));
+        i = j;
+      }
+      P.any = false;
+    };
     int lane_idx = 0;
     for (i32 r0 = 0; r0 < input_count; r0 += sub, lane_idx ^= 1) {
       const i32 nb = std::min(sub, input_count - r0);
       Lane& L = lanes_[lane_idx];
-      // the lane's previous sub-batch (compute + copy-back) must be done before its buffers are reused
-      LOG_IF(FATAL, st_ctx_sync(L.ctx) != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(L.ctx);
+      hipStream_t up_stream = serial_copies_ ? copy_ : L.stream;
+      // the lane's previous sub-batch (compute + copy-back) must be done before its buffers are reused: own stream in
+      // overlap mode; in serial mode its copy-back goes first on the copy stream, and this sub-batch's compute waits for
+      // the upload behind it
+      if (serial_copies_) copy_back(lane_idx);
+      else LOG_IF(FATAL, st_ctx_sync(L.ctx) != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(L.ctx);
       // distinct frames of this sub-batch
       std::vector<const u8*> host_frames;
       std::vector<int32_t> pairs;
@@ -206,14 +240,24 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
       for (size_t i = 0; i < host_frames.size();) {
         size_t j = i + 1;
         while (fstride == frame_bytes && j < host_frames.size() && host_frames[j] == host_frames[j - 1] + frame_bytes) ++j;
-        HIP_CHECK(hipMemcpyAsync(dev + fstride * i, host_frames[i], frame_bytes * (j - i), hipMemcpyHostToDevice, L.stream));
+        HIP_CHECK(hipMemcpyAsync(dev + fstride * i, host_frames[i], frame_bytes * (j - i), hipMemcpyHostToDevice, up_stream));
         for (; i < j; ++i) dev_frames[i] = dev + fstride * i;
+      }
+      if (serial_copies_) {
+        HIP_CHECK(hipEventRecord(L.up_done, copy_));
+        HIP_CHECK(hipStreamWaitEvent(L.stream, L.up_done, 0));
+        copy_back(lane_idx ^ 1);  // the other lane's finished sub-batch comes back behind this upload
       }
       std::vector<float*> dev_outs(nb);
       for (i32 i = 0; i < nb; ++i) dev_outs[i] = (float*)(dev + fstride * host_frames.size() + ostride * i);
       int st = st_farneback_pairs(L.ctx, dev_frames.data(), (int)dev_frames.size(), pairs.data(), nb,
                                   frame_info_.height(), frame_info_.width(), &params_, dev_outs.data());
       LOG_IF(FATAL, st != ST_OK) << "st_farneback_pairs: " << st_ctx_last_error(L.ctx);
+      if (serial_copies_) {
+        HIP_CHECK(hipEventRecord(L.comp_done, L.stream));
+        pending[lane_idx].any = true; pending[lane_idx].r0 = r0; pending[lane_idx].nb = nb; pending[lane_idx].dev_outs = dev_outs;
+        continue;
+      }
       // the output frames of a batch are one host block (new_frames) and the staged flows are adjacent on the device
       // whenever a flow field is a multiple of the staging alignment: then the whole sub-batch comes back in ONE copy
       // (16.6 MB copies reach 33 GB/s on this host, a 133 MB copy 57)
@@ -224,6 +268,12 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
         i = j;
       }
     }
+    if (serial_copies_) {
+      // the last two sub-batches, oldest first
+      copy_back(lane_idx);
+      copy_back(lane_idx ^ 1);
+      HIP_CHECK(hipStreamSynchronize(copy_));
+    }
     for (auto& l : lanes_) LOG_IF(FATAL, st_ctx_sync(l.ctx) != ST_OK) << "st_ctx_sync: " << st_ctx_last_error(l.ctx);
     for (i32 i = 0; i < input_count; ++i) insert_frame(output_columns[0], output_frames[i]);
   }
@@ -232,8 +282,11 @@ class OpticalFlowKernelHIPStaged : public StenciledBatchedKernel, public VideoKe
   struct Lane {
     st_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t up_done = nullptr, comp_done = nullptr;
     std::unique_ptr<DeviceStage> stage;
   };
+  hipStream_t copy_ = nullptr;
+  bool serial_copies_ = true;
   DeviceHandle device_;
   int gpu_;
   int sub_ = 8;
