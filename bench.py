@@ -464,10 +464,14 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         fed = {"frames": nh}
 
         def run_op(node, name):
-            o = NamedStream(scl, "legacy_" + name)
-            scl.execute_seconds, scl.steady_seconds, scl.steady_rows = 0.0, 0.0, 0
-            scl.run(scl.io.Output(node, [o]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
-            return o, (scl.steady_rows / scl.steady_seconds if scl.steady_rows else nh / scl.execute_seconds)
+            # twice, the better: the first run's execute() calls also fill the shim's page-locked output pool
+            # (a hipHostMalloc per batch of results), which a job of thousands of batches does once
+            o, best = NamedStream(scl, "legacy_" + name), 0.0
+            for _ in range(2):
+                scl.execute_seconds, scl.steady_seconds, scl.steady_rows = 0.0, 0.0, 0
+                scl.run(scl.io.Output(node, [o]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+                best = max(best, scl.steady_rows / scl.steady_seconds if scl.steady_rows else nh / scl.execute_seconds)
+            return o, best
 
         small_s, r_resize = run_op(scl.ops.Resize(frame=scl.io.Input([NamedVideoStream(scl, "lv")]), width=426, height=240,
                                                   device=DeviceType.CPU, batch=64), "resize")
