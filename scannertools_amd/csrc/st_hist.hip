@@ -264,6 +264,150 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p2: the v2 kernel with the counters of channels 0 and 1 sharing a dword (low / high 16 bits; channel 2 keeps whole dwords): 32
+// lane-indexed copies then take 64 KB instead of 96 KB and TWO 1024-thread workgroups fit a CU (64 registers per thread), so
+// one workgroup's first round trip, clear, fold and commit can run under the other's streaming.  Opt-in (ST_HIST_P2=1): the
+// gain at 32-64 frames per launch is 1-4 % (the two workgroups of a CU start and finish together in a one-round launch, so
+// little overlaps), see hist_launch.  Which half a byte's count goes to depends only on the byte's position in the vector, i.e. on
+// the thread's phase: the increment (1 or 1 << 16) is a per-thread constant and the inner loop has the same instructions as v2's.
+// A half-counter must stay below 65 536: a copy gets at most 6 bytes of a channel per vector of its T / 32 threads, so a
+// chunk is limited to kP2MaxVec vectors (the launcher raises `chunks` accordingly); the fold widens to 32 bits.
+// ---------------------------------------------------------------------------------------------
+constexpr long long kP2MaxVec = 336000;   // 6 * 336000 / 32 = 63 000 (+ the frame's < 32 unaligned end bytes) < 65 536
+
+__device__ __forceinline__ void lds_add(unsigned* p, unsigned v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int C>
+__device__ __forceinline__ void count16p(unsigned* h, uint4 q, unsigned c0, unsigned c1, unsigned c2, unsigned i0, unsigned i1,
+                                         unsigned i2) {
+  lds_add(h + c0 + (q.x & 0xff) * C, i0);
+  lds_add(h + c1 + ((q.x >> 8) & 0xff) * C, i1);
+  lds_add(h + c2 + ((q.x >> 16) & 0xff) * C, i2);
+  lds_add(h + c0 + (q.x >> 24) * C, i0);
+  lds_add(h + c1 + (q.y & 0xff) * C, i1);
+  lds_add(h + c2 + ((q.y >> 8) & 0xff) * C, i2);
+  lds_add(h + c0 + ((q.y >> 16) & 0xff) * C, i0);
+  lds_add(h + c1 + (q.y >> 24) * C, i1);
+  lds_add(h + c2 + (q.z & 0xff) * C, i2);
+  lds_add(h + c0 + ((q.z >> 8) & 0xff) * C, i0);
+  lds_add(h + c1 + ((q.z >> 16) & 0xff) * C, i1);
+  lds_add(h + c2 + (q.z >> 24) * C, i2);
+  lds_add(h + c0 + (q.w & 0xff) * C, i0);
+  lds_add(h + c1 + ((q.w >> 8) & 0xff) * C, i1);
+  lds_add(h + c2 + ((q.w >> 16) & 0xff) * C, i2);
+  lds_add(h + c0 + (q.w >> 24) * C, i0);
+}
+
+template <int C, int T>
+__global__ __launch_bounds__(T, 8) void k_hist_u8c3_p2(FrameSrc src, long long nbytes, int chunks, int bins,
+                                                        int32_t* __restrict__ out) {
+  static_assert(T % 3 == 1, "the channel phase of a thread's vectors must advance by one per step");
+  __shared__ unsigned sh[2 * 256 * C];   // [0, 256 C): channel 0 (low half) | channel 1 (high half); [256 C, 512 C): channel 2
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const uint8_t* p = src.ptrs ? src.ptrs[frame] : src.base + (size_t)frame * src.stride;
+  const unsigned copy = tid & (C - 1);
+
+  long long head = (long long)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > nbytes) head = nbytes;
+  const long long nvec = (nbytes - head) >> 4;
+  const long long tail = head + (nvec << 4);
+  typedef unsigned u4nt __attribute__((ext_vector_type(4)));
+  const u4nt* vq = reinterpret_cast<const u4nt*>(p + head);
+  auto ld = [&](long long j) { const u4nt v = __builtin_nontemporal_load(vq + j); return make_uint4(v.x, v.y, v.z, v.w); };
+  const long long per = ((nvec + chunks - 1) / chunks + 6 * T - 1) / (6 * T) * (6 * T);
+  const long long v0 = (long long)chunk * per;
+  long long v1 = v0 + per;
+  if (v1 > nvec) v1 = nvec;
+
+  long long i = v0 + tid;
+  const unsigned ph = (unsigned)((head + i) % 3);
+  // offset and increment of channel ch
+  auto off = [&](unsigned ch) { return (ch == 2 ? 256u * C : 0u) + copy; };
+  auto inc = [&](unsigned ch) { return ch == 1 ? 0x10000u : 1u; };
+  const unsigned o0 = off(ph), o1 = off((ph + 1) % 3), o2 = off((ph + 2) % 3);
+  const unsigned i0 = inc(ph), i1 = inc((ph + 1) % 3), i2 = inc((ph + 2) % 3);
+  const int full = v1 > v0 ? (int)((v1 - v0) / (6 * T)) : 0;
+  uint4 a = {}, b = {}, c = {}, d = {}, e = {}, f = {};
+  if (full > 0) {
+    a = ld(i); b = ld(i + T); c = ld(i + 2 * T);
+    d = ld(i + 3 * T); e = ld(i + 4 * T); f = ld(i + 5 * T);
+  }
+  {
+    uint4* z4 = reinterpret_cast<uint4*>(sh);
+    for (int z = tid; z < 2 * 256 * C / 4; z += T) z4[z] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  if (full > 0) {
+    for (int it = 1; it < full; ++it) {
+      i += 6 * T;
+      const uint4 na = ld(i), nb = ld(i + T), nc = ld(i + 2 * T);
+      const uint4 nd = ld(i + 3 * T), ne = ld(i + 4 * T), nf = ld(i + 5 * T);
+      __builtin_amdgcn_sched_barrier(0);
+      count16p<C>(sh, a, o0, o1, o2, i0, i1, i2);
+      count16p<C>(sh, b, o1, o2, o0, i1, i2, i0);
+      count16p<C>(sh, c, o2, o0, o1, i2, i0, i1);
+      count16p<C>(sh, d, o0, o1, o2, i0, i1, i2);
+      count16p<C>(sh, e, o1, o2, o0, i1, i2, i0);
+      count16p<C>(sh, f, o2, o0, o1, i2, i0, i1);
+      a = na; b = nb; c = nc; d = nd; e = ne; f = nf;
+    }
+    count16p<C>(sh, a, o0, o1, o2, i0, i1, i2);
+    count16p<C>(sh, b, o1, o2, o0, i1, i2, i0);
+    count16p<C>(sh, c, o2, o0, o1, i2, i0, i1);
+    count16p<C>(sh, d, o0, o1, o2, i0, i1, i2);
+    count16p<C>(sh, e, o1, o2, o0, i1, i2, i0);
+    count16p<C>(sh, f, o2, o0, o1, i2, i0, i1);
+    i += 6 * T;
+  }
+  for (; i + 2 * T < v1; i += 3 * T) {
+    uint4 a = ld(i), b = ld(i + T), c = ld(i + 2 * T);
+    count16p<C>(sh, a, o0, o1, o2, i0, i1, i2);
+    count16p<C>(sh, b, o1, o2, o0, i1, i2, i0);
+    count16p<C>(sh, c, o2, o0, o1, i2, i0, i1);
+  }
+  if (i < v1) {
+    uint4 a = ld(i);
+    count16p<C>(sh, a, o0, o1, o2, i0, i1, i2);
+    if (i + T < v1) {
+      uint4 b = ld(i + T);
+      count16p<C>(sh, b, o1, o2, o0, i1, i2, i0);
+    }
+  }
+  if (chunk == 0) {
+    for (long long b = tid; b < head; b += T) { const unsigned ch = (unsigned)(b % 3); lds_add(sh + off(ch) + p[b] * C, inc(ch)); }
+    for (long long b = tail + tid; b < nbytes; b += T) { const unsigned ch = (unsigned)(b % 3); lds_add(sh + off(ch) + p[b] * C, inc(ch)); }
+  }
+  __syncthreads();
+  // fold the C copies: thread b < 256 unpacks value b of channels 0 and 1 into dwords 0 and 1 of its row, thread 256 + b sums
+  // channel 2's row into its dword 0 (a row is touched by its thread only)
+  if (tid < 512) {
+    unsigned* row = sh + tid * C;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const unsigned v = row[(c + tid) & (C - 1)];
+      if (tid < 256) { lo += v & 0xffffu; hi += v >> 16; } else lo += v;
+    }
+    row[0] = lo;
+    if (tid < 256) row[1] = hi;
+  }
+  __syncthreads();
+  int32_t* o = out + (size_t)frame * 3 * bins;
+  for (int ob = tid; ob < 3 * bins; ob += T) {
+    const int ch = ob / bins, bin = ob - ch * bins;
+    const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
+    const unsigned* col = sh + (ch == 2 ? 256 * C : ch);   // value v of channel ch: col[v * C]
+    unsigned s = 0;
+    for (int v = lo; v < hi; ++v) s += col[v * C];
+    if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, s);
+  }
+}
+
 // Chunks per frame for the default kernel (one 1024-thread workgroup per CU at a time): the
 // launch takes ceil(n*c / CUs) rounds of workgroups that each stream 1/c of a frame, so pick the
 // c that minimises rounds/c (ties: fewer, larger chunks), with at least 6 vectors (one pipelined step) per thread.
@@ -291,12 +435,23 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
   // eight resident per CU -- clearing and folding shrink 16-fold and overlap with other workgroups' streaming
   // (ST_HIST16=0 keeps the general kernel)
   static const bool use16 = !(getenv("ST_HIST16") && atoi(getenv("ST_HIST16")) == 0);
+  // ST_HIST_P2=1: the packed two-workgroups-per-CU kernel instead of the one-per-CU one with 96 KB of whole-dword counters.
+  // Measured (round 4, 1080p, HIP events): 32 frames per launch +2 % on noise, -3 % on smooth / all-equal frames; 64 frames
+  // +1..4 %; 256 frames +1..4 % -- inside the spread between boxes, so the default stays the kernel without a counter bound.
+  static const bool use_p2 = getenv("ST_HIST_P2") && atoi(getenv("ST_HIST_P2")) == 1;
   long long chunks;
   if (variant == 32 && bins == 16 && use16) {
     chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
     long long max_chunks = (nvec + 3 * 256 * 4 - 1) / (3 * 256 * 4);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
+  } else if (variant == 32 && use_p2) {
+    // two workgroups per CU: 2 * CUs slots; a chunk's half-counters must not overflow
+    chunks = chunks_for(2 * ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
+    const long long need = (nvec + kP2MaxVec - 6 * 1024 - 1) / (kP2MaxVec - 6 * 1024);   // `per` is rounded up to 6 T vectors
+    if (chunks < need) chunks = need;
+    static const int force_chunks = getenv("ST_HIST_CHUNKS") ? atoi(getenv("ST_HIST_CHUNKS")) : 0;  // experiments
+    if (force_chunks > need) chunks = force_chunks;
   } else if (variant == 32) {
     chunks = chunks_for(ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
     static const int force_chunks = getenv("ST_HIST_CHUNKS") ? atoi(getenv("ST_HIST_CHUNKS")) : 0;  // experiments
@@ -318,6 +473,8 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     st_timed t(ctx, ST_K_HIST);
     if (variant == 32 && bins == 16 && use16)
       hipLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+    else if (variant == 32 && use_p2)
+      hipLaunchKernelGGL((k_hist_u8c3_p2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32)
       hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 8)

@@ -42,4 +42,8 @@ rocprofv3 --kernel-trace --stats -d $out/ltrace -o trace -- python3 scripts/benc
 python3 scripts/rocpd_stats.py $out/ltrace/trace_results.db | grep -v "at::native\|rocclr\|distribution\|elementwise\|vectorized" > $out/summary/legacy_kernel_stats.txt
 python3 scripts/rocpd_timeline.py $out/ltrace/trace_results.db k_resize_linear > $out/summary/legacy_timeline.txt
 rm -rf $out/ltrace
+# the Histogram kernel at Scanner-sized launches: kernel-trace durations beside the HIP-event figures
+# (afterwards, in the build container: python scripts/hist_trace_json.py $tag -> profiles/hist_small_trace.json)
+bash scripts/trace_hist.sh $tag 32 64 256 > /dev/null 2>&1
+{ for n in 32 64 256; do echo "== $n frames of 1080p per launch (scripts/trace_hist.sh: rocprofv3 --kernel-trace of scripts/bench_hist.py; 3 kinds of frames x 21 launches per instance) =="; grep k_hist gpurun_out/th_${tag}_$n.txt; echo "-- the same launches by the HIP-event brackets (st_ctx_timing):"; grep bins gpurun_out/th_${tag}_$n.log; done; } > $out/summary/hist_small_trace.txt
 cat $out/bench.json

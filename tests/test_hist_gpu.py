@@ -117,3 +117,46 @@ def test_shot_pipeline_on_device_stream(hip_ctx):
     assert (hist.sum(dim=2) == h * w).all()
     res = shot_boundaries(None, list(hist.cpu().numpy()))
     assert res[0] == cuts and all(r is None for r in res[1:])
+
+
+_VARIANT_SCRIPT = r"""
+import numpy as np, torch
+from scannertools_amd.hip import HipContext
+ctx = HipContext(0)
+def ref(fr, bins):
+    return torch.stack([torch.stack([torch.bincount((f[..., c].flatten().int() * bins) >> 8, minlength=bins) for c in range(3)]) for f in fr])
+g = torch.Generator(device="cuda").manual_seed(3)
+for (n, h, w) in ((5, 37, 53), (3, 480, 640), (2, 1080, 1920), (40, 1080, 1920)):
+    fr = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    for bins in (256, 16, 100):
+        assert torch.equal(ctx.histogram(fr, bins).long(), ref(fr, bins)), (n, h, w, bins)
+# all-equal frames: every count of a channel lands on one counter (the packed kernel's 16-bit halves must not overflow):
+# one 4K frame, and more 1080p frames than workgroup slots (the launcher would otherwise give a whole frame to a workgroup)
+for (n, h, w) in ((1, 2160, 3840), (3, 2160, 3840), (600, 1080, 1920)):
+    eq = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    eq[..., 0], eq[..., 1], eq[..., 2] = 255, 255, 0
+    got = ctx.histogram(eq, 256)
+    assert (got[:, 0, 255] == h * w).all() and (got[:, 1, 255] == h * w).all() and (got[:, 2, 0] == h * w).all(), (n, h, w)
+    assert (got.sum(dim=2) == h * w).all()
+    del eq
+# unaligned frame list
+big = torch.randint(0, 256, (4 * 5000,), dtype=torch.uint8, device="cuda", generator=g)
+views = [big[i * 5000 + off: i * 5000 + off + 3 * 33 * 47].view(33, 47, 3) for i, off in enumerate((1, 7, 16, 35))]
+assert torch.equal(ctx.histogram(views, 256).long(), ref(views, 256))
+print("variant ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"ST_HIST_P2": "1"}, {"ST_HIST_VARIANT": "8"}, {"ST_HIST_VARIANT": "0"}, {"ST_HIST16": "0"}])
+def test_hist_alternative_kernels(env):
+    """The opt-in kernels (the switch is read once per process, so each runs in its own): the packed two-per-CU instance
+    (ST_HIST_P2=1), eight copies per 256 threads, one copy per wave, and the general kernel at 16 bins -- against
+    torch.bincount, with the all-equal frames that bound the packed kernel's half-counters."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
