@@ -320,8 +320,11 @@ int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int
  * bf16 terms, the six significant products accumulated in float32; 2.67 x the float32 matrix rate on CDNA4, results
  * within one float32 rounding per product of st_conv2d_nhwc_f32's, not bit-identical to it).  Opt-in replacement for
  * the same Caffe layers (cpm2_kernel.cpp:8-52).  Activations and outputs as above; w3_dev: the layer's weights
- * rearranged ONCE by st_conv_pack_weights_bf16x3 from the [cout_pad][kh][kw][cin] float32 tensor
- * (cout_pad * kh * kw * cin * 6 bytes, 16-byte aligned). */
+ * rearranged ONCE by st_conv_pack_weights_bf16x3 from the [cout_pad][kh][kw][cin] float32 tensor into a 16-byte
+ * aligned buffer of st_conv_bf16x3_packed_bytes(...) bytes (6 bytes per weight; twice that for 3x3 / 7x7 layers with
+ * cout_pad a multiple of 128, which also get the operand-order copy the spatial-tile kernel reads -- the library picks
+ * the kernel per call, so every caller computes the same bits). */
+long long st_conv_bf16x3_packed_bytes(int cout_pad, int kh, int kw, int cin);
 int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
 int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
                           const void* w3_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,

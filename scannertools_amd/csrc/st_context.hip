@@ -62,6 +62,7 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (const char* e = getenv("ST_ROLES_NCW")) c->roles_ncw = atoi(e);
   if (const char* e = getenv("ST_ROLES_ROWS")) c->roles_rows = atoi(e);
   if (const char* e = getenv("ST_PYR_ROLES")) c->pyr_roles = atoi(e);
+  if (const char* e = getenv("ST_CONV_TILE")) c->conv_tile = atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   *out_ctx = c;

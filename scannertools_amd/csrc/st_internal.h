@@ -33,6 +33,7 @@ struct st_ctx {
   // role-split kernels (scheduling switches like tile_mode, read when the context is created; results do not depend on them):
   // ST_ITER_ROLES / ST_PYR_ROLES: -1 by launch size (default), 0 never, 1 always; ST_ROLES_NCW: 0 = by cost, 4 or 5 column waves
   int roles_mode = -1, roles_ncw = 0, roles_rows = 0, pyr_roles = -1;
+  int conv_tile = -1;   // ST_CONV_TILE: 0 = bf16x3 convolutions always on the per-tap kernel (st_conv.hip)
   // bump-allocated scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;

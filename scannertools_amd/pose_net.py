@@ -393,7 +393,7 @@ class PoseNet:
         if math == "bf16x3":
             ctx._bind()
             for name, (wp, _) in self.packed.items():
-                w3 = torch.empty((wp.numel() * 6,), dtype=torch.uint8, device=self.device)
+                w3 = torch.empty((ctx._L.st_conv_bf16x3_packed_bytes(wp.shape[0], wp.shape[1], wp.shape[2], wp.shape[3]),), dtype=torch.uint8, device=self.device)
                 ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], wp.shape[1], wp.shape[2],
                                                               wp.shape[3], ctypes.c_void_p(w3.data_ptr())))
                 self.packed3[name] = w3

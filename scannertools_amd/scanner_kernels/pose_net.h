@@ -416,7 +416,7 @@ class Net {
     if (!bf16x3_) return st_conv2d_nhwc_f32(ctx, x, n, h, w, cin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
     if (!p.w3) {
       void* w3 = nullptr;
-      if (hipMalloc(&w3, (size_t)p.cout_pad * l.k * l.k * p.cin_pad * 6) != hipSuccess) return ST_ERR_HIP;
+      if (hipMalloc(&w3, (size_t)st_conv_bf16x3_packed_bytes(p.cout_pad, l.k, l.k, p.cin_pad)) != hipSuccess) return ST_ERR_HIP;
       const int st = st_conv_pack_weights_bf16x3(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, w3);
       if (st != ST_OK) {  // an unpacked buffer must never be mistaken for packed weights by the next call
         (void)hipFree(w3);

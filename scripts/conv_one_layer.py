@@ -16,7 +16,7 @@ y = torch.empty((n, h, w, (co + 3) // 4 * 4), device="cuda")
 math = os.environ.get("MATH", "f32")
 ctx._bind()
 if math == "bf16x3":
-    w3 = torch.empty((wt.numel() * 6,), dtype=torch.uint8, device="cuda")
+    w3 = torch.empty((ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, ci),), dtype=torch.uint8, device="cuda")
     ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wt.data_ptr()), cop, k, k, ci, ctypes.c_void_p(w3.data_ptr())))
     torch.cuda.synchronize()
 ctx.timing_enable([_native.K_CONV]); ctx.timing_reset()

@@ -17,7 +17,7 @@ import oracle
 from scannertools_amd import pose_net
 from scannertools_amd.engine import CacheMode, Client, DeviceType, NamedStream, NamedVideoStream, PerfParams
 from test_flow_gpu import _check_flow, _torch_stream
-from test_pose_net_gpu import MATH, _conv
+from test_pose_net_gpu import MATH, NET_MATH, _conv
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +99,7 @@ def test_config5_layers_at_network_geometry(hip_ctx, n, h, w, ci, co, k, math):
     assert (y[..., co:] == -7.0).all()
 
 
-@pytest.mark.parametrize("math", MATH)
+@pytest.mark.parametrize("math", NET_MATH)
 def test_config5_network_at_368x656(hip_ctx, math):
     """All 92 convolutions + 3 poolings at the network's real input (a 1080p frame at scale 368/1080: 368x656), batch 2,
     against the float32 torch network on the CPU."""

@@ -2,6 +2,7 @@
 torch.nn.functional on the same float32 weights -- layer shapes one by one (every kernel size, both block
 widths, channel slices, pixel-count tails) and the whole network end to end."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -12,7 +13,27 @@ from scannertools_amd import pose_net
 pytestmark = pytest.mark.gpu
 
 
-MATH = ["f32", "bf16x3"]   # the float32 matrix instruction (default) and the opt-in split-bf16 arithmetic of the same accuracy
+# the float32 matrix instruction (default), the opt-in split-bf16 arithmetic of the same accuracy (3x3 / 7x7 layers with
+# 128-channel output blocks on the spatial-tile kernel, the rest on the per-tap kernel), and the latter for every layer
+MATH = ["f32", "bf16x3", "bf16x3_pertap"]
+NET_MATH = MATH[:2]   # PoseNet(math=...)
+_PERTAP = {}
+
+
+def _pertap_ctx():
+    """A context created under ST_CONV_TILE=0 (the switch is read at st_ctx_create)."""
+    if "ctx" not in _PERTAP:
+        from scannertools_amd.hip import HipContext
+        saved = os.environ.get("ST_CONV_TILE")
+        os.environ["ST_CONV_TILE"] = "0"
+        try:
+            _PERTAP["ctx"] = HipContext(0)
+        finally:
+            if saved is None:
+                del os.environ["ST_CONV_TILE"]
+            else:
+                os.environ["ST_CONV_TILE"] = saved
+    return _PERTAP["ctx"]
 
 
 def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math="f32"):
@@ -29,9 +50,11 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
     wp, bp = wp.cuda(), bp.cuda()
     ys = cout_total or (co + 3) // 4 * 4
     y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
+    if math == "bf16x3_pertap":
+        hip_ctx, math = _pertap_ctx(), "bf16x3"
     hip_ctx._bind()
     if math == "bf16x3":
-        w3 = torch.empty((wp.numel() * 6,), dtype=torch.uint8, device="cuda")
+        w3 = torch.empty((hip_ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, cip),), dtype=torch.uint8, device="cuda")
         hip_ctx._check(hip_ctx._L.st_conv_pack_weights_bf16x3(hip_ctx._h, ctypes.c_void_p(wp.data_ptr()), cop, k, k, cip, ctypes.c_void_p(w3.data_ptr())))
         hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_bf16x3(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
                                                          ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
@@ -45,7 +68,11 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
 
 @pytest.mark.parametrize("n,h,w,ci,co,k,relu", [(1, 9, 13, 3, 64, 3, 1), (2, 23, 31, 16, 128, 3, 1), (1, 17, 19, 128, 38, 1, 0),
                                                  (2, 12, 20, 64, 19, 7, 0), (1, 46, 82, 185, 128, 7, 1), (3, 8, 8, 512, 512, 3, 1),
-                                                 (1, 5, 7, 32, 200, 5, 1)])
+                                                 (1, 5, 7, 32, 200, 5, 1),
+                                                 # the spatial-tile kernel's edges: one-pixel maps, a map narrower than the kernel, tiles
+                                                 # cut by the right / bottom border, two tile columns, two output blocks, one slice
+                                                 (2, 1, 1, 16, 128, 7, 1), (1, 3, 2, 32, 128, 3, 0), (2, 47, 83, 48, 128, 7, 1),
+                                                 (1, 50, 300, 32, 256, 3, 1), (1, 33, 130, 16, 100, 7, 0)])
 @pytest.mark.parametrize("math", MATH)
 def test_conv_layer_matches_torch(hip_ctx, n, h, w, ci, co, k, relu, math):
     g = torch.Generator().manual_seed(n * 1000 + ci + co + k)
@@ -107,7 +134,7 @@ def test_maxpool_and_layout(hip_ctx):
     assert torch.equal(y[..., :3], ref)
 
 
-@pytest.mark.parametrize("math", MATH)
+@pytest.mark.parametrize("math", NET_MATH)
 def test_pose_network_end_to_end(hip_ctx, math):
     """All 92 convolutions + 3 poolings on a small input, against the float32 torch network (CPU, so that no
     other GPU library is in the comparison); the reference's own precision, so the bound is float32 round-off
