@@ -152,7 +152,7 @@ __device__ __forceinline__ void count16c(unsigned* h, uint4 q, unsigned c0, unsi
   lds_inc(h + c0 + (q.w >> (24 + SHIFT)) * C);
 }
 
-template <int C, int T, int SHIFT = 0>
+template <int C, int T, int SHIFT = 0, bool HALF = false>
 __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
                                                            int32_t* __restrict__ out) {
   static_assert(T % 3 == 1, "the channel phase of a thread's vectors must advance by one per step");
@@ -197,7 +197,32 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   }
   for (int z = tid; z < 3 * NB * C; z += T) sh[z] = 0;
   __syncthreads();
-  if (full > 0) {
+  if (full > 0 && HALF) {
+    // half-steps: the three vectors just counted are re-requested at once, so three to six are in flight and the drain after the
+    // last load is three vectors' counting instead of six
+    for (int it = 1; it < full; ++it) {
+      i += 6 * T;
+      count16c<C, SHIFT>(sh, a, o0, o1, o2);
+      count16c<C, SHIFT>(sh, b, o1, o2, o0);
+      count16c<C, SHIFT>(sh, c, o2, o0, o1);
+      __builtin_amdgcn_sched_barrier(0);
+      a = ld(i); b = ld(i + T); c = ld(i + 2 * T);
+      __builtin_amdgcn_sched_barrier(0);
+      count16c<C, SHIFT>(sh, d, o0, o1, o2);
+      count16c<C, SHIFT>(sh, e, o1, o2, o0);
+      count16c<C, SHIFT>(sh, f, o2, o0, o1);
+      __builtin_amdgcn_sched_barrier(0);
+      d = ld(i + 3 * T); e = ld(i + 4 * T); f = ld(i + 5 * T);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    count16c<C, SHIFT>(sh, a, o0, o1, o2);
+    count16c<C, SHIFT>(sh, b, o1, o2, o0);
+    count16c<C, SHIFT>(sh, c, o2, o0, o1);
+    count16c<C, SHIFT>(sh, d, o0, o1, o2);
+    count16c<C, SHIFT>(sh, e, o1, o2, o0);
+    count16c<C, SHIFT>(sh, f, o2, o0, o1);
+    i += 6 * T;
+  } else if (full > 0) {
     for (int it = 1; it < full; ++it) {
       i += 6 * T;
       const uint4 na = ld(i), nb = ld(i + T), nc = ld(i + 2 * T);
@@ -439,6 +464,11 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
   // Measured (round 4, 1080p, HIP events): 32 frames per launch +2 % on noise, -3 % on smooth / all-equal frames; 64 frames
   // +1..4 %; 256 frames +1..4 % -- inside the spread between boxes, so the default stays the kernel without a counter bound.
   static const bool use_p2 = getenv("ST_HIST_P2") && atoi(getenv("ST_HIST_P2")) == 1;
+  // Half-steps (three vectors re-requested as soon as they are counted) shorten the drain after a workgroup's last load from
+  // six vectors' counting to three: 37.5 -> 35.8 us for 32 frames per launch (8 pipelined steps per workgroup), nothing at 64
+  // (16 steps), -1..4 % at 256 on noise (each load then has half a step to land).  Used for launches of at most 10 steps per
+  // workgroup; ST_HIST_HALF=0 / 1 forces it off / on.
+  static const int half_env = getenv("ST_HIST_HALF") ? atoi(getenv("ST_HIST_HALF")) : -1;
   long long chunks;
   if (variant == 32 && bins == 16 && use16) {
     chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
@@ -462,6 +492,8 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
   }
+  const long long steps_per_wg = ((nvec + chunks - 1) / chunks + 6 * 1024 - 1) / (6 * 1024);
+  const bool half_steps = half_env == 1 || (half_env != 0 && steps_per_wg <= 10);
   ST_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * 3 * (size_t)bins * n, ctx->stream));
   // grid.y is limited to 65535 frames per launch
   for (int f0 = 0; f0 < n; f0 += 65535) {
@@ -475,6 +507,8 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
       hipLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32 && use_p2)
       hipLaunchKernelGGL((k_hist_u8c3_p2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+    else if (variant == 32 && half_steps)
+      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024, 0, true>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32)
       hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
     else if (variant == 8)

@@ -16,7 +16,7 @@ for n in (32, 64, 256):
     if not os.path.exists(path):
         continue
     for line in open(path):
-        m = re.match(r"(k_hist_u8c3_v2<32, (1024, 0|256, 4)>)\s+n=\s*(\d+)\s+median\s+([\d.]+) us\s+min\s+([\d.]+)", line)
+        m = re.match(r"(k_hist_u8c3_v2<32, (1024, 0|256, 4), (?:true|false)>)\s+n=\s*(\d+)\s+median\s+([\d.]+) us\s+min\s+([\d.]+)", line)
         if m:
             rec.setdefault("batch_%d" % n, {})["bins_256" if "1024" in m.group(2) else "bins_16"] = {
                 "kernel": m.group(1), "launches": int(m.group(3)), "median_us": float(m.group(4)), "min_us": float(m.group(5))}
