@@ -315,6 +315,17 @@ int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev, const flo
 int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
                        const float* w_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
                        float* y_dev, int y_stride, int y_offset);
+/* The same convolution with the weights ALSO in the spatial-tile kernel's operand order (wt_dev: st_conv_f32_tile_bytes(...)
+ * bytes filled once by st_conv_pack_weights_f32_tile from the same float32 tensor; the size is 0 and wt_dev may be null for
+ * layers the tile kernel does not take -- anything but 3x3 / 7x7 with cout_pad a multiple of 128).  The library picks the
+ * kernel per call (tile shape by map size; ST_CONV_TILE=0 at st_ctx_create keeps the per-tap kernel), so every caller computes
+ * the same bits: a k-ordered float32 fmaf chain per output in both kernels -- slices outer / taps inner in the tile kernel,
+ * taps outer in the per-tap kernel, hence not bit-identical to each other.  st_conv2d_nhwc_f32 = this with wt_dev null. */
+long long st_conv_f32_tile_bytes(int cout_pad, int kh, int kw, int cin);
+int st_conv_pack_weights_f32_tile(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
+int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                             const float* w_dev, const void* wt_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad,
+                             int relu, float* y_dev, int y_stride, int y_offset);
 /* 2x2 max pooling, stride 2: (n, h, w, c) -> (n, h/2, w/2, c), c a multiple of 4. */
 /* The same convolution on the bf16 matrix pipe at float32-grade accuracy ("bf16x3": every operand split into three
  * bf16 terms, the six significant products accumulated in float32; 2.67 x the float32 matrix rate on CDNA4, results

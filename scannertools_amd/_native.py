@@ -118,6 +118,9 @@ SIGNATURES = {
     "st_cpm2_limb_scores": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _i, _i, _i, _i, _c.c_float, _i, _vp]),
     "st_conv2d_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_conv_bf16x3_packed_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
+    "st_conv_f32_tile_bytes": (ctypes.c_longlong, [_i, _i, _i, _i]),
+    "st_conv_pack_weights_f32_tile": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "st_conv2d_nhwc_f32_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_conv_pack_weights_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "st_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_maxpool2_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),

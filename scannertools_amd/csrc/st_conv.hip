@@ -652,6 +652,198 @@ __global__ __launch_bounds__(512) void k_conv_tile_bf16x3(ConvTileArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The spatial tile for the float32 instruction (v_mfma_f32_32x32x2_f32): same workgroup shape, region, weight streaming and
+// pinned side work as k_conv_tile_bf16x3; what differs is the operand layout.  LDS: the region channel-major,
+// [buffer][16 channels][CTF_RPS] floats (a lane's A operand of step kk is ONE float, channel 2 kk + (lane >> 5) of its pixel:
+// 32 consecutive lanes read 32 consecutive floats; the plane stride 818 = 2 mod 16 spreads an item's four channel stores of
+// eight pixels over 32 banks).  Weights in operand order: [cout block][slice][tap][32-column tile][4-step group][lane] x 4 floats
+// (st_conv_pack_weights_f32_tile), four 16-byte loads per wave and tap, one tap ahead (a tap is 32 instructions of 64 cycles).
+// Accumulation order of an output: slices outer, taps inner, channels ascending inside a slice -- a k-ordered fmaf chain as
+// in k_conv_nhwc_f32 (taps outer there), independent of the tile shape.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CTF_RPS = 818;
+
+__global__ __launch_bounds__(256) void k_pack_weights_f32_tile(const float* __restrict__ w, int cout_pad, int taps, int cin,
+                                                               float* __restrict__ out) {
+  const long long total = (long long)cout_pad * taps * cin;
+  const int S = cin / 16;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cin);
+    const long long row = i / cin;
+    const int tap = (int)(row % taps), co = (int)(row / taps);
+    const int slice = c >> 4, k = c & 15, kk = k >> 1, lk = k & 1;
+    const int cb = co >> 7, j = (co >> 5) & 3, c31 = co & 31;
+    const size_t base = (((((size_t)cb * S + slice) * taps + tap) * 4 + j) * 2 + (kk >> 2)) * 64 + (lk * 32 + c31);
+    out[base * 4 + (kk & 3)] = w[i];
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void k_conv_tile_f32(ConvTileArgs a) {
+  constexpr int T = KS * KS;
+  __shared__ float Af[2][16][CTF_RPS];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, lk = lane >> 5;
+  int bt = blockIdx.x;
+  const int txi = bt % a.tiles_x;
+  bt /= a.tiles_x;
+  const int tyi = bt % a.tiles_y, img = bt / a.tiles_y;
+  const int y0 = tyi * a.th, x0 = txi * a.tw;
+  const int S = a.cin / 16;
+  const float* __restrict__ ximg = a.x + (size_t)img * a.h * a.wd * a.xs + a.xoff;
+
+  int goff[CT_ITEMS], loff[CT_ITEMS];
+  unsigned exists = 0, inb = 0;
+#pragma unroll
+  for (int i = 0; i < CT_ITEMS; ++i) {
+    const int e = i * 512 + t, r = e >> 2, cq = e & 3;
+    goff[i] = 0;
+    loff[i] = 0;
+    if (r < a.rp) {
+      const int ry = r / a.rw, rx = r - ry * a.rw;
+      const int yy = y0 - a.pad + ry, xx = x0 - a.pad + rx;
+      exists |= 1u << i;
+      loff[i] = 4 * cq * CTF_RPS + r;
+      if ((unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd) {
+        inb |= 1u << i;
+        goff[i] = (yy * a.wd + xx) * a.xs + 4 * cq;
+      }
+    }
+  }
+  constexpr int IGAP = KS == 7 ? 7 : 1, ILAT = KS == 7 ? 5 : 2, NRG = KS == 7 ? 1 : 3;
+  float4 rg[NRG];
+  auto stash_from = [&](int buf, int i, float4 v) {
+    if ((exists >> i) & 1) {
+      float* __restrict__ d = &Af[buf][0][0] + loff[i];
+      d[0] = v.x; d[CTF_RPS] = v.y; d[2 * CTF_RPS] = v.z; d[3 * CTF_RPS] = v.w;
+    }
+  };
+
+  const int wm = (wv >> 1) * 64;
+  const int npix = a.th * a.tw;
+  int abase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int p = wm + 32 * i + l31;
+    if (p >= npix) p = npix - 1;
+    const int ty = p / a.tw;
+    abase[i] = ty * a.rw + (p - ty * a.tw) + lk * CTF_RPS;
+  }
+  const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(a.w3t) + ((size_t)blockIdx.y * S * T) * 512 + (wv & 1) * 256 + lane;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float na[2][8];      // pixels of the next tap: [instruction tile][step]
+  uint4 nb[2][2];      // weights of the next tap: [column tile][4-step group]
+  auto loadB = [&](int q) {
+    const uint4* __restrict__ src = wq + (size_t)q * 512;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) nb[j][g] = src[(j * 2 + g) * 64];
+  };
+  auto readA = [&](int buf, int tapoff) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int ab = abase[i];
+      asm volatile("" : "+v"(ab));
+      const float* __restrict__ src = &Af[buf][0][0] + ab + tapoff;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) na[i][kk] = src[2 * kk * CTF_RPS];
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < CT_ITEMS; ++i)
+    stash_from(0, i, (inb >> i) & 1 ? *reinterpret_cast<const float4*>(ximg + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f));
+  const int nq = S * T;
+  loadB(0);
+  __syncthreads();
+  readA(0, 0);
+  for (int s = 0; s < S; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < S;   // uniform
+#pragma clang loop unroll(full)
+    for (int tap = 0; tap < T; ++tap) {
+      float af[2][8], bfr[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          af[i][kk] = na[i][kk];
+          const uint4 v = nb[i][kk >> 2];
+          bfr[i][kk] = __uint_as_float((kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w);
+        }
+      // 32 matrix instructions, each followed by one pinned piece of the work for the next tap (k_conv_tile_bf16x3): 0-3 the
+      // four weight loads of tap + 1 (unconditional, clamped), 4-19 the sixteen region reads of tap + 1, 20 the request of a
+      // region item of the next slice, 21 its four stores
+      const int q1 = s * T + tap + 1;
+      const uint4* __restrict__ wsrc = wq + (size_t)(q1 < nq ? q1 : nq - 1) * 512;
+      const float* asrc[2] = {nullptr, nullptr};
+      const bool item_load = tap % IGAP == 0 && tap / IGAP < CT_ITEMS;   // constants after unrolling
+      const bool item_store = tap >= ILAT && (tap - ILAT) % IGAP == 0 && (tap - ILAT) / IGAP < CT_ITEMS;
+      const int li = item_load ? tap / IGAP : 0, si = item_store ? (tap - ILAT) / IGAP : 0;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int kk = k >> 2, i = (k >> 1) & 1, j = k & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bfr[j][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 4) {
+          nb[k >> 1][k & 1] = wsrc[k * 64];
+        } else if (k < 20) {
+          if (tap + 1 < T) {
+            const int i2 = (k - 4) >> 3, k2 = (k - 4) & 7;
+            if (k2 == 0) {
+              int rw = a.rw, ab = abase[i2];
+              asm volatile("" : "+s"(rw));   // recomputed per tap (see k_conv_tile_bf16x3)
+              asm volatile("" : "+v"(ab));
+              asrc[i2] = &Af[buf][0][0] + ab + ((tap + 1) / KS) * rw + (tap + 1) % KS;
+            }
+            na[i2][k2] = asrc[i2][2 * k2 * CTF_RPS];
+          }
+        } else if (k == 20) {
+          if (item_load && more)
+            rg[li % NRG] = (inb >> li) & 1 ? *reinterpret_cast<const float4*>(ximg + goff[li] + 16 * (s + 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (k == 21) {
+          if (item_store && more) stash_from(buf ^ 1, si, rg[si % NRG]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (more) readA(buf ^ 1, 0);
+  }
+
+  const int wn = (wv & 1) * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (p >= npix) continue;
+      const int ty = p / a.tw, tx = p - ty * a.tw;
+      const int yy = y0 + ty, xx = x0 + tx;
+      if (yy >= a.h || xx >= a.wd) continue;
+      float* __restrict__ yp = a.y + ((size_t)((size_t)img * a.h + yy) * a.wd + xx) * a.ys + a.yoff;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nn = blockIdx.y * 128 + wn + 32 * j + l31;
+        if (nn < a.cout) {
+          float v = acc[i][j][r] + a.bias[nn];
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          yp[nn] = v;
+        }
+      }
+    }
+}
+
 // the tile shape for an h x w map and a K x K kernel: the (TH, TW) with the fewest 256-pixel instruction blocks per image
 // whose region fits the LDS buffer; false when even the best wastes more than a quarter of the matrix work
 bool conv_tile_plan(int h, int w, int ks, int* th, int* tw, double* eff) {
@@ -731,9 +923,9 @@ __global__ __launch_bounds__(256) void k_planar_to_nhwc(PlanarArgs a) {
 
 }  // namespace
 
-ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
-                                 const float* w_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
-                                 float* y_dev, int y_stride, int y_offset) {
+ST_EXPORT int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                                       const float* w_dev, const void* wt_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad,
+                                       int relu, float* y_dev, int y_stride, int y_offset) {
   ST_TRY(st_enter(ctx));
   if (!x_dev || !w_dev || !bias_dev || !y_dev || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0)
     return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
@@ -751,6 +943,26 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
   a.m = (long long)n * h * w;
   const long long bm = (a.m + CV_BM - 1) / CV_BM;
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+  int th = 0, tw = 0;
+  double eff = 0;
+  if (wt_dev && ctx->conv_tile != 0 && conv_tile_weights(kh, kw, cout_pad, cin) && conv_tile_plan(h, w, kh, &th, &tw, &eff)) {
+    if ((uintptr_t)wt_dev & 15) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: the tile-order weights must be 16-byte aligned");
+    ConvTileArgs ta;
+    ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
+    ta.w3t = (const unsigned*)wt_dev;
+    ta.n = n; ta.h = h; ta.wd = w; ta.cin = cin; ta.xs = x_stride; ta.xoff = x_offset; ta.pad = kh / 2;
+    ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
+    ta.th = th; ta.tw = tw; ta.rw = tw + kh - 1; ta.rp = (th + kh - 1) * (tw + kh - 1);
+    ta.tiles_x = (w + tw - 1) / tw; ta.tiles_y = (h + th - 1) / th;
+    const long long tiles = (long long)n * ta.tiles_x * ta.tiles_y;
+    if (tiles > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+    dim3 tgrid((unsigned)tiles, cout_pad / 128);
+    st_timed t(ctx, ST_K_CONV);
+    if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7>), tgrid, dim3(512), 0, ctx->stream, ta);
+    else hipLaunchKernelGGL((k_conv_tile_f32<3>), tgrid, dim3(512), 0, ctx->stream, ta);
+    ST_HIP(ctx, hipGetLastError());
+    return ST_OK;
+  }
   dim3 grid((unsigned)bm, cout_pad / bn);
   st_timed t(ctx, ST_K_CONV);
   if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_f32<128, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
@@ -759,6 +971,32 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
   return ST_OK;
 }
 
+ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
+                                 const float* w_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
+                                 float* y_dev, int y_stride, int y_offset) {
+  return st_conv2d_nhwc_f32_tiled(ctx, x_dev, n, h, w, cin, x_stride, x_offset, w_dev, nullptr, bias_dev, kh, kw, cout, cout_pad, relu, y_dev,
+                                  y_stride, y_offset);
+}
+
+
+ST_EXPORT long long st_conv_f32_tile_bytes(int cout_pad, int kh, int kw, int cin) {
+  if (cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0 || !conv_tile_weights(kh, kw, cout_pad, cin)) return 0;
+  return (long long)cout_pad * kh * kw * cin * 4;
+}
+
+ST_EXPORT int st_conv_pack_weights_f32_tile(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev) {
+  ST_TRY(st_enter(ctx));
+  if (!w_dev || !out_dev || cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0 || ((uintptr_t)out_dev & 15))
+    return st_set_error(ctx, ST_ERR_INVALID, "conv pack: bad arguments (16-byte aligned output)");
+  if (!conv_tile_weights(kh, kw, cout_pad, cin))
+    return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv pack: the tile order exists for 3x3 / 7x7 layers with cout_pad a multiple of 128 and cin a multiple of 16 (st_conv_f32_tile_bytes returns 0 otherwise)");
+  const long long total = (long long)cout_pad * kh * kw * cin;
+  long long bx = (total + 255) / 256;
+  if (bx > 65536) bx = 65536;
+  hipLaunchKernelGGL(k_pack_weights_f32_tile, dim3((unsigned)bx), dim3(256), 0, ctx->stream, w_dev, cout_pad, kh * kw, cin, (float*)out_dev);
+  ST_HIP(ctx, hipGetLastError());
+  return ST_OK;
+}
 
 ST_EXPORT long long st_conv_bf16x3_packed_bytes(int cout_pad, int kh, int kw, int cin) {
   if (cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0) return 0;

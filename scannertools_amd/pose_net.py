@@ -398,6 +398,17 @@ class PoseNet:
                                                               wp.shape[3], ctypes.c_void_p(w3.data_ptr())))
                 self.packed3[name] = w3
             torch.cuda.synchronize(self.device)
+        self.packed_tile = {}   # name -> float32 weights in the spatial-tile kernel's operand order (3x3 / 7x7 layers with 128-channel blocks)
+        if math == "f32":
+            ctx._bind()
+            for name, (wp, _) in self.packed.items():
+                nb = ctx._L.st_conv_f32_tile_bytes(wp.shape[0], wp.shape[1], wp.shape[2], wp.shape[3])
+                if nb > 0:
+                    wt_ = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+                    ctx._check(ctx._L.st_conv_pack_weights_f32_tile(ctx._h, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], wp.shape[1], wp.shape[2],
+                                                                    wp.shape[3], ctypes.c_void_p(wt_.data_ptr())))
+                    self.packed_tile[name] = wt_
+            torch.cuda.synchronize(self.device)
 
     # -- plumbing -------------------------------------------------------------------------------------
     def _conv(self, name, x, cin, xoff, y, cout, yoff, k, relu):
@@ -410,9 +421,11 @@ class PoseNet:
                                                     ctypes.c_void_p(self.packed3[name].data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, cout,
                                                     wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
             return
-        self.ctx._check(L.st_conv2d_nhwc_f32(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, cin, xs, xoff,
-                                             ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, cout,
-                                             wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
+        wt_ = self.packed_tile.get(name)
+        self.ctx._check(L.st_conv2d_nhwc_f32_tiled(self.ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, cin, xs, xoff,
+                                                   ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(wt_.data_ptr()) if wt_ is not None else None,
+                                                   ctypes.c_void_p(bp.data_ptr()), k, k, cout,
+                                                   wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
 
     def _pool(self, x, c):
         n, h, w, xs = x.shape

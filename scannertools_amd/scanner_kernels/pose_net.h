@@ -408,12 +408,30 @@ class Net {
     float* w = nullptr;
     float* b = nullptr;
     void* w3 = nullptr;  // the same weights as bf16 triples (bf16x3 arithmetic only; packed on first use)
+    void* wt = nullptr;  // float32 weights in the spatial-tile kernel's operand order (float32 arithmetic, eligible layers; on first use)
+    bool wt_tried = false;
     int cin_pad = 0, cout_pad = 0, k = 0;
   };
 
   // one convolution layer in the selected arithmetic
   int conv(st_ctx* ctx, const float* x, int n, int h, int w, int cin, int xs, int xoff, Packed& p, const LayerSpec& l, float* y, int ys, int yoff) {
-    if (!bf16x3_) return st_conv2d_nhwc_f32(ctx, x, n, h, w, cin, xs, xoff, p.w, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
+    if (!bf16x3_) {
+      if (!p.wt_tried) {
+        p.wt_tried = true;
+        const long long nb = st_conv_f32_tile_bytes(p.cout_pad, l.k, l.k, p.cin_pad);
+        if (nb > 0) {
+          void* wt = nullptr;
+          if (hipMalloc(&wt, (size_t)nb) != hipSuccess) return ST_ERR_HIP;
+          const int st = st_conv_pack_weights_f32_tile(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, wt);
+          if (st != ST_OK) {
+            (void)hipFree(wt);
+            return st;
+          }
+          p.wt = wt;
+        }
+      }
+      return st_conv2d_nhwc_f32_tiled(ctx, x, n, h, w, cin, xs, xoff, p.w, p.wt, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
+    }
     if (!p.w3) {
       void* w3 = nullptr;
       if (hipMalloc(&w3, (size_t)st_conv_bf16x3_packed_bytes(p.cout_pad, l.k, l.k, p.cin_pad)) != hipSuccess) return ST_ERR_HIP;
@@ -477,6 +495,7 @@ class Net {
       if (kv.second.w) (void)hipFree(kv.second.w);
       if (kv.second.b) (void)hipFree(kv.second.b);
       if (kv.second.w3) (void)hipFree(kv.second.w3);
+      if (kv.second.wt) (void)hipFree(kv.second.wt);
     }
     packed_.clear();
   }

@@ -25,13 +25,19 @@ for (h, w, ci, co, k, cnt) in shapes:
         w3 = torch.empty((ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, ci),), dtype=torch.uint8, device="cuda")
         ctx._bind()
         ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wt.data_ptr()), cop, k, k, ci, ctypes.c_void_p(w3.data_ptr())))
+    wtile = None
+    if math == "f32" and ctx._L.st_conv_f32_tile_bytes(cop, k, k, ci) > 0:
+        wtile = torch.empty((ctx._L.st_conv_f32_tile_bytes(cop, k, k, ci),), dtype=torch.uint8, device="cuda")
+        ctx._bind()
+        ctx._check(ctx._L.st_conv_pack_weights_f32_tile(ctx._h, ctypes.c_void_p(wt.data_ptr()), cop, k, k, ci, ctypes.c_void_p(wtile.data_ptr())))
     def run():
         ctx._bind()
         if math == "bf16x3":
             ctx._check(ctx._L.st_conv2d_nhwc_bf16x3(ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, ci, ci, 0, ctypes.c_void_p(w3.data_ptr()),
                                                     ctypes.c_void_p(b.data_ptr()), k, k, co, cop, 1, ctypes.c_void_p(y.data_ptr()), y.shape[3], 0))
             return
-        ctx._check(ctx._L.st_conv2d_nhwc_f32(ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, ci, ci, 0, ctypes.c_void_p(wt.data_ptr()),
+        ctx._check(ctx._L.st_conv2d_nhwc_f32_tiled(ctx._h, ctypes.c_void_p(x.data_ptr()), n, h, w, ci, ci, 0, ctypes.c_void_p(wt.data_ptr()),
+                                             ctypes.c_void_p(wtile.data_ptr()) if wtile is not None else None,
                                              ctypes.c_void_p(b.data_ptr()), k, k, co, cop, 1, ctypes.c_void_p(y.data_ptr()), y.shape[3], 0))
     run(); torch.cuda.synchronize()
     ctx.timing_enable([_native.K_CONV]); ctx.timing_reset()

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 # the float32 matrix instruction (default), the opt-in split-bf16 arithmetic of the same accuracy (3x3 / 7x7 layers with
 # 128-channel output blocks on the spatial-tile kernel, the rest on the per-tap kernel), and the latter for every layer
-MATH = ["f32", "bf16x3", "bf16x3_pertap"]
+MATH = ["f32", "bf16x3", "f32_pertap", "bf16x3_pertap"]
 NET_MATH = MATH[:2]   # PoseNet(math=...)
 _PERTAP = {}
 
@@ -50,8 +50,8 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
     wp, bp = wp.cuda(), bp.cuda()
     ys = cout_total or (co + 3) // 4 * 4
     y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
-    if math == "bf16x3_pertap":
-        hip_ctx, math = _pertap_ctx(), "bf16x3"
+    if math.endswith("_pertap"):
+        hip_ctx, math = _pertap_ctx(), math[:-7]
     hip_ctx._bind()
     if math == "bf16x3":
         w3 = torch.empty((hip_ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, cip),), dtype=torch.uint8, device="cuda")
@@ -60,9 +60,15 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
                                                          ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
                                                          int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
         return y
-    hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_f32(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
-                                                  ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
-                                                  int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
+    nb = hip_ctx._L.st_conv_f32_tile_bytes(cop, k, k, cip)
+    wt_ = None
+    if nb > 0:
+        wt_ = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        hip_ctx._check(hip_ctx._L.st_conv_pack_weights_f32_tile(hip_ctx._h, ctypes.c_void_p(wp.data_ptr()), cop, k, k, cip, ctypes.c_void_p(wt_.data_ptr())))
+    hip_ctx._check(hip_ctx._L.st_conv2d_nhwc_f32_tiled(hip_ctx._h, ctypes.c_void_p(x_nhwc.data_ptr()), n, h, w, cin, xs, xoff,
+                                                        ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(wt_.data_ptr()) if wt_ is not None else None,
+                                                        ctypes.c_void_p(bp.data_ptr()), k, k, co, cop,
+                                                        int(relu), ctypes.c_void_p(y.data_ptr()), ys, yoff))
     return y
 
 
