@@ -125,6 +125,35 @@ def test_conv_channel_slices_and_identity_known_answer(hip_ctx, math):
     np.testing.assert_array_equal(y[..., :16].cpu().numpy(), exp.numpy())
 
 
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_conv_tile_random_shapes(hip_ctx, math):
+    """Seeded random map sizes, channel counts and batch sizes for the spatial-tile kernels (3x3 / 7x7, 128-channel output blocks):
+    every tile shape the planner picks -- tiles cut by the right and bottom borders, several tile columns, maps smaller than a
+    tile, inputs read from a channel slice -- against float64 and against the per-tap kernel of the same arithmetic."""
+    rng = np.random.default_rng(20260 + len(math))
+    for case in range(24):
+        k = (3, 7)[case % 2]
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 140))
+        ci = int(rng.choice([16, 32, 48, 80]))
+        co = int(rng.choice([128, 100, 256, 129]))
+        n = int(rng.integers(1, 4))
+        xoff = int(rng.choice([0, 16]))
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn((n, h, w, ci + xoff + 16), generator=g)
+        wt = torch.randn((co, ci, k, k), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))
+        b = torch.randn((co,), generator=g) * 0.1
+        ref = torch.relu(torch.nn.functional.conv2d(x[..., xoff:xoff + ci].permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=k // 2))
+        ys = (co + 3) // 4 * 4 + 8
+        y = _conv(hip_ctx, x.cuda(), ci, xoff, wt, b, 1, cout_total=ys, yoff=4, math=math)
+        yp = _conv(hip_ctx, x.cuda(), ci, xoff, wt, b, 1, cout_total=ys, yoff=4, math=math + "_pertap")
+        got = y[..., 4:4 + co].permute(0, 3, 1, 2).cpu().double()
+        scale = max(float(ref.abs().max()), 1.0)
+        msg = (case, n, h, w, ci, co, k)
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, msg
+        assert float((y - yp).abs().max()) <= 4e-5 * scale, msg
+        assert (y[..., :4] == -7.0).all() and (y[..., 4 + co:] == -7.0).all(), msg
+
+
 def test_maxpool_and_layout(hip_ctx):
     g = torch.Generator().manual_seed(2)
     x = torch.randn((2, 3, 10, 14), generator=g).cuda()
