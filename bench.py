@@ -390,7 +390,7 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                             "of people on the host is not in this loop" % (nb5, w, h, sc5, nw5, nh5),
                 "dtype": "f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation)",
                 "frames_per_s": nb5 / dt5, "ms_per_batch": dt5 * 1e3, "gflop_per_frame": fl5 / 1e9,
-                "roofline": {"kernel": "k_conv_nhwc_f32", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
+                "roofline": {"kernel": "k_conv_tile_f32 (3x3 / 7x7 layers with 128-channel output blocks) + k_conv_nhwc_f32 (the rest)", "bound": "mfma", "achieved": tf5, "peak": 157.3, "unit": "TFLOP/s",
                              "frac": tf5 / 157.3, "launches": nl5, "kernel_ms_per_batch": ms5 / 2},
                 "other_kernels_ms_per_batch": {"cpm2_input": kms5[_native.K_CPM2_INPUT][1] / 2, "resize_maps": kms5[_native.K_CPM2_RESIZE][1] / 2,
                                                "nms": kms5[_native.K_CPM2_NMS][1] / 2, "limb_scores": kms5[_native.K_CPM2_LIMBS][1] / 2},
@@ -425,7 +425,7 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                             "float32-equivalent one",
                     "dtype": "bf16x3 (v_mfma_f32_32x32x16_bf16 on hi/mid/lo terms, f32 accumulation)",
                     "frames_per_s": nb5 / dt3, "ms_per_batch": dt3 * 1e3,
-                    "roofline": {"kernel": "k_conv_nhwc_bf16x3", "bound": "mfma", "achieved_useful": tf3, "achieved_executed": 6 * tf3,
+                    "roofline": {"kernel": "k_conv_tile_bf16x3 (3x3 / 7x7 layers with 128-channel output blocks) + k_conv_nhwc_bf16x3 (the rest)", "bound": "mfma", "achieved_useful": tf3, "achieved_executed": 6 * tf3,
                                  "peak": 2500.0, "unit": "TFLOP/s", "frac": 6 * tf3 / 2500.0, "frac_of_f32_matrix_peak": tf3 / 157.3,
                                  "kernel_ms_per_batch": ms3 / 2},
                     "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
