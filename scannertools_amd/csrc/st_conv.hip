@@ -24,6 +24,9 @@
 // MFMAs; one barrier per slice), and inside a slice the operands of step k+2 are read from LDS before
 // the MFMAs of step k.  A 16-channel slice keeps the kernel at 111 VGPRs / 33 KB of LDS = 4 blocks per
 // CU; 32-channel slices (2 blocks per CU) measured 13 % slower (profiles/README.md).
+// Round 4: 3x3 / 7x7 layers with whole 128-channel output blocks run on the spatial-tile kernels further down
+// (k_conv_tile_f32, k_conv_tile_bf16x3: the tile's input region held in LDS across the taps, weights in operand order from L1);
+// the per-tap kernels here keep the 1x1 layers, the 64-channel-output layers and maps no tile shape fits.
 #include <cstring>
 
 #include "st_internal.h"
@@ -416,9 +419,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_bf16x3(ConvArgs a, const u
 //     barrier between taps;
 //   * the B operands (weights) never touch LDS: st_conv_pack_weights_bf16x3 also writes them in the instruction's own
 //     operand order ([cout block][slice][tap][32-column tile][split][lane] x 16 bytes), so a wave fetches the 6 KB of a tap
-//     with six fully coalesced 16-byte loads straight into registers, one tap ahead; the four waves that share them hit L1;
-//   * the next slice's region is loaded into registers at the start of a slice and split / stored into the other LDS
-//     buffer between the taps' matrix instructions; ONE barrier per slice (49 or 9 taps x 24 MFMAs per wave).
+//     with six fully coalesced 16-byte loads straight into registers, TWO taps ahead (a tap's 768 matrix cycles do not cover
+//     an L2 round trip); the four waves that share them hit L1;
+//   * the next slice's region arrives one (pixel, channel quad) item per thread at a time and is split / stored into the other
+//     LDS buffer between the taps' matrix instructions; ONE barrier per slice (49 or 9 taps x 24 MFMAs per wave);
+//   * inside a tap every matrix instruction is followed by one pinned piece of the side work (see the main loop).
 // L1 fills per executed flop fall 3.3-fold (12 KB of weights per tap and slice for a 256 x 128 tile, the region's 0.4-2 KB
 // amortised over the taps).  Accumulation order of an output: slices outer, taps inner, the six terms as in
 // k_conv_nhwc_bf16x3 -- independent of the tile shape, so the tiling never changes a bit; against the per-tap kernel
