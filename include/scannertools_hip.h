@@ -257,6 +257,8 @@ enum st_color_code {
   ST_COLOR_BGR2YCrCb = 36, ST_COLOR_RGB2YCrCb = 37, ST_COLOR_YCrCb2BGR = 38, ST_COLOR_YCrCb2RGB = 39,
   ST_COLOR_BGR2HSV = 40, ST_COLOR_RGB2HSV = 41, ST_COLOR_HSV2BGR = 54, ST_COLOR_HSV2RGB = 55,
   ST_COLOR_BGR2HSV_FULL = 66, ST_COLOR_RGB2HSV_FULL = 67, ST_COLOR_HSV2BGR_FULL = 70, ST_COLOR_HSV2RGB_FULL = 71,
+  ST_COLOR_BGR2HLS = 52, ST_COLOR_RGB2HLS = 53, ST_COLOR_HLS2BGR = 60, ST_COLOR_HLS2RGB = 61,
+  ST_COLOR_BGR2HLS_FULL = 68, ST_COLOR_RGB2HLS_FULL = 69, ST_COLOR_HLS2BGR_FULL = 72, ST_COLOR_HLS2RGB_FULL = 73,
   ST_COLOR_BGR2YUV = 82, ST_COLOR_RGB2YUV = 83, ST_COLOR_YUV2BGR = 84, ST_COLOR_YUV2RGB = 85
 };
 int st_cvt_color_out_channels(int code, int in_channels);

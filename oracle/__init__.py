@@ -255,6 +255,8 @@ COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR, CO
 COLOR_BGR2YCrCb, COLOR_RGB2YCrCb, COLOR_YCrCb2BGR, COLOR_YCrCb2RGB = 36, 37, 38, 39
 COLOR_RGB2HSV, COLOR_HSV2BGR, COLOR_HSV2RGB = 41, 54, 55
 COLOR_BGR2HSV_FULL, COLOR_RGB2HSV_FULL, COLOR_HSV2BGR_FULL, COLOR_HSV2RGB_FULL = 66, 67, 70, 71
+COLOR_BGR2HLS, COLOR_RGB2HLS, COLOR_HLS2BGR, COLOR_HLS2RGB = 52, 53, 60, 61
+COLOR_BGR2HLS_FULL, COLOR_RGB2HLS_FULL, COLOR_HLS2BGR_FULL, COLOR_HLS2RGB_FULL = 68, 69, 72, 73
 COLOR_BGR2YUV, COLOR_RGB2YUV, COLOR_YUV2BGR, COLOR_YUV2RGB = 82, 83, 84, 85
 COLOR_BGR2XYZ, COLOR_RGB2XYZ, COLOR_XYZ2BGR, COLOR_XYZ2RGB = 32, 33, 34, 35
 

@@ -1063,7 +1063,9 @@ ORC_API int orc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* d
 enum { ORC_BGR2RGB = 4, ORC_BGR2GRAY = 6, ORC_RGB2GRAY = 7, ORC_GRAY2BGR = 8, ORC_BGR2YCrCb = 36, ORC_RGB2YCrCb = 37,
        ORC_YCrCb2BGR = 38, ORC_YCrCb2RGB = 39, ORC_BGR2HSV = 40, ORC_RGB2HSV = 41, ORC_HSV2BGR = 54, ORC_HSV2RGB = 55,
        ORC_BGR2HSV_FULL = 66, ORC_RGB2HSV_FULL = 67, ORC_HSV2BGR_FULL = 70, ORC_HSV2RGB_FULL = 71,
-       ORC_BGR2YUV = 82, ORC_RGB2YUV = 83, ORC_YUV2BGR = 84, ORC_YUV2RGB = 85 };
+       ORC_BGR2YUV = 82, ORC_RGB2YUV = 83, ORC_YUV2BGR = 84, ORC_YUV2RGB = 85,
+       ORC_BGR2HLS = 52, ORC_RGB2HLS = 53, ORC_HLS2BGR = 60, ORC_HLS2RGB = 61,
+       ORC_BGR2HLS_FULL = 68, ORC_RGB2HLS_FULL = 69, ORC_HLS2BGR_FULL = 72, ORC_HLS2RGB_FULL = 73 };
 
 /* Further codes of the reference's table (convert_color_kernel.cpp:60-93), restated from
  * imgproc/src/color_hsv.simd.hpp and color_yuv.simd.hpp:
@@ -1086,6 +1088,8 @@ ORC_API int orc_cvt_out_channels(int code, int in_channels) {
     case ORC_BGR2HSV: case ORC_BGR2YCrCb: case ORC_RGB2YCrCb: case ORC_YCrCb2BGR: case ORC_YCrCb2RGB:
     case ORC_RGB2HSV: case ORC_HSV2BGR: case ORC_HSV2RGB: case ORC_BGR2HSV_FULL: case ORC_RGB2HSV_FULL:
     case ORC_HSV2BGR_FULL: case ORC_HSV2RGB_FULL: case ORC_BGR2YUV: case ORC_RGB2YUV: case ORC_YUV2BGR: case ORC_YUV2RGB:
+    case ORC_BGR2HLS: case ORC_RGB2HLS: case ORC_HLS2BGR: case ORC_HLS2RGB:
+    case ORC_BGR2HLS_FULL: case ORC_RGB2HLS_FULL: case ORC_HLS2BGR_FULL: case ORC_HLS2RGB_FULL:
       return in_channels == 3 ? 3 : -1;
     case 32: case 33: case 34: case 35: return in_channels == 3 ? 3 : -1;   /* BGR2XYZ, RGB2XYZ, XYZ2BGR, XYZ2RGB */
     /* channel layout family (cv::cvtColor codes 0..3, 5, 9..31) */
@@ -1359,6 +1363,70 @@ ORC_API int orc_cvt_color_u8(const uint8_t* src, int h, int w, int cn, int code,
       const float hh = src[3 * i], ss = src[3 * i + 1] * (1.f / 255.f), vv = src[3 * i + 2] * (1.f / 255.f);
       float b, g, r;
       orc_hsv2rgb_native(hh, ss, vv, hscale, &b, &g, &r);
+      dst[3 * i + bidx] = orc_sat_u8_float(b * 255.f);
+      dst[3 * i + 1] = orc_sat_u8_float(g * 255.f);
+      dst[3 * i + (bidx ^ 2)] = orc_sat_u8_float(r * 255.f);
+    }
+  } else if (code == ORC_BGR2HLS || code == ORC_RGB2HLS || code == ORC_BGR2HLS_FULL || code == ORC_RGB2HLS_FULL) {
+    /* RGB2HLS_b (imgproc/src/color_hsv.simd.hpp): bytes x (1/255) -> RGB2HLS_f, scalar formulation -> H =
+     * saturate_cast<uchar>(h x hrange/360) with hrange 180 (256 for _FULL), L and S x 255.  The vector bodies of OpenCV 4
+     * compute the same quantities with a fused multiply-add and 2 - (max + min); where a build takes them the last bit of
+     * a float can differ.  PARITY UNPINNED. */
+    const int bidx = (code == ORC_BGR2HLS || code == ORC_BGR2HLS_FULL) ? 0 : 2;
+    const float hscale = ((code == ORC_BGR2HLS || code == ORC_RGB2HLS) ? 180.f : 256.f) / 360.f;
+    for (size_t i = 0; i < n; ++i) {
+      const float b = src[3 * i + bidx] * (1.f / 255.f), g = src[3 * i + 1] * (1.f / 255.f), r = src[3 * i + (bidx ^ 2)] * (1.f / 255.f);
+      float h = 0.f, s = 0.f, l, vmin, vmax, diff;
+      vmax = vmin = r;
+      if (vmax < g) vmax = g;
+      if (vmax < b) vmax = b;
+      if (vmin > g) vmin = g;
+      if (vmin > b) vmin = b;
+      diff = vmax - vmin;
+      l = (vmax + vmin) * 0.5f;
+      if (diff > FLT_EPSILON) {
+        s = l < 0.5f ? diff / (vmax + vmin) : diff / (2 - vmax - vmin);
+        diff = 60.f / diff;
+        if (vmax == r) h = (g - b) * diff;
+        else if (vmax == g) h = (b - r) * diff + 120.f;
+        else h = (r - g) * diff + 240.f;
+        if (h < 0.f) h += 360.f;
+      }
+      dst[3 * i] = orc_sat_u8_float(h * hscale);
+      dst[3 * i + 1] = orc_sat_u8_float(l * 255.f);
+      dst[3 * i + 2] = orc_sat_u8_float(s * 255.f);
+    }
+  } else if (code == ORC_HLS2BGR || code == ORC_HLS2RGB || code == ORC_HLS2BGR_FULL || code == ORC_HLS2RGB_FULL) {
+    /* HLS2RGB_b: bytes -> (h, l/255, s/255) -> HLS2RGB_native (p2 = l <= 0.5 ? l (1 + s) : l + s - l s; p1 = 2 l - p2; h x
+     * 6/hrange wrapped into [0, 6); tab = {p2, p1, p1 + (p2 - p1)(1 - h), p1 + (p2 - p1) h}; the sector table of HSV2RGB) ->
+     * saturate_cast<uchar>(x * 255); hrange 180 (255 for _FULL, as cvtColor passes it for 8-bit data).  PARITY UNPINNED. */
+    static const int sector_data[][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    const int bidx = (code == ORC_HLS2BGR || code == ORC_HLS2BGR_FULL) ? 0 : 2;
+    const float hscale = 6.f / ((code == ORC_HLS2BGR || code == ORC_HLS2RGB) ? 180 : 255);
+    for (size_t i = 0; i < n; ++i) {
+      float h = src[3 * i];
+      const float l = src[3 * i + 1] * (1.f / 255.f), s = src[3 * i + 2] * (1.f / 255.f);
+      float b, g, r;
+      if (s == 0) {
+        b = g = r = l;
+      } else {
+        float tab[4];
+        const float p2 = l <= 0.5f ? l * (1 + s) : l + s - l * s;
+        const float p1 = 2 * l - p2;
+        h *= hscale;
+        while (h < 0) h += 6;
+        while (h >= 6) h -= 6;
+        int sector = (int)floorf(h);
+        h -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        tab[0] = p2;
+        tab[1] = p1;
+        tab[2] = p1 + (p2 - p1) * (1 - h);
+        tab[3] = p1 + (p2 - p1) * h;
+        b = tab[sector_data[sector][0]];
+        g = tab[sector_data[sector][1]];
+        r = tab[sector_data[sector][2]];
+      }
       dst[3 * i + bidx] = orc_sat_u8_float(b * 255.f);
       dst[3 * i + 1] = orc_sat_u8_float(g * 255.f);
       dst[3 * i + (bidx ^ 2)] = orc_sat_u8_float(r * 255.f);

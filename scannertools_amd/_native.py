@@ -20,6 +20,8 @@ COLOR_CODES = {"COLOR_BGR2RGB": 4, "COLOR_RGB2BGR": 4, "COLOR_BGR2GRAY": 6, "COL
                "COLOR_YCrCb2BGR": 38, "COLOR_YCrCb2RGB": 39, "COLOR_BGR2HSV": 40, "COLOR_RGB2HSV": 41,
                "COLOR_HSV2BGR": 54, "COLOR_HSV2RGB": 55, "COLOR_BGR2HSV_FULL": 66, "COLOR_RGB2HSV_FULL": 67,
                "COLOR_HSV2BGR_FULL": 70, "COLOR_HSV2RGB_FULL": 71, "COLOR_BGR2YUV": 82, "COLOR_RGB2YUV": 83,
+               "COLOR_BGR2HLS": 52, "COLOR_RGB2HLS": 53, "COLOR_HLS2BGR": 60, "COLOR_HLS2RGB": 61,
+               "COLOR_BGR2HLS_FULL": 68, "COLOR_RGB2HLS_FULL": 69, "COLOR_HLS2BGR_FULL": 72, "COLOR_HLS2RGB_FULL": 73,
                "COLOR_YUV2BGR": 84, "COLOR_YUV2RGB": 85,
                "COLOR_BGR2XYZ": 32, "COLOR_RGB2XYZ": 33, "COLOR_XYZ2BGR": 34, "COLOR_XYZ2RGB": 35,
                # YUV 4:2:0 sources ((3H/2, W, 1) frames) and packed 4:2:2 sources ((H, W, 2) frames) -> RGB / BGR / RGBA / BGRA / gray

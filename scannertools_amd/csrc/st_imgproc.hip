@@ -1012,6 +1012,49 @@ __device__ __forceinline__ void cvt_pixel(const CvtArgsK& a, const int* sdiv, co
     }
     const int bb = rs_sat_float(b * 255.f), gg = rs_sat_float(g * 255.f), rr = rs_sat_float(r * 255.f);
     d[0] = bgr ? bb : rr; d[1] = gg; d[2] = bgr ? rr : bb;
+  } else if (a.code == ST_COLOR_BGR2HLS || a.code == ST_COLOR_RGB2HLS || a.code == ST_COLOR_BGR2HLS_FULL || a.code == ST_COLOR_RGB2HLS_FULL) {
+    // RGB2HLS_b: bytes / 255 -> RGB2HLS_f in float (scalar formulation) -> H = saturate_cast<uchar>(h * hrange / 360), L, S x 255
+    const bool bgr = a.code == ST_COLOR_BGR2HLS || a.code == ST_COLOR_BGR2HLS_FULL;
+    const float hscale = ((a.code == ST_COLOR_BGR2HLS || a.code == ST_COLOR_RGB2HLS) ? 180.f : 256.f) / 360.f;
+    const float b = (float)(bgr ? s[0] : s[2]) * (1.f / 255.f), g = (float)s[1] * (1.f / 255.f), r = (float)(bgr ? s[2] : s[0]) * (1.f / 255.f);
+    float h = 0.f, sat = 0.f;
+    const float vmax = fmaxf(r, fmaxf(g, b)), vmin = fminf(r, fminf(g, b));
+    float diff = vmax - vmin;
+    const float l = (vmax + vmin) * 0.5f;
+    if (diff > 1.1920929e-07f) {   // FLT_EPSILON
+      sat = l < 0.5f ? diff / (vmax + vmin) : diff / (2.f - vmax - vmin);
+      diff = 60.f / diff;
+      if (vmax == r) h = (g - b) * diff;
+      else if (vmax == g) h = (b - r) * diff + 120.f;
+      else h = (r - g) * diff + 240.f;
+      if (h < 0.f) h += 360.f;
+    }
+    d[0] = rs_sat_float(h * hscale); d[1] = rs_sat_float(l * 255.f); d[2] = rs_sat_float(sat * 255.f);
+  } else if (a.code == ST_COLOR_HLS2BGR || a.code == ST_COLOR_HLS2RGB || a.code == ST_COLOR_HLS2BGR_FULL || a.code == ST_COLOR_HLS2RGB_FULL) {
+    // HLS2RGB_b: bytes -> (h, l/255, s/255) -> HLS2RGB_native in float -> saturate_cast<uchar>(x * 255)
+    const bool bgr = a.code == ST_COLOR_HLS2BGR || a.code == ST_COLOR_HLS2BGR_FULL;
+    const float hscale = (a.code == ST_COLOR_HLS2BGR || a.code == ST_COLOR_HLS2RGB) ? 6.f / 180 : 6.f / 255;
+    float hh = (float)s[0];
+    const float l = (float)s[1] * (1.f / 255.f), ss = (float)s[2] * (1.f / 255.f);
+    float b, g, r;
+    if (ss == 0) {
+      b = g = r = l;
+    } else {
+      const float p2 = l <= 0.5f ? l * (1.f + ss) : l + ss - l * ss;
+      const float p1 = 2.f * l - p2;
+      hh *= hscale;
+      while (hh >= 6.f) hh -= 6.f;   // a byte times 6 / hrange is never negative
+      int sector = (int)floorf(hh);
+      hh -= sector;
+      if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+      const float t0 = p2, t1 = p1, t2 = p1 + (p2 - p1) * (1.f - hh), t3 = p1 + (p2 - p1) * hh;
+      // sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> (b, g, r)
+      b = sector == 0 || sector == 1 ? t1 : (sector == 2 ? t3 : (sector == 5 ? t2 : t0));
+      g = sector == 0 ? t3 : (sector == 1 || sector == 2 ? t0 : (sector == 3 ? t2 : t1));
+      r = sector == 0 || sector == 5 ? t0 : (sector == 1 ? t2 : (sector == 4 ? t3 : t1));
+    }
+    const int bb = rs_sat_float(b * 255.f), gg = rs_sat_float(g * 255.f), rr = rs_sat_float(r * 255.f);
+    d[0] = bgr ? bb : rr; d[1] = gg; d[2] = bgr ? rr : bb;
   } else {  // BGR2HSV / RGB2HSV, hue range 180 (256 for _FULL)
     const bool bgr = a.code == ST_COLOR_BGR2HSV || a.code == ST_COLOR_BGR2HSV_FULL;
     const int hr = (a.code == ST_COLOR_BGR2HSV || a.code == ST_COLOR_RGB2HSV) ? 180 : 256;
@@ -1472,6 +1515,8 @@ ST_EXPORT int st_cvt_color_out_channels(int code, int in_channels) {
     case ST_COLOR_BGR2RGB: case ST_COLOR_BGR2HSV: case ST_COLOR_BGR2YCrCb: case ST_COLOR_RGB2YCrCb:
     case ST_COLOR_YCrCb2BGR: case ST_COLOR_YCrCb2RGB: case ST_COLOR_RGB2HSV: case ST_COLOR_HSV2BGR: case ST_COLOR_HSV2RGB:
     case ST_COLOR_BGR2HSV_FULL: case ST_COLOR_RGB2HSV_FULL: case ST_COLOR_HSV2BGR_FULL: case ST_COLOR_HSV2RGB_FULL:
+    case ST_COLOR_BGR2HLS: case ST_COLOR_RGB2HLS: case ST_COLOR_HLS2BGR: case ST_COLOR_HLS2RGB:
+    case ST_COLOR_BGR2HLS_FULL: case ST_COLOR_RGB2HLS_FULL: case ST_COLOR_HLS2BGR_FULL: case ST_COLOR_HLS2RGB_FULL:
     case ST_COLOR_BGR2YUV: case ST_COLOR_RGB2YUV: case ST_COLOR_YUV2BGR: case ST_COLOR_YUV2RGB:
     case ST_COLOR_BGR2XYZ: case ST_COLOR_RGB2XYZ: case ST_COLOR_XYZ2BGR: case ST_COLOR_XYZ2RGB:
       return in_channels == 3 ? 3 : -1;

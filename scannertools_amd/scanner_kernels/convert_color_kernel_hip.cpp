@@ -36,6 +36,10 @@ const std::map<std::string, int> COLOR_CONVERSION_TYPES = {
     {u8"COLOR_HSV2BGR", ST_COLOR_HSV2BGR},   {u8"COLOR_HSV2RGB", ST_COLOR_HSV2RGB},
     {u8"COLOR_BGR2HSV_FULL", ST_COLOR_BGR2HSV_FULL}, {u8"COLOR_RGB2HSV_FULL", ST_COLOR_RGB2HSV_FULL},
     {u8"COLOR_HSV2BGR_FULL", ST_COLOR_HSV2BGR_FULL}, {u8"COLOR_HSV2RGB_FULL", ST_COLOR_HSV2RGB_FULL},
+    {u8"COLOR_BGR2HLS", ST_COLOR_BGR2HLS},   {u8"COLOR_RGB2HLS", ST_COLOR_RGB2HLS},
+    {u8"COLOR_HLS2BGR", ST_COLOR_HLS2BGR},   {u8"COLOR_HLS2RGB", ST_COLOR_HLS2RGB},
+    {u8"COLOR_BGR2HLS_FULL", ST_COLOR_BGR2HLS_FULL}, {u8"COLOR_RGB2HLS_FULL", ST_COLOR_RGB2HLS_FULL},
+    {u8"COLOR_HLS2BGR_FULL", ST_COLOR_HLS2BGR_FULL}, {u8"COLOR_HLS2RGB_FULL", ST_COLOR_HLS2RGB_FULL},
     {u8"COLOR_BGR2YUV", ST_COLOR_BGR2YUV},   {u8"COLOR_RGB2YUV", ST_COLOR_RGB2YUV},
     {u8"COLOR_YUV2BGR", ST_COLOR_YUV2BGR},   {u8"COLOR_YUV2RGB", ST_COLOR_YUV2RGB},
     {u8"COLOR_BGR2XYZ", ST_COLOR_BGR2XYZ},   {u8"COLOR_RGB2XYZ", ST_COLOR_RGB2XYZ},

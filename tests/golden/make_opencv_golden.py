@@ -29,7 +29,8 @@ def main():
     out["gray_bgr2gray"] = cv2.cvtColor(f, cv2.COLOR_BGR2GRAY)
     out["gray_rgb2gray"] = cv2.cvtColor(f, cv2.COLOR_RGB2GRAY)
     for name in ("COLOR_BGR2HSV", "COLOR_RGB2HSV", "COLOR_HSV2BGR", "COLOR_BGR2YCrCb", "COLOR_YCrCb2BGR", "COLOR_BGR2YUV",
-                 "COLOR_YUV2BGR", "COLOR_BGR2XYZ", "COLOR_XYZ2BGR", "COLOR_BGR2HSV_FULL", "COLOR_HSV2BGR_FULL"):
+                 "COLOR_YUV2BGR", "COLOR_BGR2XYZ", "COLOR_XYZ2BGR", "COLOR_BGR2HSV_FULL", "COLOR_HSV2BGR_FULL",
+                 "COLOR_BGR2HLS", "COLOR_HLS2BGR", "COLOR_RGB2HLS_FULL", "COLOR_HLS2RGB_FULL"):
         out["cvt_" + name] = cv2.cvtColor(f, getattr(cv2, name))
     rs = random_frames(1, 1, 97, 131)[0]
     out["resize_in"] = rs

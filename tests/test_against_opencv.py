@@ -33,7 +33,9 @@ def test_histogram_and_color_against_opencv():
     for name in ("COLOR_BGR2RGB", "COLOR_BGR2HSV", "COLOR_BGR2YCrCb", "COLOR_RGB2YCrCb", "COLOR_YCrCb2BGR", "COLOR_YCrCb2RGB",
                  "COLOR_RGB2HSV", "COLOR_HSV2BGR", "COLOR_HSV2RGB", "COLOR_BGR2HSV_FULL", "COLOR_RGB2HSV_FULL",
                  "COLOR_HSV2BGR_FULL", "COLOR_HSV2RGB_FULL", "COLOR_BGR2YUV", "COLOR_RGB2YUV", "COLOR_YUV2BGR", "COLOR_YUV2RGB",
-                 "COLOR_BGR2XYZ", "COLOR_RGB2XYZ", "COLOR_XYZ2BGR", "COLOR_XYZ2RGB"):
+                 "COLOR_BGR2XYZ", "COLOR_RGB2XYZ", "COLOR_XYZ2BGR", "COLOR_XYZ2RGB",
+                 "COLOR_BGR2HLS", "COLOR_RGB2HLS", "COLOR_HLS2BGR", "COLOR_HLS2RGB", "COLOR_BGR2HLS_FULL", "COLOR_RGB2HLS_FULL",
+                 "COLOR_HLS2BGR_FULL", "COLOR_HLS2RGB_FULL"):
         np.testing.assert_array_equal(oracle.cvt_color(f, getattr(oracle, name)), cv2.cvtColor(f, getattr(cv2, name)), err_msg=name)
     # channel layout family (codes 0..3, 5, 9..31): every code on a source of the channel count it takes, the enum
     # value itself checked against cv2's

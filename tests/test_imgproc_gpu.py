@@ -185,7 +185,10 @@ def test_resize_op_target_size_rules():
                                        ("COLOR_BGR2HSV_FULL", 66), ("COLOR_RGB2HSV_FULL", 67), ("COLOR_HSV2BGR_FULL", 70),
                                        ("COLOR_HSV2RGB_FULL", 71), ("COLOR_BGR2YUV", 82), ("COLOR_RGB2YUV", 83),
                                        ("COLOR_YUV2BGR", 84), ("COLOR_YUV2RGB", 85), ("COLOR_BGR2XYZ", 32), ("COLOR_RGB2XYZ", 33),
-                                       ("COLOR_XYZ2BGR", 34), ("COLOR_XYZ2RGB", 35)])
+                                       ("COLOR_XYZ2BGR", 34), ("COLOR_XYZ2RGB", 35),
+                                       ("COLOR_BGR2HLS", 52), ("COLOR_RGB2HLS", 53), ("COLOR_HLS2BGR", 60), ("COLOR_HLS2RGB", 61),
+                                       ("COLOR_BGR2HLS_FULL", 68), ("COLOR_RGB2HLS_FULL", 69), ("COLOR_HLS2BGR_FULL", 72),
+                                       ("COLOR_HLS2RGB_FULL", 73)])
 @pytest.mark.parametrize("h,w", [(1, 1), (6, 10), (37, 53), (480, 640)])
 def test_cvt_color_matches_oracle(hip_ctx, name, code, h, w):
     frames = random_frames(h + w + code, 2, h, w)
@@ -216,9 +219,13 @@ def test_cvt_color_exhaustive_hsv_and_known_answers(hip_ctx):
     v = np.unique(np.concatenate([np.arange(0, 256, 3), [254, 255]])).astype(np.uint8)
     cube = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, len(v), len(v) * len(v), 3))
     for name in ("COLOR_HSV2BGR", "COLOR_HSV2RGB_FULL", "COLOR_RGB2HSV", "COLOR_BGR2HSV_FULL", "COLOR_RGB2YUV", "COLOR_YUV2BGR",
-                 "COLOR_BGR2XYZ", "COLOR_RGB2XYZ", "COLOR_XYZ2BGR", "COLOR_XYZ2RGB"):
+                 "COLOR_BGR2XYZ", "COLOR_RGB2XYZ", "COLOR_XYZ2BGR", "COLOR_XYZ2RGB",
+                 # HLS runs in float both ways (divisions, a data-dependent branch per pixel): the cube must agree bit for bit
+                 "COLOR_BGR2HLS", "COLOR_RGB2HLS_FULL", "COLOR_HLS2BGR", "COLOR_HLS2RGB", "COLOR_HLS2BGR_FULL", "COLOR_HLS2RGB_FULL"):
         got = hip_ctx.cvt_color(torch.from_numpy(cube).cuda(), name).cpu().numpy()
         np.testing.assert_array_equal(got[0], oracle.cvt_color(cube[0], getattr(oracle, name)), err_msg=name)
+    hls = hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2HLS").cpu().numpy()[0, 0]
+    assert hls.tolist() == [[120, 128, 255], [60, 128, 255], [0, 128, 255], [0, 255, 0], [0, 0, 0], [0, 128, 0]]
     xyz = hip_ctx.cvt_color(torch.from_numpy(px).cuda(), "COLOR_BGR2XYZ").cpu().numpy()[0, 0]
     assert xyz[3].tolist() == [242, 255, 255] and xyz[4].tolist() == [0, 0, 0]      # white (Z saturates), black
     with pytest.raises(ValueError):

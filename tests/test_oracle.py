@@ -254,6 +254,34 @@ def test_cvt_color_oracle_known_answers():
         oracle.cvt_color(f, 44)   # COLOR_BGR2Lab: not restated
 
 
+def test_hls_oracle_known_answers():
+    """8-bit HLS: OpenCV's values for the primaries and grays (H in half degrees, L = (max + min) / 2, S = 255 for pure
+    colours), the definition against colorsys within rounding, the four directions / hue ranges consistent with each
+    other, and a round trip within the quantisation of the three bytes."""
+    import colorsys
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128], [0, 255, 255]]], np.uint8)  # B, G, R
+    hls = oracle.cvt_color(px, oracle.COLOR_BGR2HLS)[0]
+    assert hls.tolist() == [[120, 128, 255], [60, 128, 255], [0, 128, 255], [0, 255, 0], [0, 0, 0], [0, 128, 0], [30, 128, 255]]
+    full = oracle.cvt_color(px, oracle.COLOR_BGR2HLS_FULL)[0]
+    assert full[:3].tolist() == [[171, 128, 255], [85, 128, 255], [0, 128, 255]]           # 240, 120, 0 degrees x 256 / 360
+    rng = np.random.default_rng(7)
+    f = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    got = oracle.cvt_color(f, oracle.COLOR_BGR2HLS).reshape(-1, 3).astype(float)
+    for (b, g, r), (hh, ll, ss) in zip(f.reshape(-1, 3)[:300], got[:300]):
+        h, l, s = colorsys.rgb_to_hls(r / 255., g / 255., b / 255.)
+        assert abs(ll - l * 255) <= 0.51 and abs(ss - s * 255) <= 0.51
+        dh = abs(hh - h * 180)
+        assert min(dh, 180 - dh) <= 0.51 or s * 255 < 8 or max(b, g, r) - min(b, g, r) < 8
+    np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_RGB2HLS), oracle.cvt_color(np.ascontiguousarray(f[..., ::-1]), oracle.COLOR_BGR2HLS))
+    np.testing.assert_array_equal(oracle.cvt_color(f, oracle.COLOR_HLS2RGB), oracle.cvt_color(f, oracle.COLOR_HLS2BGR)[..., ::-1])
+    back = oracle.cvt_color(oracle.cvt_color(px, oracle.COLOR_BGR2HLS), oracle.COLOR_HLS2BGR)[0]
+    assert np.abs(back.astype(int) - px[0].astype(int)).max() <= 1
+    # hue bytes beyond the range wrap (h x 6 / 180 >= 6), s = 0 is the gray axis
+    wrap = np.array([[[200, 128, 255], [20, 128, 255], [77, 90, 0]]], np.uint8)
+    out = oracle.cvt_color(wrap, oracle.COLOR_HLS2BGR)[0]
+    assert out[0].tolist() == out[1].tolist() and out[2].tolist() == [90, 90, 90]
+
+
 def test_ycrcb_oracle_known_answers():
     """8-bit YCrCb: OpenCV's values for the primaries, the float definition within rounding, and a
     round trip within one grey level."""
