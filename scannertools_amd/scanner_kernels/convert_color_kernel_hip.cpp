@@ -8,7 +8,8 @@
 // cv::cvtColor / cvc::cvtColor calls are replaced by ONE st_cvt_color_u8_batch() call per execute().
 // Implemented names: COLOR_BGR2RGB, COLOR_RGB2BGR, COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_GRAY2BGR,
 // COLOR_GRAY2RGB, COLOR_BGR/RGB2YCrCb, COLOR_YCrCb2BGR/RGB, COLOR_BGR/RGB2YUV, COLOR_YUV2BGR/RGB,
-// COLOR_BGR/RGB2HSV, COLOR_HSV2BGR/RGB and the four _FULL hue-range variants, and the channel layout family (codes 0..3, 5,
+// COLOR_BGR/RGB2HSV, COLOR_HSV2BGR/RGB and the four _FULL hue-range variants, the same eight names for HLS, XYZ, the YUV 4:2:0 /
+// 4:2:2 sources, and the channel layout family (codes 0..3, 5,
 // 9..31: BGRA / RGBA, BGR565, BGR555, gray from / to them); an unknown name invalidates the stream as in the reference
 // (:231-236), a name of the reference's table that is not implemented here is reported the same way
 // instead of being run on the CPU.  SCANNERTOOLS_GRAY_BITS (15 default, 14) selects the luma table
