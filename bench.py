@@ -221,8 +221,9 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         gbs = (3 * h * w + 3 * bins * 4) * nb * reps / (ms * 1e-3) / 1e9
         small["batch_%d" % nb] = {"frames_per_s": nb * reps / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
                                   "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / max(n, 1)}
-        # A HIP-event pair around a 35-70 us kernel reads 5-6 us more than the kernel runs (the brackets' own packets on the
-        # stream); the kernel-trace duration of the same launch is committed under profiles/ and quoted here while
+        # The Histogram launch carries its timing events itself (hipExtLaunchKernelGGL: timestamps of the dispatch's own
+        # completion signal); marker events before and after a 35-70 us kernel read 5-6 us more than it runs.  The
+        # kernel-trace duration of the same launch is committed under profiles/ and quoted beside the live figure while
         # st_hist.hip is the file it was measured on.
         try:
             import hashlib
@@ -236,8 +237,9 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                                                           "source": tr.get("source")}
         except Exception:
             pass
-    small["what"] = ("frac / avg_launch_ms: HIP-event brackets around each launch, measured live; kernel_trace: the same launch's "
-                     "duration in the committed rocprofv3 kernel trace (the brackets add 5-6 us)")
+    small["what"] = ("frac / avg_launch_ms: HIP events attached to each dispatch (hipExtLaunchKernelGGL), measured live; kernel_trace: "
+                     "the same launch's duration in the committed rocprofv3 kernel trace (marker events around the launch, as "
+                     "rounds 1-3 measured it, read 5-6 us more)")
     out["histogram_small_batches"] = small
 
     # (iv) OpticalFlow at the batch sizes a drop-in graph uses: the reference creates the op with no batch= (one pair per

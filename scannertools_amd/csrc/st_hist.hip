@@ -15,6 +15,8 @@
 // layout: scripts/ubench/ldsatomic.hip.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "st_internal.h"
 
 namespace {
@@ -502,19 +504,21 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     if (s.ptrs) s.ptrs += f0; else s.base += (size_t)f0 * s.stride;
     int32_t* o = out_dev + (size_t)f0 * 3 * bins;
     const dim3 grid((unsigned)chunks, (unsigned)nf);
-    st_timed t(ctx, ST_K_HIST);
+    // timing events travel with the dispatch itself (st_time_dispatch): the figure is the kernel's own duration
+    hipEvent_t e0, e1;
+    ST_TRY(st_time_dispatch(ctx, ST_K_HIST, &e0, &e1));
     if (variant == 32 && bins == 16 && use16)
-      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32 && use_p2)
-      hipLaunchKernelGGL((k_hist_u8c3_p2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL((k_hist_u8c3_p2<32, 1024>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32 && half_steps)
-      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024, 0, true>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024, 0, true>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     else if (variant == 32)
-      hipLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     else if (variant == 8)
-      hipLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     else
-      hipLaunchKernelGGL(k_hist_u8c3, grid, dim3(kThreads), 0, ctx->stream, s, nbytes, (int)chunks, bins, o);
+      hipExtLaunchKernelGGL(k_hist_u8c3, grid, dim3(kThreads), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     ST_HIP(ctx, hipGetLastError());
   }
   return ST_OK;

@@ -75,6 +75,7 @@ inline size_t st_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a
 // Timing brackets for kernel class `id` (no-ops unless enabled in timing_mask).
 int st_time_begin(st_ctx* ctx, int id);
 int st_time_end(st_ctx* ctx, int id);
+int st_time_dispatch(st_ctx* ctx, int id, hipEvent_t* start, hipEvent_t* stop);   // events for hipExtLaunchKernelGGL (st_context.hip)
 
 // A bracket is closed only if it was opened: when st_time_begin fails (event creation / record) the
 // launch simply goes untimed; the failure stays in last_error and the slot's counters are untouched.
