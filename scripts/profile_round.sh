@@ -45,5 +45,5 @@ rm -rf $out/ltrace
 # the Histogram kernel at Scanner-sized launches: kernel-trace durations beside the HIP-event figures
 # (afterwards, in the build container: python scripts/hist_trace_json.py $tag -> profiles/hist_small_trace.json)
 bash scripts/trace_hist.sh $tag 32 64 256 > /dev/null 2>&1
-{ for n in 32 64 256; do echo "== $n frames of 1080p per launch (scripts/trace_hist.sh: rocprofv3 --kernel-trace of scripts/bench_hist.py; 3 kinds of frames x 21 launches per instance) =="; grep k_hist gpurun_out/th_${tag}_$n.txt; echo "-- the same launches by the HIP-event brackets (st_ctx_timing):"; grep bins gpurun_out/th_${tag}_$n.log; done; } > $out/summary/hist_small_trace.txt
+{ for n in 32 64 256; do echo "== $n frames of 1080p per launch (scripts/trace_hist.sh: rocprofv3 --kernel-trace of scripts/bench_hist.py; 3 kinds of frames x 21 launches per instance) =="; grep k_hist gpurun_out/th_${tag}_$n.txt; echo "-- the library's own timing of the same launches WHILE TRACED (events on the dispatch; the tracer's interception adds ~5 us -- untraced they read the trace's figure, bench.py histogram_small_batches):"; grep bins gpurun_out/th_${tag}_$n.log; done; } > $out/summary/hist_small_trace.txt
 cat $out/bench.json
