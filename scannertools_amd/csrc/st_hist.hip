@@ -14,6 +14,7 @@
 // Measured at 256 1080p frames per launch: 5.7 TB/s (scripts/bench_hist.py); LDS-atomic rates per
 // layout: scripts/ubench/ldsatomic.hip.
 #include <cstdlib>
+#include <string>
 
 #include <hip/hip_ext.h>
 
@@ -154,9 +155,23 @@ __device__ __forceinline__ void count16c(unsigned* h, uint4 q, unsigned c0, unsi
   lds_inc(h + c0 + (q.w >> (24 + SHIFT)) * C);
 }
 
+// How a workgroup's counters reach the output row of its frame:
+//   HC_ATOMIC  one global atomic per non-empty bin into a row the launcher zeroed (a memset launch ahead of the kernel);
+//   HC_DIRECT  the frame has ONE workgroup (chunks == 1, launches of >= one frame per CU): plain stores, no memset.
+// (Round 4 also built a third way for the chunked case -- partial rows in the workspace, a ticket per frame, the workgroup that
+// draws the last ticket sums the rows and stores: no memset, no atomics on the output.  Measured at 32 frames per launch:
+// with device-scope fences around the ticket 131 us instead of 36 (each fence writes back and invalidates its XCD's whole L2);
+// with fence-free device-scope atomic accesses to the rows 37.8 us of kernel instead of 35.6 and 38-41 us per call instead of
+// 37 -- the store acknowledgements and the ticket's round trip at the end of every workgroup cost more than the memset launch
+// they replace; the 16-bin instance with its 128 chunks per frame 90 us.  Removed.)
+enum { HC_ATOMIC = 0, HC_DIRECT = 1 };
+struct HistCommit {
+  int mode;
+};
+
 template <int C, int T, int SHIFT = 0, bool HALF = false>
 __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbytes, int chunks, int bins,
-                                                           int32_t* __restrict__ out) {
+                                                           int32_t* __restrict__ out, HistCommit hc) {
   static_assert(T % 3 == 1, "the channel phase of a thread's vectors must advance by one per step");
   constexpr int NB = 256 >> SHIFT;   // counters per channel
   __shared__ unsigned sh[3 * NB * C];
@@ -274,11 +289,13 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
   }
   __syncthreads();
   int32_t* o = out + (size_t)frame * 3 * bins;
+  const bool plain = hc.mode != HC_ATOMIC;
   if (SHIFT) {
     // the counters ARE the output bins (bins == NB, checked by the launcher)
     for (int ob = tid; ob < 3 * NB; ob += T) {
       const unsigned v = sh[ob * C];
-      if (v) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, v);
+      if (plain) o[ob] = (int32_t)v;
+      else if (v) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, v);
     }
     return;
   }
@@ -287,7 +304,8 @@ __global__ __launch_bounds__(T) void k_hist_u8c3_v2(FrameSrc src, long long nbyt
     const int lo = (256 * bin + bins - 1) / bins, hi = (256 * (bin + 1) + bins - 1) / bins;
     unsigned s = 0;
     for (int v = lo; v < hi; ++v) s += sh[(ch * 256 + v) * C];
-    if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, s);
+    if (plain) o[ob] = (int32_t)s;
+    else if (s) atomicAdd(reinterpret_cast<unsigned*>(o) + ob, s);
   }
 }
 
@@ -452,7 +470,15 @@ long long chunks_for(int num_cus, int n, long long nvec, int threads) {
   return best;
 }
 
-int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev) {
+// What one call launches
+struct HistPlan {
+  int kernel;        // 16: the 16-bin instance, 32: 32 copies / 1024 threads, 2: packed two-per-CU, 8: eight copies / 256 threads, 0: one copy per wave
+  bool half_steps;
+  long long chunks;
+  int mode;          // HC_*
+};
+
+HistPlan hist_plan(st_ctx* ctx, int n, int h, int w, int bins) {
   const long long nbytes = 3LL * h * w;
   const long long nvec = nbytes / 16;
   // ST_HIST_VARIANT selects the older kernels for A/B runs: 8 = eight copies per 256-thread
@@ -471,32 +497,49 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
   // (16 steps), -1..4 % at 256 on noise (each load then has half a step to land).  Used for launches of at most 10 steps per
   // workgroup; ST_HIST_HALF=0 / 1 forces it off / on.
   static const int half_env = getenv("ST_HIST_HALF") ? atoi(getenv("ST_HIST_HALF")) : -1;
-  long long chunks;
+  // ST_HIST_COMMIT=atomic: memset + global atomics also where a frame has one workgroup (A/B)
+  static const bool atomic_commit = getenv("ST_HIST_COMMIT") && std::string(getenv("ST_HIST_COMMIT")) == "atomic";
+  HistPlan p;
+  p.half_steps = false;
+  p.mode = HC_ATOMIC;
+  const int nl = n < 65535 ? n : 65535;   // frames per launch (grid.y)
   if (variant == 32 && bins == 16 && use16) {
-    chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
+    p.kernel = 16;
+    p.chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
     long long max_chunks = (nvec + 3 * 256 * 4 - 1) / (3 * 256 * 4);
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
+    if (p.chunks > max_chunks) p.chunks = max_chunks;
+    if (p.chunks < 1) p.chunks = 1;
   } else if (variant == 32 && use_p2) {
     // two workgroups per CU: 2 * CUs slots; a chunk's half-counters must not overflow
-    chunks = chunks_for(2 * ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
+    p.kernel = 2;
+    p.chunks = chunks_for(2 * ctx->num_cus, nl, nvec, 1024);
     const long long need = (nvec + kP2MaxVec - 6 * 1024 - 1) / (kP2MaxVec - 6 * 1024);   // `per` is rounded up to 6 T vectors
-    if (chunks < need) chunks = need;
+    if (p.chunks < need) p.chunks = need;
     static const int force_chunks = getenv("ST_HIST_CHUNKS") ? atoi(getenv("ST_HIST_CHUNKS")) : 0;  // experiments
-    if (force_chunks > need) chunks = force_chunks;
+    if (force_chunks > need) p.chunks = force_chunks;
   } else if (variant == 32) {
-    chunks = chunks_for(ctx->num_cus, n < 65535 ? n : 65535, nvec, 1024);
+    p.kernel = 32;
+    p.chunks = chunks_for(ctx->num_cus, nl, nvec, 1024);
     static const int force_chunks = getenv("ST_HIST_CHUNKS") ? atoi(getenv("ST_HIST_CHUNKS")) : 0;  // experiments
-    if (force_chunks > 0) chunks = force_chunks;
+    if (force_chunks > 0) p.chunks = force_chunks;
+    const long long steps_per_wg = ((nvec + p.chunks - 1) / p.chunks + 6 * 1024 - 1) / (6 * 1024);
+    p.half_steps = half_env == 1 || (half_env != 0 && steps_per_wg <= 10);
   } else {
-    chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
+    p.kernel = variant == 8 ? 8 : 0;
+    p.chunks = ((long long)ctx->num_cus * 16 + n - 1) / n;
     long long max_chunks = (nvec + 3 * kThreads * 4 - 1) / (3 * kThreads * 4);  // >= 12 vectors per thread
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
+    if (p.chunks > max_chunks) p.chunks = max_chunks;
+    if (p.chunks < 1) p.chunks = 1;
   }
-  const long long steps_per_wg = ((nvec + chunks - 1) / chunks + 6 * 1024 - 1) / (6 * 1024);
-  const bool half_steps = half_env == 1 || (half_env != 0 && steps_per_wg <= 10);
-  ST_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * 3 * (size_t)bins * n, ctx->stream));
+  if ((p.kernel == 16 || p.kernel == 32) && !atomic_commit && p.chunks == 1) p.mode = HC_DIRECT;
+  return p;
+}
+
+int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_t* out_dev, const HistPlan& plan) {
+  const long long nbytes = 3LL * h * w;
+  const long long chunks = plan.chunks;
+  const HistCommit hc{plan.mode};
+  if (plan.mode == HC_ATOMIC) ST_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * 3 * (size_t)bins * n, ctx->stream));
   // grid.y is limited to 65535 frames per launch
   for (int f0 = 0; f0 < n; f0 += 65535) {
     int nf = n - f0 < 65535 ? n - f0 : 65535;
@@ -507,16 +550,16 @@ int hist_launch(st_ctx* ctx, FrameSrc src, int n, int h, int w, int bins, int32_
     // timing events travel with the dispatch itself (st_time_dispatch): the figure is the kernel's own duration
     hipEvent_t e0, e1;
     ST_TRY(st_time_dispatch(ctx, ST_K_HIST, &e0, &e1));
-    if (variant == 32 && bins == 16 && use16)
-      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
-    else if (variant == 32 && use_p2)
+    if (plan.kernel == 16)
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 256, 4>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o, hc);
+    else if (plan.kernel == 2)
       hipExtLaunchKernelGGL((k_hist_u8c3_p2<32, 1024>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
-    else if (variant == 32 && half_steps)
-      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024, 0, true>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
-    else if (variant == 32)
-      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
-    else if (variant == 8)
-      hipExtLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
+    else if (plan.kernel == 32 && plan.half_steps)
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024, 0, true>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o, hc);
+    else if (plan.kernel == 32)
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<32, 1024>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o, hc);
+    else if (plan.kernel == 8)
+      hipExtLaunchKernelGGL((k_hist_u8c3_v2<8, 256>), grid, dim3(256), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o, hc);
     else
       hipExtLaunchKernelGGL(k_hist_u8c3, grid, dim3(kThreads), 0, ctx->stream, e0, e1, 0, s, nbytes, (int)chunks, bins, o);
     ST_HIP(ctx, hipGetLastError());
@@ -666,11 +709,12 @@ ST_EXPORT int st_hist_u8c3_batch(st_ctx* ctx, const uint8_t* const* frames_dev, 
   if (!frames_dev) return st_set_error(ctx, ST_ERR_INVALID, "histogram: null frame table");
   for (int i = 0; i < n; ++i)
     if (!frames_dev[i]) return st_set_error(ctx, ST_ERR_INVALID, "histogram: frame %d is null", i);
+  const HistPlan plan = hist_plan(ctx, n, h, w, bins);
   ST_TRY(st_ws_reserve(ctx, st_align_up(sizeof(void*) * (size_t)n)));
   const uint8_t** table = (const uint8_t**)st_ws_alloc(ctx, sizeof(void*) * (size_t)n);
   ST_HIP(ctx, hipMemcpyAsync(table, frames_dev, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   FrameSrc src{table, nullptr, 0};
-  return hist_launch(ctx, src, n, h, w, bins, out_dev);
+  return hist_launch(ctx, src, n, h, w, bins, out_dev, plan);
 }
 
 ST_EXPORT int st_hist_u8c3_strided(st_ctx* ctx, const uint8_t* base_dev, size_t frame_stride_bytes, int n, int h,
@@ -681,5 +725,6 @@ ST_EXPORT int st_hist_u8c3_strided(st_ctx* ctx, const uint8_t* base_dev, size_t 
   if (!base_dev || frame_stride_bytes < (size_t)3 * h * w)
     return st_set_error(ctx, ST_ERR_INVALID, "histogram: bad base/stride");
   FrameSrc src{nullptr, base_dev, frame_stride_bytes};
-  return hist_launch(ctx, src, n, h, w, bins, out_dev);
+  const HistPlan plan = hist_plan(ctx, n, h, w, bins);
+  return hist_launch(ctx, src, n, h, w, bins, out_dev, plan);
 }

@@ -147,7 +147,7 @@ print("variant ok")
 """
 
 
-@pytest.mark.parametrize("env", [{"ST_HIST_P2": "1"}, {"ST_HIST_VARIANT": "8"}, {"ST_HIST_VARIANT": "0"}, {"ST_HIST16": "0"}, {"ST_HIST_HALF": "1"}, {"ST_HIST_HALF": "0"}])
+@pytest.mark.parametrize("env", [{"ST_HIST_P2": "1"}, {"ST_HIST_VARIANT": "8"}, {"ST_HIST_VARIANT": "0"}, {"ST_HIST16": "0"}, {"ST_HIST_HALF": "1"}, {"ST_HIST_HALF": "0"}, {"ST_HIST_COMMIT": "atomic"}])
 def test_hist_alternative_kernels(env):
     """The opt-in kernels (the switch is read once per process, so each runs in its own): the packed two-per-CU instance
     (ST_HIST_P2=1), eight copies per 256 threads, one copy per wave, and the general kernel at 16 bins -- against
