@@ -20,20 +20,25 @@ NET_MATH = MATH[:2]   # PoseNet(math=...)
 _PERTAP = {}
 
 
-def _pertap_ctx():
-    """A context created under ST_CONV_TILE=0 (the switch is read at st_ctx_create)."""
-    if "ctx" not in _PERTAP:
+def _mode_ctx(value):
+    """A context created under ST_CONV_TILE=value (read at st_ctx_create): "0" the per-tap kernels for every layer, "1" the
+    spatial-tile kernels wherever a tile shape exists (left to itself the library picks by launch size -- the same bits)."""
+    if value not in _PERTAP:
         from scannertools_amd.hip import HipContext
         saved = os.environ.get("ST_CONV_TILE")
-        os.environ["ST_CONV_TILE"] = "0"
+        os.environ["ST_CONV_TILE"] = value
         try:
-            _PERTAP["ctx"] = HipContext(0)
+            _PERTAP[value] = HipContext(0)
         finally:
             if saved is None:
                 del os.environ["ST_CONV_TILE"]
             else:
                 os.environ["ST_CONV_TILE"] = saved
-    return _PERTAP["ctx"]
+    return _PERTAP[value]
+
+
+def _pertap_ctx():
+    return _mode_ctx("0")
 
 
 def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math="f32"):
@@ -52,6 +57,8 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
     y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
     if math.endswith("_pertap"):
         hip_ctx, math = _pertap_ctx(), math[:-7]
+    else:
+        hip_ctx = _mode_ctx("1")   # the tile kernels whatever the launch size
     hip_ctx._bind()
     if math == "bf16x3":
         w3 = torch.empty((hip_ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, cip),), dtype=torch.uint8, device="cuda")
@@ -129,7 +136,8 @@ def test_conv_channel_slices_and_identity_known_answer(hip_ctx, math):
 def test_conv_tile_random_shapes(hip_ctx, math):
     """Seeded random map sizes, channel counts and batch sizes for the spatial-tile kernels (3x3 / 7x7, 128-channel output blocks):
     every tile shape the planner picks -- tiles cut by the right and bottom borders, several tile columns, maps smaller than a
-    tile, inputs read from a channel slice -- against float64 and against the per-tap kernel of the same arithmetic."""
+    tile, inputs read from a channel slice -- against float64, and bit for bit against the per-tap kernel of the same
+    arithmetic (both accumulate slices outer, taps inner, so the launcher may pick either by launch size)."""
     rng = np.random.default_rng(20260 + len(math))
     for case in range(24):
         k = (3, 7)[case % 2]
@@ -150,7 +158,7 @@ def test_conv_tile_random_shapes(hip_ctx, math):
         scale = max(float(ref.abs().max()), 1.0)
         msg = (case, n, h, w, ci, co, k)
         assert float((got - ref).abs().max()) <= 2e-5 * scale, msg
-        assert float((y - yp).abs().max()) <= 4e-5 * scale, msg
+        assert torch.equal(y, yp), msg    # the per-tap kernels accumulate in the tile kernels' order: the same bits
         assert (y[..., :4] == -7.0).all() and (y[..., 4 + co:] == -7.0).all(), msg
 
 
@@ -184,6 +192,24 @@ def test_pose_network_end_to_end(hip_ctx, math):
     assert scale > 1e-3
     assert float((got - ref).abs().max()) <= 1e-3 * scale, (float((got - ref).abs().max()), scale)
     assert pose_net.flops(368, 656) > 4e11 and len(pose_net.all_layers()) == 92
+
+
+@pytest.mark.parametrize("math", NET_MATH)
+def test_network_bits_do_not_depend_on_the_kernel_choice(hip_ctx, math):
+    """The library picks the per-tap or the spatial-tile kernel per layer by launch size; both accumulate in the same order,
+    so a frame's maps are the same bits whichever runs -- alone, in a batch of 6, with the tile kernels forced, with the
+    per-tap kernels forced."""
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand((6, 3, 96, 128), generator=g) - 0.5
+    outs = {}
+    for name, ctx in (("auto", hip_ctx), ("tile", _mode_ctx("1")), ("pertap", _mode_ctx("0"))):
+        net = pose_net.PoseNet(ctx, seed=8, math=math)
+        outs[name] = net.forward(x.cuda()).cpu()
+        if name == "auto":
+            outs["single"] = net.forward(x[2:3].cuda()).cpu()
+        del net
+    assert torch.equal(outs["auto"], outs["tile"]) and torch.equal(outs["auto"], outs["pertap"])
+    assert torch.equal(outs["single"][0], outs["auto"][2])
 
 
 def test_whole_pose_pipeline_through_the_engine(hip_ctx):
