@@ -320,9 +320,10 @@ int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int
 /* The same convolution with the weights ALSO in the spatial-tile kernel's operand order (wt_dev: st_conv_f32_tile_bytes(...)
  * bytes filled once by st_conv_pack_weights_f32_tile from the same float32 tensor; the size is 0 and wt_dev may be null for
  * layers the tile kernel does not take -- anything but 3x3 / 7x7 with cout_pad a multiple of 128).  The library picks the
- * kernel per call (tile shape by map size; ST_CONV_TILE=0 at st_ctx_create keeps the per-tap kernel), so every caller computes
- * the same bits: a k-ordered float32 fmaf chain per output in both kernels -- slices outer / taps inner in the tile kernel,
- * taps outer in the per-tap kernel, hence not bit-identical to each other.  st_conv2d_nhwc_f32 = this with wt_dev null. */
+ * kernel per call (tile shape by map size, tile or per-tap kernel by launch size; ST_CONV_TILE=0 / 1 at st_ctx_create forces
+ * the per-tap / the tile kernel).  Both accumulate every output as the same k-ordered float32 fmaf chain (16-channel slices
+ * outer, taps inner, channels ascending), so the choice -- and with it the batch size -- never changes a bit.
+ * st_conv2d_nhwc_f32 = this with wt_dev null. */
 long long st_conv_f32_tile_bytes(int cout_pad, int kh, int kw, int cin);
 int st_conv_pack_weights_f32_tile(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
 int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
@@ -336,7 +337,7 @@ int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int 
  * rearranged ONCE by st_conv_pack_weights_bf16x3 from the [cout_pad][kh][kw][cin] float32 tensor into a 16-byte
  * aligned buffer of st_conv_bf16x3_packed_bytes(...) bytes (6 bytes per weight; twice that for 3x3 / 7x7 layers with
  * cout_pad a multiple of 128, which also get the operand-order copy the spatial-tile kernel reads -- the library picks
- * the kernel per call, so every caller computes the same bits). */
+ * the kernel per call; both kernels add the same products in the same order, so the result does not depend on the choice). */
 long long st_conv_bf16x3_packed_bytes(int cout_pad, int kh, int kw, int cin);
 int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
 int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,

@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_bf16x3(ConvArgs a, const u
 //   * inside a tap every matrix instruction is followed by one pinned piece of the side work (see the main loop).
 // L1 fills per executed flop fall 3.3-fold (12 KB of weights per tap and slice for a 256 x 128 tile, the region's 0.4-2 KB
 // amortised over the taps).  Accumulation order of an output: slices outer, taps inner, the six terms as in
-// k_conv_nhwc_bf16x3 -- independent of the tile shape, so the tiling never changes a bit; against the per-tap kernel
-// (taps outer, slices inner) the same products are added in another order: same accuracy, other roundings.
+// k_conv_nhwc_bf16x3 -- independent of the tile shape, so the tiling never changes a bit, and the order the per-tap kernel
+// walks K in too: the two kernels give the same bits and the launcher may pick either.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CT_RPMAX = 800;   // region pixels per LDS buffer
 constexpr int CT_ITEMS = (CT_RPMAX * 4 + 511) / 512;   // (pixel, channel quad) items per thread and slice
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512) void k_conv_tile_bf16x3(ConvTileArgs a) {
 // eight pixels over 32 banks).  Weights in operand order: [cout block][slice][tap][32-column tile][4-step group][lane] x 4 floats
 // (st_conv_pack_weights_f32_tile), four 16-byte loads per wave and tap, one tap ahead (a tap is 32 instructions of 64 cycles).
 // Accumulation order of an output: slices outer, taps inner, channels ascending inside a slice -- a k-ordered fmaf chain as
-// in k_conv_nhwc_f32 (taps outer there), independent of the tile shape.
+// in k_conv_nhwc_f32 (the same walk there: same bits), independent of the tile shape.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CTF_RPS = 818;
 
