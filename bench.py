@@ -458,6 +458,11 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                             "frame with the maximum of candidate joints and people, the worst case for the host-side assembly" % (nb5, 2 * nb5),
                     "frames_per_s": sc5c.steady_rows / sc5c.steady_seconds, "first_call_frames_per_s": nb5 / (sc5c.execute_seconds - sc5c.steady_seconds),
                     "people_in_first_frame": len(list(o5.load())[0])}
+                # the reference's own calling pattern: batch=5 (scannertools_caffe/tests/test_all.py:20)
+                node5b = sc5c.ops.OpenPose(frame=sc5c.io.Input([NamedVideoStream(sc5c, "v5")]), model_directory=mdir, device=DeviceType.GPU, batch=5)
+                sc5c.execute_seconds, sc5c.steady_seconds, sc5c.steady_rows = 0.0, 0.0, 0
+                sc5c.run(sc5c.io.Output(node5b, [NamedStream(sc5c, "pose5b")]), PerfParams.estimate(), cache_mode=CacheMode.Overwrite)
+                out["config5_pose_conv_stack"]["openpose_op"]["batch_5_frames_per_s"] = sc5c.steady_rows / sc5c.steady_seconds
                 shutil.rmtree(mdir, ignore_errors=True)
             except Exception as e:  # auxiliary record
                 out["config5_pose_conv_stack"]["openpose_op"] = {"error": repr(e)}
