@@ -467,10 +467,13 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x3_tile(const float* _
   }
 }
 
-template <int KS>
-__global__ __launch_bounds__(512) void k_conv_tile_bf16x3(ConvTileArgs a) {
-  constexpr int T = KS * KS;
-  __shared__ unsigned Ar[2][3][CT_RPMAX * 8];
+// NW: waves per workgroup -- 8 (256 pixels, region <= 800 pixels, one workgroup per CU) or 4 (128 pixels, region <= 400, two
+// per CU: twice the workgroups for launches that would leave CUs idle; the same bits, the accumulation order does not depend on
+// the tile)
+template <int KS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a) {
+  constexpr int T = KS * KS, THREADS = NW * 64;
+  __shared__ unsigned Ar[2][3][(NW == 8 ? CT_RPMAX : CT_RPMAX / 2) * 8];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, lk = lane >> 5;
   int bt = blockIdx.x;
   const int txi = bt % a.tiles_x;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(512) void k_conv_tile_bf16x3(ConvTileArgs a) {
   unsigned exists = 0, inb = 0;
 #pragma unroll
   for (int i = 0; i < CT_ITEMS; ++i) {
-    const int e = i * 512 + t, r = e >> 2, cq = e & 3;
+    const int e = i * THREADS + t, r = e >> 2, cq = e & 3;
     goff[i] = 0;
     loff[i] = 0;
     if (r < a.rp) {
@@ -662,14 +665,13 @@ __global__ __launch_bounds__(512) void k_conv_tile_bf16x3(ConvTileArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // The spatial tile for the float32 instruction (v_mfma_f32_32x32x2_f32): same workgroup shape, region, weight streaming and
 // pinned side work as k_conv_tile_bf16x3; what differs is the operand layout.  LDS: the region channel-major,
-// [buffer][16 channels][CTF_RPS] floats (a lane's A operand of step kk is ONE float, channel 2 kk + (lane >> 5) of its pixel:
+// [buffer][16 channels][818 (418 for the 4-wave instance)] floats (a lane's A operand of step kk is ONE float, channel 2 kk + (lane >> 5) of its pixel:
 // 32 consecutive lanes read 32 consecutive floats; the plane stride 818 = 2 mod 16 spreads an item's four channel stores of
 // eight pixels over 32 banks).  Weights in operand order: [cout block][slice][tap][32-column tile][4-step group][lane] x 4 floats
 // (st_conv_pack_weights_f32_tile), four 16-byte loads per wave and tap, one tap ahead (a tap is 32 instructions of 64 cycles).
 // Accumulation order of an output: slices outer, taps inner, channels ascending inside a slice -- a k-ordered fmaf chain as
 // in k_conv_nhwc_f32 (the same walk there: same bits), independent of the tile shape.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CTF_RPS = 818;
 
 __global__ __launch_bounds__(256) void k_pack_weights_f32_tile(const float* __restrict__ w, int cout_pad, int taps, int cin,
                                                                float* __restrict__ out) {
@@ -686,9 +688,9 @@ __global__ __launch_bounds__(256) void k_pack_weights_f32_tile(const float* __re
   }
 }
 
-template <int KS>
-__global__ __launch_bounds__(512) void k_conv_tile_f32(ConvTileArgs a) {
-  constexpr int T = KS * KS;
+template <int KS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
+  constexpr int T = KS * KS, THREADS = NW * 64, CTF_RPS = NW == 8 ? 818 : 418;   // plane strides = 2 mod 16
   __shared__ float Af[2][16][CTF_RPS];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, lk = lane >> 5;
   int bt = blockIdx.x;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(512) void k_conv_tile_f32(ConvTileArgs a) {
   unsigned exists = 0, inb = 0;
 #pragma unroll
   for (int i = 0; i < CT_ITEMS; ++i) {
-    const int e = i * 512 + t, r = e >> 2, cq = e & 3;
+    const int e = i * THREADS + t, r = e >> 2, cq = e & 3;
     goff[i] = 0;
     loff[i] = 0;
     if (r < a.rp) {
@@ -851,20 +853,20 @@ __global__ __launch_bounds__(512) void k_conv_tile_f32(ConvTileArgs a) {
     }
 }
 
-// the tile shape for an h x w map and a K x K kernel: the (TH, TW) with the fewest 256-pixel instruction blocks per image
-// whose region fits the LDS buffer; false when even the best wastes more than a quarter of the matrix work
-bool conv_tile_plan(int h, int w, int ks, int* th, int* tw, double* eff) {
+// the tile shape for an h x w map and a K x K kernel: the (TH, TW) with the fewest maxpx-pixel instruction blocks per image
+// whose region fits the LDS buffer (rpmax pixels); false when even the best wastes more than a quarter of the matrix work
+bool conv_tile_plan(int h, int w, int ks, int maxpx, int rpmax, int* th, int* tw, double* eff) {
   double best = 0;
   for (int nx = 1; nx <= w; ++nx) {
     const int cw = (w + nx - 1) / nx;
-    if (cw > 256) continue;
+    if (cw > maxpx) continue;
     if (cw < 8 && nx > 1) break;
-    int ch = 256 / cw;
+    int ch = maxpx / cw;
     if (ch > h) ch = h;
-    while (ch > 1 && (ch + ks - 1) * (cw + ks - 1) > CT_RPMAX) --ch;
-    if ((ch + ks - 1) * (cw + ks - 1) > CT_RPMAX) continue;
+    while (ch > 1 && (ch + ks - 1) * (cw + ks - 1) > rpmax) --ch;
+    if ((ch + ks - 1) * (cw + ks - 1) > rpmax) continue;
     const long long tiles = (long long)nx * ((h + ch - 1) / ch);
-    const double e = (double)h * w / (256.0 * (double)tiles);
+    const double e = (double)h * w / ((double)maxpx * (double)tiles);
     if (e > best + 1e-9) { best = e; *th = ch; *tw = cw; }
   }
   *eff = best;
@@ -872,6 +874,33 @@ bool conv_tile_plan(int h, int w, int ks, int* th, int* tw, double* eff) {
 }
 
 bool conv_tile_weights(int kh, int kw, int cout_pad, int cin) { return kh == kw && (kh == 3 || kh == 7) && cout_pad % 128 == 0 && cin % 16 == 0; }
+
+// Which kernel a 3x3 / 7x7 layer with whole 128-channel output blocks runs on: 8 = the 8-wave tile kernel (256-pixel tiles, one
+// workgroup per CU) when its launch fills three quarters of the chip, else 4 = the 4-wave instance (128-pixel tiles, two per
+// CU: twice the workgroups -- 46x82, 7x7, 128 -> 128, 5 frames: bf16x3 0.20 against 0.36 ms (per-tap kernel 0.44), float32
+// 0.42 against 0.77 (0.62); from 16 frames on the two are equal), 0 = the per-tap kernel (no tile shape fits).  Fills the
+// geometry of `ta`.  Every choice accumulates an output in the same order, so none changes a bit; ST_CONV_TILE=0 forces the
+// per-tap kernel, 1 the 8-wave tile kernel wherever a tile shape exists, 4 the 4-wave one.
+int conv_tile_choose(st_ctx* ctx, int n, int h, int w, int kh, int kw, int cout_pad, int cin, ConvTileArgs* ta) {
+  if (ctx->conv_tile == 0 || !conv_tile_weights(kh, kw, cout_pad, cin)) return 0;
+  int th8 = 0, tw8 = 0, th4 = 0, tw4 = 0;
+  double e8 = 0, e4 = 0;
+  const bool ok8 = conv_tile_plan(h, w, kh, 256, CT_RPMAX, &th8, &tw8, &e8);
+  const bool ok4 = conv_tile_plan(h, w, kh, 128, CT_RPMAX / 2, &th4, &tw4, &e4);
+  auto wgs = [&](int th, int tw) { return (long long)n * ((w + tw - 1) / tw) * ((h + th - 1) / th) * (cout_pad / 128); };
+  int nw = 0;
+  if (ctx->conv_tile == 1) nw = ok8 ? 8 : (ok4 ? 4 : 0);
+  else if (ctx->conv_tile == 4) nw = ok4 ? 4 : (ok8 ? 8 : 0);
+  else if (ok8 && wgs(th8, tw8) >= (long long)ctx->num_cus * 3 / 4) nw = 8;
+  else if (ok4) nw = 4;
+  else if (ok8) nw = 8;
+  if (!nw) return 0;
+  const int th = nw == 8 ? th8 : th4, tw = nw == 8 ? tw8 : tw4;
+  ta->n = n; ta->h = h; ta->wd = w; ta->cin = cin; ta->pad = kh / 2;
+  ta->th = th; ta->tw = tw; ta->rw = tw + kh - 1; ta->rp = (th + kh - 1) * (tw + kh - 1);
+  ta->tiles_x = (w + tw - 1) / tw; ta->tiles_y = (h + th - 1) / th;
+  return nw;
+}
 
 struct PoolArgs {
   const float* x;
@@ -950,30 +979,21 @@ ST_EXPORT int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, i
   a.m = (long long)n * h * w;
   const long long bm = (a.m + CV_BM - 1) / CV_BM;
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-  int th = 0, tw = 0;
-  double eff = 0;
-  // The tile kernel runs one 512-thread workgroup per CU: a launch that fills less than three quarters of the chip is faster on
-  // the per-tap kernel's 128-pixel blocks (46x82, 7x7, 128 -> 128: 8 frames 0.65 against 0.80 ms, 16 frames 1.06 against
-  // 0.89).  Both kernels accumulate every output in the same order, so the choice never changes a bit (ST_CONV_TILE=1 forces
-  // the tile kernel, 0 the per-tap kernel).
-  bool tile = wt_dev && ctx->conv_tile != 0 && conv_tile_weights(kh, kw, cout_pad, cin) && conv_tile_plan(h, w, kh, &th, &tw, &eff);
-  if (tile && ctx->conv_tile != 1)
-    tile = (long long)n * ((w + tw - 1) / tw) * ((h + th - 1) / th) * (cout_pad / 128) >= (long long)ctx->num_cus * 3 / 4;
-  if (tile) {
+  // Kernel by launch size (conv_tile_choose); every choice accumulates each output in the same order, so it never changes a bit.
+  ConvTileArgs ta;
+  const int nw = wt_dev ? conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, &ta) : 0;
+  if (nw) {
     if ((uintptr_t)wt_dev & 15) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: the tile-order weights must be 16-byte aligned");
-    ConvTileArgs ta;
     ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
     ta.w3t = (const unsigned*)wt_dev;
-    ta.n = n; ta.h = h; ta.wd = w; ta.cin = cin; ta.xs = x_stride; ta.xoff = x_offset; ta.pad = kh / 2;
+    ta.xs = x_stride; ta.xoff = x_offset;
     ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
-    ta.th = th; ta.tw = tw; ta.rw = tw + kh - 1; ta.rp = (th + kh - 1) * (tw + kh - 1);
-    ta.tiles_x = (w + tw - 1) / tw; ta.tiles_y = (h + th - 1) / th;
-    const long long tiles = (long long)n * ta.tiles_x * ta.tiles_y;
-    if (tiles > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-    dim3 tgrid((unsigned)tiles, cout_pad / 128);
+    dim3 tgrid((unsigned)((long long)n * ta.tiles_x * ta.tiles_y), cout_pad / 128);
     st_timed t(ctx, ST_K_CONV);
-    if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7>), tgrid, dim3(512), 0, ctx->stream, ta);
-    else hipLaunchKernelGGL((k_conv_tile_f32<3>), tgrid, dim3(512), 0, ctx->stream, ta);
+    if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+    else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+    else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+    else hipLaunchKernelGGL((k_conv_tile_f32<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
@@ -1053,24 +1073,19 @@ ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int 
   a.m = (long long)n * h * w;
   const long long bm = (a.m + CV_BM - 1) / CV_BM;
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-  // 3x3 / 7x7 layers with whole 128-channel output blocks: the spatial-tile kernel (ST_CONV_TILE=0, read at st_ctx_create,
-  // keeps the per-tap kernel), when a tile shape wastes less than a quarter of the 256-pixel instruction blocks
-  int th = 0, tw = 0;
-  double eff = 0;
-  if (ctx->conv_tile != 0 && conv_tile_weights(kh, kw, cout_pad, cin) && conv_tile_plan(h, w, kh, &th, &tw, &eff)) {
-    ConvTileArgs ta;
+  ConvTileArgs ta;
+  const int nw = conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, &ta);
+  if (nw) {
     ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
     ta.w3t = (const unsigned*)w3_dev + (size_t)cout_pad * kh * kw * (cin / 2) * 3;
-    ta.n = n; ta.h = h; ta.wd = w; ta.cin = cin; ta.xs = x_stride; ta.xoff = x_offset; ta.pad = kh / 2;
+    ta.xs = x_stride; ta.xoff = x_offset;
     ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
-    ta.th = th; ta.tw = tw; ta.rw = tw + kh - 1; ta.rp = (th + kh - 1) * (tw + kh - 1);
-    ta.tiles_x = (w + tw - 1) / tw; ta.tiles_y = (h + th - 1) / th;
-    const long long tiles = (long long)n * ta.tiles_x * ta.tiles_y;
-    if (tiles > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-    dim3 tgrid((unsigned)tiles, cout_pad / 128);
+    dim3 tgrid((unsigned)((long long)n * ta.tiles_x * ta.tiles_y), cout_pad / 128);
     st_timed t(ctx, ST_K_CONV);
-    if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7>), tgrid, dim3(512), 0, ctx->stream, ta);
-    else hipLaunchKernelGGL((k_conv_tile_bf16x3<3>), tgrid, dim3(512), 0, ctx->stream, ta);
+    if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+    else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+    else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+    else hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
   }
