@@ -413,21 +413,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_bf16x3(ConvArgs a, const u
 // bf16x3 on a SPATIAL tile (round 4).  k_conv_nhwc_bf16x3 pulls, per 16-channel slice of one tap, 8 KB of float32
 // pixels and 12 KB of split weights through the L1 for a 128 x 128 tile -- 31 B per clock and CU at full matrix rate,
 // more than a CU's miss queue sustains; its matrix pipe is busy 43 % of the time.  A 7x7 layer fetches
-// every input pixel 49 times that way.  Here a workgroup owns TH x TW <= 256 output pixels of ONE image and 128 output
+// every input pixel 49 times that way.  Here a workgroup owns TH x TW <= 32 NW output pixels of ONE image and 128 output
 // channels:
 //   * per 16-channel slice the input REGION (TH + K - 1) x (TW + K - 1) of the tile is split into its three bf16 planes
-//     ONCE and kept in LDS (<= 800 pixels x 96 B, two buffers = 150 KB: one workgroup of 512 threads per CU); the K x K
+//     ONCE and kept in LDS (NW = 4: <= 400 pixels x 96 B, two buffers = 75 KB, two workgroups of 256 threads per CU); the K x K
 //     taps of the slice read their A operands from it at a tap-dependent offset -- no global traffic, no split and no
 //     barrier between taps;
 //   * the B operands (weights) never touch LDS: st_conv_pack_weights_bf16x3 also writes them in the instruction's own
 //     operand order ([cout block][slice][tap][32-column tile][split][lane] x 16 bytes), so a wave fetches the 6 KB of a tap
 //     with six fully coalesced 16-byte loads straight into registers, TWO taps ahead (a tap's 768 matrix cycles do not cover
-//     an L2 round trip); the four waves that share them hit L1;
+//     an L2 round trip); the waves that share them hit L1;
 //   * the next slice's region arrives one (pixel, channel quad) item per thread at a time and is split / stored into the other
 //     LDS buffer between the taps' matrix instructions; ONE barrier per slice (49 or 9 taps x 24 MFMAs per wave);
 //   * inside a tap every matrix instruction is followed by one pinned piece of the side work (see the main loop).
-// L1 fills per executed flop fall 3.3-fold (12 KB of weights per tap and slice for a 256 x 128 tile, the region's 0.4-2 KB
-// amortised over the taps).  Accumulation order of an output: slices outer, taps inner, the six terms as in
+// L1 fills per executed flop fall 1.7-fold with 128 x 128 tiles (3.3-fold with 256 x 128: 12 KB of weights per tap and slice
+// either way, the region's 0.4-2 KB amortised over the taps).  Accumulation order of an output: slices outer, taps inner, the six terms as in
 // k_conv_nhwc_bf16x3 -- independent of the tile shape, so the tiling never changes a bit, and the order the per-tap kernel
 // walks K in too: the two kernels give the same bits and the launcher may pick either.
 // ---------------------------------------------------------------------------------------------------------------
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x3_tile(const float* _
   }
 }
 
-// NW: waves per workgroup -- 8 (256 pixels, region <= 800 pixels, one workgroup per CU) or 4 (128 pixels, region <= 400, two
-// per CU: twice the workgroups for launches that would leave CUs idle; the same bits, the accumulation order does not depend on
-// the tile)
+// NW: waves per workgroup -- 4 (128 pixels, region <= 400 pixels, two workgroups per CU; the instance in use) or 8 (256 pixels,
+// region <= 800, one per CU; level with it from 16 frames per call on, behind it below -- not instantiated); the same bits, the
+// accumulation order does not depend on the tile
 template <int KS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a) {
   constexpr int T = KS * KS, THREADS = NW * 64;
@@ -880,12 +880,15 @@ bool conv_tile_weights(int kh, int kw, int cout_pad, int cin) { return kh == kw 
 // CU: twice the workgroups -- 46x82, 7x7, 128 -> 128, 5 frames: bf16x3 0.20 against 0.36 ms (per-tap kernel 0.44), float32
 // 0.42 against 0.77 (0.62); from 16 frames on the two are equal), 0 = the per-tap kernel (no tile shape fits).  Fills the
 // geometry of `ta`.  Every choice accumulates an output in the same order, so none changes a bit; ST_CONV_TILE=0 forces the
-// per-tap kernel, 1 the 8-wave tile kernel wherever a tile shape exists, 4 the 4-wave one.
-int conv_tile_choose(st_ctx* ctx, int n, int h, int w, int kh, int kw, int cout_pad, int cin, ConvTileArgs* ta) {
+// per-tap kernel, 1 the 8-wave tile kernel wherever a tile shape exists, 4 the 4-wave one.  The 8-wave instance exists for the
+// float32 instruction only (`allow8`): there it is 2.7 % ahead over the network at 32 frames per call (247 against 240
+// frames/s); in bf16x3 the 4-wave instance is level or ahead at every size (419 against 416), and each instance of that kernel
+// is half a minute of compile time.
+int conv_tile_choose(st_ctx* ctx, int n, int h, int w, int kh, int kw, int cout_pad, int cin, bool allow8, ConvTileArgs* ta) {
   if (ctx->conv_tile == 0 || !conv_tile_weights(kh, kw, cout_pad, cin)) return 0;
   int th8 = 0, tw8 = 0, th4 = 0, tw4 = 0;
   double e8 = 0, e4 = 0;
-  const bool ok8 = conv_tile_plan(h, w, kh, 256, CT_RPMAX, &th8, &tw8, &e8);
+  const bool ok8 = allow8 && conv_tile_plan(h, w, kh, 256, CT_RPMAX, &th8, &tw8, &e8);
   const bool ok4 = conv_tile_plan(h, w, kh, 128, CT_RPMAX / 2, &th4, &tw4, &e4);
   auto wgs = [&](int th, int tw) { return (long long)n * ((w + tw - 1) / tw) * ((h + th - 1) / th) * (cout_pad / 128); };
   int nw = 0;
@@ -981,7 +984,7 @@ ST_EXPORT int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, i
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
   // Kernel by launch size (conv_tile_choose); every choice accumulates each output in the same order, so it never changes a bit.
   ConvTileArgs ta;
-  const int nw = wt_dev ? conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, &ta) : 0;
+  const int nw = wt_dev ? conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, true, &ta) : 0;
   if (nw) {
     if ((uintptr_t)wt_dev & 15) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: the tile-order weights must be 16-byte aligned");
     ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
@@ -1074,7 +1077,7 @@ ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int 
   const long long bm = (a.m + CV_BM - 1) / CV_BM;
   if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
   ConvTileArgs ta;
-  const int nw = conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, &ta);
+  const int nw = conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, false, &ta);
   if (nw) {
     ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
     ta.w3t = (const unsigned*)w3_dev + (size_t)cout_pad * kh * kw * (cin / 2) * 3;
@@ -1082,9 +1085,7 @@ ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int 
     ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
     dim3 tgrid((unsigned)((long long)n * ta.tiles_x * ta.tiles_y), cout_pad / 128);
     st_timed t(ctx, ST_K_CONV);
-    if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
-    else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
-    else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+    if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     else hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     ST_HIP(ctx, hipGetLastError());
     return ST_OK;
