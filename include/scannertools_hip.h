@@ -329,6 +329,20 @@ int st_conv_pack_weights_f32_tile(st_ctx* ctx, const float* w_dev, int cout_pad,
 int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
                              const float* w_dev, const void* wt_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad,
                              int relu, float* y_dev, int y_stride, int y_offset);
+/* TWO convolutions of the same geometry (n, h, w, cin, kernel, cout_pad, relu) on different operands -- the two branches of a
+ * stage of the pose network -- in one launch where the spatial-tile kernel runs (at the reference's five frames per call a
+ * 7x7 layer alone leaves a third of the CUs idle), else one after the other.  The result is exactly what the two single
+ * calls give.  w: the float32 tensor (f32) / the packed buffer (bf16x3); w_tile: f32 tile-order copy or null (bf16x3: unused). */
+typedef struct st_conv_operands {
+  const float* x; int x_stride, x_offset;
+  const void* w; const void* w_tile;
+  const float* bias; int cout;
+  float* y; int y_stride, y_offset;
+} st_conv_operands;
+int st_conv2d_nhwc_f32_pair(st_ctx* ctx, int n, int h, int w, int cin, int kh, int kw, int cout_pad, int relu,
+                            const st_conv_operands* a, const st_conv_operands* b);
+int st_conv2d_nhwc_bf16x3_pair(st_ctx* ctx, int n, int h, int w, int cin, int kh, int kw, int cout_pad, int relu,
+                               const st_conv_operands* a, const st_conv_operands* b);
 /* 2x2 max pooling, stride 2: (n, h, w, c) -> (n, h/2, w/2, c), c a multiple of 4. */
 /* The same convolution on the bf16 matrix pipe at float32-grade accuracy ("bf16x3": every operand split into three
  * bf16 terms, the six significant products accumulated in float32; 2.67 x the float32 matrix rate on CDNA4, results

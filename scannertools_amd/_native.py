@@ -63,6 +63,14 @@ class StError(RuntimeError):
         self.status = status
 
 
+class ConvOperands(ctypes.Structure):
+    """st_conv_operands (include/scannertools_hip.h): one of the two convolutions of a paired launch."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_stride", ctypes.c_int), ("x_offset", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("w_tile", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("cout", ctypes.c_int),
+                ("y", ctypes.c_void_p), ("y_stride", ctypes.c_int), ("y_offset", ctypes.c_int)]
+
+
 class FbParams(ctypes.Structure):
     """``st_fb_params``: arguments of cv::FarnebackOpticalFlow::create as the reference passes
     them (scannertools_cpp/imgproc/optical_flow_kernel_cpu.cpp:15-16) + the gray table width."""
@@ -124,6 +132,8 @@ SIGNATURES = {
     "st_conv_pack_weights_f32_tile": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "st_conv2d_nhwc_f32_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_conv_pack_weights_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "st_conv2d_nhwc_f32_pair": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(ConvOperands), _c.POINTER(ConvOperands)]),
+    "st_conv2d_nhwc_bf16x3_pair": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(ConvOperands), _c.POINTER(ConvOperands)]),
     "st_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_maxpool2_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),
     "st_planar_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),

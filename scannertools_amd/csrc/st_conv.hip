@@ -434,13 +434,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_nhwc_bf16x3(ConvArgs a, const u
 constexpr int CT_RPMAX = 800;   // region pixels per LDS buffer
 constexpr int CT_ITEMS = (CT_RPMAX * 4 + 511) / 512;   // (pixel, channel quad) items per thread and slice
 
-struct ConvTileArgs {
+// One launch may carry TWO convolutions of the same geometry (grid.z: the two branches of a stage of the pose network, which
+// read different activations with different weights): at the reference's five frames per call a 7x7 layer is 160 workgroups
+// for 256 CUs, the pair 320.
+struct ConvTileOperands {
   const float* x;
   const unsigned* w3t;   // tile-order weights
   const float* bias;
   float* y;
-  int n, h, wd, cin, xs, xoff, pad;
-  int cout, ys, yoff, relu;
+  int xs, xoff, cout, ys, yoff;
+};
+struct ConvTileArgs {
+  ConvTileOperands op[2];
+  int n, h, wd, cin, pad, relu;
   int th, tw, rw, rp;        // tile rows / columns, region columns, region pixels
   int tiles_x, tiles_y;      // tiles per image
 };
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x3_tile(const float* _
 // accumulation order does not depend on the tile
 template <int KS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a) {
+  const ConvTileOperands& o = a.op[blockIdx.z];
   constexpr int T = KS * KS, THREADS = NW * 64;
   __shared__ unsigned Ar[2][3][(NW == 8 ? CT_RPMAX : CT_RPMAX / 2) * 8];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, lk = lane >> 5;
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
   const int tyi = bt % a.tiles_y, img = bt / a.tiles_y;
   const int y0 = tyi * a.th, x0 = txi * a.tw;
   const int S = a.cin / 16;
-  const float* __restrict__ ximg = a.x + (size_t)img * a.h * a.wd * a.xs + a.xoff;
+  const float* __restrict__ ximg = o.x + (size_t)img * a.h * a.wd * o.xs + o.xoff;
 
   // region pixel r, 16-byte half c -> dword offset inside a plane (32-byte rows, the halves swapped on rows 8..15 mod 16)
   auto swz = [](int r, int c) { return r * 8 + ((c ^ ((r >> 3) & 1)) << 2); };
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
       loff[i] = swz(r, cq >> 1) + 2 * (cq & 1);
       if ((unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd) {
         inb |= 1u << i;
-        goff[i] = (yy * a.wd + xx) * a.xs + 4 * cq;
+        goff[i] = (yy * a.wd + xx) * o.xs + 4 * cq;
       }
     }
   }
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
     abase[i] = ty * a.rw + (p - ty * a.tw);
   }
   // weights of (slice, tap) q for this wave: 6 x 1 KB, lane-contiguous
-  const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(a.w3t) + ((size_t)blockIdx.y * S * T) * 768 + (wv & 1) * 384 + lane;
+  const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(o.w3t) + ((size_t)blockIdx.y * S * T) * 768 + (wv & 1) * 384 + lane;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -649,12 +656,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
       const int ty = p / a.tw, tx = p - ty * a.tw;
       const int yy = y0 + ty, xx = x0 + tx;
       if (yy >= a.h || xx >= a.wd) continue;
-      float* __restrict__ yp = a.y + ((size_t)((size_t)img * a.h + yy) * a.wd + xx) * a.ys + a.yoff;
+      float* __restrict__ yp = o.y + ((size_t)((size_t)img * a.h + yy) * a.wd + xx) * o.ys + o.yoff;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nn = blockIdx.y * 128 + wn + 32 * j + l31;
-        if (nn < a.cout) {
-          float v = acc[i][j][r] + a.bias[nn];
+        if (nn < o.cout) {
+          float v = acc[i][j][r] + o.bias[nn];
           if (a.relu) v = v > 0.f ? v : 0.f;
           yp[nn] = v;
         }
@@ -690,6 +697,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_f32_tile(const float* __re
 
 template <int KS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
+  const ConvTileOperands& o = a.op[blockIdx.z];
   constexpr int T = KS * KS, THREADS = NW * 64, CTF_RPS = NW == 8 ? 818 : 418;   // plane strides = 2 mod 16
   __shared__ float Af[2][16][CTF_RPS];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, lk = lane >> 5;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
   const int tyi = bt % a.tiles_y, img = bt / a.tiles_y;
   const int y0 = tyi * a.th, x0 = txi * a.tw;
   const int S = a.cin / 16;
-  const float* __restrict__ ximg = a.x + (size_t)img * a.h * a.wd * a.xs + a.xoff;
+  const float* __restrict__ ximg = o.x + (size_t)img * a.h * a.wd * o.xs + o.xoff;
 
   int goff[CT_ITEMS], loff[CT_ITEMS];
   unsigned exists = 0, inb = 0;
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
       loff[i] = 4 * cq * CTF_RPS + r;
       if ((unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.wd) {
         inb |= 1u << i;
-        goff[i] = (yy * a.wd + xx) * a.xs + 4 * cq;
+        goff[i] = (yy * a.wd + xx) * o.xs + 4 * cq;
       }
     }
   }
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
     const int ty = p / a.tw;
     abase[i] = ty * a.rw + (p - ty * a.tw) + lk * CTF_RPS;
   }
-  const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(a.w3t) + ((size_t)blockIdx.y * S * T) * 512 + (wv & 1) * 256 + lane;
+  const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(o.w3t) + ((size_t)blockIdx.y * S * T) * 512 + (wv & 1) * 256 + lane;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -840,12 +848,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
       const int ty = p / a.tw, tx = p - ty * a.tw;
       const int yy = y0 + ty, xx = x0 + tx;
       if (yy >= a.h || xx >= a.wd) continue;
-      float* __restrict__ yp = a.y + ((size_t)((size_t)img * a.h + yy) * a.wd + xx) * a.ys + a.yoff;
+      float* __restrict__ yp = o.y + ((size_t)((size_t)img * a.h + yy) * a.wd + xx) * o.ys + o.yoff;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nn = blockIdx.y * 128 + wn + 32 * j + l31;
-        if (nn < a.cout) {
-          float v = acc[i][j][r] + a.bias[nn];
+        if (nn < o.cout) {
+          float v = acc[i][j][r] + o.bias[nn];
           if (a.relu) v = v > 0.f ? v : 0.f;
           yp[nn] = v;
         }
@@ -962,50 +970,89 @@ __global__ __launch_bounds__(256) void k_planar_to_nhwc(PlanarArgs a) {
 
 }  // namespace
 
+namespace {
+// One or two convolutions of the same geometry (`nops`): checks, kernel choice, launch.  Two go into ONE launch where the
+// spatial-tile kernel runs (grid.z), else into one per-tap launch each.  f32: operands' `w` is the float32 tensor and
+// `w_tile` its tile-order copy or null; bf16x3: `w` is the packed buffer of st_conv_pack_weights_bf16x3.
+int conv_launch(st_ctx* ctx, bool f32, int n, int h, int w, int cin, int kh, int kw, int cout_pad, int relu, const st_conv_operands* ops,
+                int nops) {
+  if (!ops || n <= 0 || h <= 0 || w <= 0 || cin <= 0) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
+  if (kh != kw || !(kh & 1) || kh > 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: %dx%d kernels (odd square kernels up to 7 are implemented)", kh, kw);
+  if (cout_pad <= 0 || cout_pad % 64) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: cout_pad must be a multiple of 64 >= cout");
+  bool tile_weights = true;
+  for (int k = 0; k < nops; ++k) {
+    const st_conv_operands& o = ops[k];
+    if (!o.x || !o.w || !o.bias || !o.y || o.cout <= 0) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
+    if (cin % 16 || o.x_offset % 4 || o.x_stride % 4 || o.x_offset + cin > o.x_stride || ((uintptr_t)o.x & 15) || ((uintptr_t)o.w & 15))
+      return st_set_error(ctx, ST_ERR_INVALID, "conv2d: input channels must be a multiple of 16 inside a 16-byte aligned buffer (cin=%d stride=%d offset=%d)", cin, o.x_stride, o.x_offset);
+    if (cout_pad < o.cout) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: cout_pad must be a multiple of 64 >= cout");
+    if (o.y_offset + o.cout > o.y_stride) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: output slice exceeds the buffer's channel count");
+    if (f32 && o.w_tile && ((uintptr_t)o.w_tile & 15)) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: the tile-order weights must be 16-byte aligned");
+    if (f32 && !o.w_tile) tile_weights = false;
+  }
+  const int bn = cout_pad % 128 == 0 ? 128 : 64;
+  const long long m = (long long)n * h * w;
+  const long long bm = (m + CV_BM - 1) / CV_BM;
+  if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+  // Kernel by launch size (conv_tile_choose); every choice accumulates each output in the same order, so it never changes a bit.
+  ConvTileArgs ta;
+  const int nw = tile_weights ? conv_tile_choose(ctx, n * nops, h, w, kh, kw, cout_pad, cin, f32, &ta) : 0;
+  if (nw) {
+    ta.n = n;
+    ta.relu = relu ? 1 : 0;
+    for (int k = 0; k < nops; ++k) {
+      const st_conv_operands& o = ops[k];
+      ConvTileOperands& t = ta.op[k];
+      t.x = o.x; t.bias = o.bias; t.y = o.y;
+      t.w3t = f32 ? (const unsigned*)o.w_tile : (const unsigned*)o.w + (size_t)cout_pad * kh * kw * (cin / 2) * 3;
+      t.xs = o.x_stride; t.xoff = o.x_offset; t.cout = o.cout; t.ys = o.y_stride; t.yoff = o.y_offset;
+    }
+    if (nops == 1) ta.op[1] = ta.op[0];
+    const long long tiles = (long long)n * ta.tiles_x * ta.tiles_y;
+    if (tiles > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+    dim3 tgrid((unsigned)tiles, cout_pad / 128, nops);
+    st_timed t(ctx, ST_K_CONV);
+    if (f32) {
+      if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+      else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+      else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+      else hipLaunchKernelGGL((k_conv_tile_f32<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+    } else {
+      if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+      else hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+    }
+    ST_HIP(ctx, hipGetLastError());
+    return ST_OK;
+  }
+  for (int k = 0; k < nops; ++k) {
+    const st_conv_operands& o = ops[k];
+    ConvArgs a;
+    a.x = o.x; a.w = f32 ? (const float*)o.w : nullptr; a.bias = o.bias; a.y = o.y;
+    a.n = n; a.h = h; a.wd = w; a.cin = cin; a.xs = o.x_stride; a.xoff = o.x_offset;
+    a.kh = kh; a.kw = kw; a.pad = kh / 2;
+    a.cout = o.cout; a.ys = o.y_stride; a.yoff = o.y_offset; a.relu = relu ? 1 : 0;
+    a.m = m;
+    dim3 grid((unsigned)bm, cout_pad / bn);
+    st_timed t(ctx, ST_K_CONV);
+    if (f32) {
+      if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_f32<128, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_conv_nhwc_f32<64, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+      if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_bf16x3<128>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)o.w);
+      else hipLaunchKernelGGL((k_conv_nhwc_bf16x3<64>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)o.w);
+    }
+    ST_HIP(ctx, hipGetLastError());
+  }
+  return ST_OK;
+}
+}  // namespace
+
 ST_EXPORT int st_conv2d_nhwc_f32_tiled(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
                                        const float* w_dev, const void* wt_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad,
                                        int relu, float* y_dev, int y_stride, int y_offset) {
   ST_TRY(st_enter(ctx));
-  if (!x_dev || !w_dev || !bias_dev || !y_dev || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0)
-    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
-  if (cin % 16 || x_offset % 4 || x_stride % 4 || x_offset + cin > x_stride || ((uintptr_t)x_dev & 15) || ((uintptr_t)w_dev & 15))
-    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: input channels must be a multiple of 16 inside a 16-byte aligned buffer (cin=%d stride=%d offset=%d)", cin, x_stride, x_offset);
-  if (kh != kw || !(kh & 1) || kh > 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: %dx%d kernels (odd square kernels up to 7 are implemented)", kh, kw);
-  const int bn = cout_pad % 128 == 0 ? 128 : 64;
-  if (cout_pad < cout || cout_pad % 64) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: cout_pad must be a multiple of 64 >= cout");
-  if (y_offset + cout > y_stride) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: output slice exceeds the buffer's channel count");
-  ConvArgs a;
-  a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.y = y_dev;
-  a.n = n; a.h = h; a.wd = w; a.cin = cin; a.xs = x_stride; a.xoff = x_offset;
-  a.kh = kh; a.kw = kw; a.pad = kh / 2;
-  a.cout = cout; a.ys = y_stride; a.yoff = y_offset; a.relu = relu ? 1 : 0;
-  a.m = (long long)n * h * w;
-  const long long bm = (a.m + CV_BM - 1) / CV_BM;
-  if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-  // Kernel by launch size (conv_tile_choose); every choice accumulates each output in the same order, so it never changes a bit.
-  ConvTileArgs ta;
-  const int nw = wt_dev ? conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, true, &ta) : 0;
-  if (nw) {
-    if ((uintptr_t)wt_dev & 15) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: the tile-order weights must be 16-byte aligned");
-    ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
-    ta.w3t = (const unsigned*)wt_dev;
-    ta.xs = x_stride; ta.xoff = x_offset;
-    ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
-    dim3 tgrid((unsigned)((long long)n * ta.tiles_x * ta.tiles_y), cout_pad / 128);
-    st_timed t(ctx, ST_K_CONV);
-    if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
-    else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
-    else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
-    else hipLaunchKernelGGL((k_conv_tile_f32<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
-    ST_HIP(ctx, hipGetLastError());
-    return ST_OK;
-  }
-  dim3 grid((unsigned)bm, cout_pad / bn);
-  st_timed t(ctx, ST_K_CONV);
-  if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_f32<128, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_conv_nhwc_f32<64, 16, 1, 1>), grid, dim3(256), 0, ctx->stream, a);
-  ST_HIP(ctx, hipGetLastError());
-  return ST_OK;
+  const st_conv_operands o{x_dev, x_stride, x_offset, w_dev, wt_dev, bias_dev, cout, y_dev, y_stride, y_offset};
+  return conv_launch(ctx, true, n, h, w, cin, kh, kw, cout_pad, relu, &o, 1);
 }
 
 ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
@@ -1015,6 +1062,21 @@ ST_EXPORT int st_conv2d_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, 
                                   y_stride, y_offset);
 }
 
+ST_EXPORT int st_conv2d_nhwc_f32_pair(st_ctx* ctx, int n, int h, int w, int cin, int kh, int kw, int cout_pad, int relu,
+                                      const st_conv_operands* a, const st_conv_operands* b) {
+  ST_TRY(st_enter(ctx));
+  if (!a || !b) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: null operands");
+  const st_conv_operands ops[2] = {*a, *b};
+  return conv_launch(ctx, true, n, h, w, cin, kh, kw, cout_pad, relu, ops, 2);
+}
+
+ST_EXPORT int st_conv2d_nhwc_bf16x3_pair(st_ctx* ctx, int n, int h, int w, int cin, int kh, int kw, int cout_pad, int relu,
+                                         const st_conv_operands* a, const st_conv_operands* b) {
+  ST_TRY(st_enter(ctx));
+  if (!a || !b) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: null operands");
+  const st_conv_operands ops[2] = {*a, *b};
+  return conv_launch(ctx, false, n, h, w, cin, kh, kw, cout_pad, relu, ops, 2);
+}
 
 ST_EXPORT long long st_conv_f32_tile_bytes(int cout_pad, int kh, int kw, int cin) {
   if (cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0 || !conv_tile_weights(kh, kw, cout_pad, cin)) return 0;
@@ -1060,42 +1122,8 @@ ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int 
                                     const void* w3_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,
                                     float* y_dev, int y_stride, int y_offset) {
   ST_TRY(st_enter(ctx));
-  if (!x_dev || !w3_dev || !bias_dev || !y_dev || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0)
-    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: bad arguments");
-  if (cin % 16 || x_offset % 4 || x_stride % 4 || x_offset + cin > x_stride || ((uintptr_t)x_dev & 15) || ((uintptr_t)w3_dev & 15))
-    return st_set_error(ctx, ST_ERR_INVALID, "conv2d: input channels must be a multiple of 16 inside a 16-byte aligned buffer (cin=%d stride=%d offset=%d)", cin, x_stride, x_offset);
-  if (kh != kw || !(kh & 1) || kh > 7) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: %dx%d kernels (odd square kernels up to 7 are implemented)", kh, kw);
-  const int bn = cout_pad % 128 == 0 ? 128 : 64;
-  if (cout_pad < cout || cout_pad % 64) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: cout_pad must be a multiple of 64 >= cout");
-  if (y_offset + cout > y_stride) return st_set_error(ctx, ST_ERR_INVALID, "conv2d: output slice exceeds the buffer's channel count");
-  ConvArgs a;
-  a.x = x_dev; a.w = nullptr; a.bias = bias_dev; a.y = y_dev;
-  a.n = n; a.h = h; a.wd = w; a.cin = cin; a.xs = x_stride; a.xoff = x_offset;
-  a.kh = kh; a.kw = kw; a.pad = kh / 2;
-  a.cout = cout; a.ys = y_stride; a.yoff = y_offset; a.relu = relu ? 1 : 0;
-  a.m = (long long)n * h * w;
-  const long long bm = (a.m + CV_BM - 1) / CV_BM;
-  if (bm > 2147483647LL) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
-  ConvTileArgs ta;
-  const int nw = conv_tile_choose(ctx, n, h, w, kh, kw, cout_pad, cin, false, &ta);
-  if (nw) {
-    ta.x = x_dev; ta.bias = bias_dev; ta.y = y_dev;
-    ta.w3t = (const unsigned*)w3_dev + (size_t)cout_pad * kh * kw * (cin / 2) * 3;
-    ta.xs = x_stride; ta.xoff = x_offset;
-    ta.cout = cout; ta.ys = y_stride; ta.yoff = y_offset; ta.relu = relu ? 1 : 0;
-    dim3 tgrid((unsigned)((long long)n * ta.tiles_x * ta.tiles_y), cout_pad / 128);
-    st_timed t(ctx, ST_K_CONV);
-    if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
-    else hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
-    ST_HIP(ctx, hipGetLastError());
-    return ST_OK;
-  }
-  dim3 grid((unsigned)bm, cout_pad / bn);
-  st_timed t(ctx, ST_K_CONV);
-  if (bn == 128) hipLaunchKernelGGL((k_conv_nhwc_bf16x3<128>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)w3_dev);
-  else hipLaunchKernelGGL((k_conv_nhwc_bf16x3<64>), grid, dim3(256), 0, ctx->stream, a, (const unsigned*)w3_dev);
-  ST_HIP(ctx, hipGetLastError());
-  return ST_OK;
+  const st_conv_operands o{x_dev, x_stride, x_offset, w3_dev, nullptr, bias_dev, cout, y_dev, y_stride, y_offset};
+  return conv_launch(ctx, false, n, h, w, cin, kh, kw, cout_pad, relu, &o, 1);
 }
 
 ST_EXPORT int st_maxpool2_nhwc_f32(st_ctx* ctx, const float* x_dev, int n, int h, int w, int c, int x_stride, float* y_dev,

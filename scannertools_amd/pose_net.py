@@ -427,6 +427,33 @@ class PoseNet:
                                                    ctypes.c_void_p(bp.data_ptr()), k, k, cout,
                                                    wp.shape[0], int(relu), ctypes.c_void_p(y.data_ptr()), y.shape[3], yoff))
 
+    def _operands(self, name, x, xoff, y, cout, yoff):
+        from ._native import ConvOperands
+        wp, bp = self.packed[name]
+        o = ConvOperands()
+        o.x, o.x_stride, o.x_offset = x.data_ptr(), x.shape[3], xoff
+        if self.math == "bf16x3":
+            o.w, o.w_tile = self.packed3[name].data_ptr(), None
+        else:
+            wt_ = self.packed_tile.get(name)
+            o.w, o.w_tile = wp.data_ptr(), (wt_.data_ptr() if wt_ is not None else None)
+        o.bias, o.cout = bp.data_ptr(), cout
+        o.y, o.y_stride, o.y_offset = y.data_ptr(), y.shape[3], yoff
+        return o
+
+    def _conv_pair(self, a, b, cin, k, relu):
+        """Two convolutions of the same geometry (the two branches of a stage) through st_conv2d_nhwc_*_pair; a, b =
+        (name, x, xoff, y, cout, yoff).  The same bits as two _conv calls."""
+        (na, xa, xoa, ya, coa, yoa), (nb, xb, xob, yb, cob, yob) = a, b
+        n, h, w, _ = xa.shape
+        cop = self.packed[na][0].shape[0]
+        assert cop == self.packed[nb][0].shape[0] and xa.shape[:3] == xb.shape[:3]
+        oa, ob = self._operands(na, xa, xoa, ya, coa, yoa), self._operands(nb, xb, xob, yb, cob, yob)
+        L = self.ctx._L
+        self.ctx._bind()
+        fn = L.st_conv2d_nhwc_bf16x3_pair if self.math == "bf16x3" else L.st_conv2d_nhwc_f32_pair
+        self.ctx._check(fn(self.ctx._h, n, h, w, cin, k, k, cop, int(relu), ctypes.byref(oa), ctypes.byref(ob)))
+
     def _pool(self, x, c):
         n, h, w, xs = x.shape
         y = self.torch.zeros((n, h // 2, w // 2, xs), dtype=self.torch.float32, device=self.device)
@@ -477,24 +504,32 @@ class PoseNet:
             self._conv(name, x, x.shape[3], 0, y, co, 0, k, relu)
             x = y
         h8, w8 = H // 8, W // 8
-        tmp = [torch.empty((n, h8, w8, 128), dtype=torch.float32, device=self.device) for _ in range(2)]
-        wide = torch.empty((n, h8, w8, 512), dtype=torch.float32, device=self.device)
+        # The two branches of a stage (PAF, heat maps) have the same layer shapes: layer i of both goes out as ONE paired call
+        # (one launch where the spatial-tile kernel runs -- at a few frames per call a branch alone leaves CUs idle), each
+        # branch with its own temporaries.
+        tmp = [[torch.empty((n, h8, w8, 128), dtype=torch.float32, device=self.device) for _ in range(2)] for _ in range(2)]
+        wide = [torch.empty((n, h8, w8, 512), dtype=torch.float32, device=self.device) for _ in range(2)]
+        branches = (("L1", N_PAF, OFF_PAF), ("L2", N_HEAT, OFF_HEAT))
         for st in range(1, 7):
             src, dst = cat[(st - 1) & 1], cat[st & 1]
-            for br, nout, boff in (("L1", N_PAF, OFF_PAF), ("L2", N_HEAT, OFF_HEAT)):
-                layers = branch_layers(st, nout)
-                x, xc, xoff = (src, N_FEAT, OFF_FEAT) if st == 1 else (src, CAT_PAD, 0)
-                for i, (ci, co, k, relu) in enumerate(layers):
-                    name = "stage%d_%s_%d" % (st, br, i + 1)
-                    last = i == len(layers) - 1
-                    if last:
+            layers = [branch_layers(st, nout) for _, nout, _ in branches]
+            cur = [((src, N_FEAT, OFF_FEAT) if st == 1 else (src, CAT_PAD, 0)) for _ in branches]
+            for i in range(len(layers[0])):
+                ops = []
+                for b, (br, nout, boff) in enumerate(branches):
+                    ci, co, k, relu = layers[b][i]
+                    if i == len(layers[b]) - 1:
                         y, yoff = dst, boff
                     elif co == 512:
-                        y, yoff = wide, 0
+                        y, yoff = wide[b], 0
                     else:
-                        y, yoff = tmp[i & 1], 0
-                    self._conv(name, x, xc, xoff, y, co, yoff, k, relu)
-                    x, xc, xoff = y, y.shape[3], 0
+                        y, yoff = tmp[b][i & 1], 0
+                    x, xc, xoff = cur[b]
+                    ops.append(("stage%d_%s_%d" % (st, br, i + 1), x, xoff, y, co, yoff, xc, k, relu))
+                    cur[b] = (y, y.shape[3], 0)
+                (n0, x0, xo0, y0, c0, yo0, xc0, k0, r0), (n1, x1, xo1, y1, c1, yo1, xc1, k1, r1) = ops
+                assert (xc0, k0, r0) == (xc1, k1, r1)
+                self._conv_pair((n0, x0, xo0, y0, c0, yo0), (n1, x1, xo1, y1, c1, yo1), xc0, k0, r0)
         return cat[6 & 1]
 
     # -- float32 reference on the same weights (tests, bench parity) ---------------------------------------

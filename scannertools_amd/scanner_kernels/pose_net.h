@@ -380,24 +380,38 @@ class Net {
         h /= 2; w /= 2;
       }
     }
+    // The two branches of a stage have the same layer shapes: layer i of both goes out as ONE paired call (one launch where the
+    // spatial-tile kernel runs: at a few frames per call a branch alone leaves CUs idle), each branch with its own temporaries
+    // -- the same calls as scannertools_amd/pose_net.py: forward_raw, so the two drivers stay bit-identical.
     for (int st = 1; st <= 6; ++st) {
       const float* src = cat_[(st - 1) & 1];
       float* dst = cat_[st & 1];
-      for (int br = 1; br <= 2; ++br) {
-        const auto layers = branch_layers(st, br);
-        const float* xin = src;
-        int xs = kCatPad, xcin = st == 1 ? kFeat : kCatPad, xoff = st == 1 ? kOffFeat : 0;
-        for (int i = 0; i < (int)layers.size(); ++i) {
-          const LayerSpec& l = layers[i];
+      const std::vector<LayerSpec> layers[2] = {branch_layers(st, 1), branch_layers(st, 2)};
+      const float* xin[2] = {src, src};
+      int xs[2] = {kCatPad, kCatPad}, xoff[2] = {st == 1 ? kOffFeat : 0, st == 1 ? kOffFeat : 0};
+      int xcin = st == 1 ? kFeat : kCatPad;
+      for (int i = 0; i < (int)layers[0].size(); ++i) {
+        st_conv_operands ops[2];
+        for (int b = 0; b < 2; ++b) {
+          const LayerSpec& l = layers[b][i];
           Packed& p = packed_[l.name];
           float* yout;
           int ys, yoff;
-          if (i == (int)layers.size() - 1) { yout = dst; ys = kCatPad; yoff = br == 1 ? kOffPaf : kOffHeat; }
-          else if (l.cout == 512) { yout = wide_; ys = 512; yoff = 0; }
-          else { yout = tmp_[i & 1]; ys = 128; yoff = 0; }
-          if (conv(ctx, xin, n, h, w, xcin, xs, xoff, p, l, yout, ys, yoff) != ST_OK) return fail("st_conv2d_nhwc");
-          xin = yout; xs = ys; xcin = ys; xoff = 0;
+          if (i == (int)layers[b].size() - 1) { yout = dst; ys = kCatPad; yoff = b == 0 ? kOffPaf : kOffHeat; }
+          else if (l.cout == 512) { yout = wide_[b]; ys = 512; yoff = 0; }
+          else { yout = tmp_[b][i & 1]; ys = 128; yoff = 0; }
+          const int st_w = prepare_weights(ctx, p, l);
+          if (st_w != ST_OK) return fail("st_conv_pack_weights");
+          ops[b] = st_conv_operands{xin[b], xs[b], xoff[b], bf16x3_ ? (const void*)p.w3 : (const void*)p.w, bf16x3_ ? nullptr : p.wt, p.b, l.cout,
+                                    yout, ys, yoff};
+          xin[b] = yout; xs[b] = ys; xoff[b] = 0;
         }
+        const LayerSpec& l0 = layers[0][i];
+        const int cop = packed_[l0.name].cout_pad;
+        const int rc = bf16x3_ ? st_conv2d_nhwc_bf16x3_pair(ctx, n, h, w, xcin, l0.k, l0.k, cop, l0.relu, &ops[0], &ops[1])
+                               : st_conv2d_nhwc_f32_pair(ctx, n, h, w, xcin, l0.k, l0.k, cop, l0.relu, &ops[0], &ops[1]);
+        if (rc != ST_OK) return fail("st_conv2d_nhwc_pair");
+        xcin = ops[0].y_stride;
       }
     }
     return cat_[6 & 1];
@@ -413,8 +427,8 @@ class Net {
     int cin_pad = 0, cout_pad = 0, k = 0;
   };
 
-  // one convolution layer in the selected arithmetic
-  int conv(st_ctx* ctx, const float* x, int n, int h, int w, int cin, int xs, int xoff, Packed& p, const LayerSpec& l, float* y, int ys, int yoff) {
+  // the layer's weights in the form(s) the selected arithmetic reads, packed on first use
+  int prepare_weights(st_ctx* ctx, Packed& p, const LayerSpec& l) {
     if (!bf16x3_) {
       if (!p.wt_tried) {
         p.wt_tried = true;
@@ -430,7 +444,7 @@ class Net {
           p.wt = wt;
         }
       }
-      return st_conv2d_nhwc_f32_tiled(ctx, x, n, h, w, cin, xs, xoff, p.w, p.wt, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
+      return ST_OK;
     }
     if (!p.w3) {
       void* w3 = nullptr;
@@ -442,6 +456,14 @@ class Net {
       }
       p.w3 = w3;
     }
+    return ST_OK;
+  }
+
+  // one convolution layer in the selected arithmetic
+  int conv(st_ctx* ctx, const float* x, int n, int h, int w, int cin, int xs, int xoff, Packed& p, const LayerSpec& l, float* y, int ys, int yoff) {
+    const int st = prepare_weights(ctx, p, l);
+    if (st != ST_OK) return st;
+    if (!bf16x3_) return st_conv2d_nhwc_f32_tiled(ctx, x, n, h, w, cin, xs, xoff, p.w, p.wt, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
     return st_conv2d_nhwc_bf16x3(ctx, x, n, h, w, cin, xs, xoff, p.w3, p.b, l.k, l.k, l.cout, p.cout_pad, l.relu, y, ys, yoff);
   }
 
@@ -456,7 +478,8 @@ class Net {
     // the largest trunk activation is conv1's (64 channels at full resolution); grow-only, shared by all slots
     if (big > cap_big_) { ok = ok && alloc(&a_, big) && alloc(&b_, big); cap_big_ = ok ? big : 0; }
     if (ok && small > cap_small_) {
-      ok = alloc(&tmp_[0], small * 128) && alloc(&tmp_[1], small * 128) && alloc(&wide_, small * 512);
+      ok = true;
+      for (int b = 0; b < 2 && ok; ++b) ok = alloc(&tmp_[b][0], small * 128) && alloc(&tmp_[b][1], small * 128) && alloc(&wide_[b], small * 512);
       cap_small_ = ok ? small : 0;
     }
     Slot& sl = slots_[slot];
@@ -475,7 +498,7 @@ class Net {
     return true;
   }
   void free_buffers() {
-    float** all[] = {&a_, &b_, &tmp_[0], &tmp_[1], &wide_};
+    float** all[] = {&a_, &b_, &tmp_[0][0], &tmp_[0][1], &tmp_[1][0], &tmp_[1][1], &wide_[0], &wide_[1]};
     for (auto p : all) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
@@ -509,7 +532,7 @@ class Net {
     size_t cap = 0;
   };
   Slot slots_[kMaxSlots];
-  float *a_ = nullptr, *b_ = nullptr, *tmp_[2] = {nullptr, nullptr}, *wide_ = nullptr;
+  float *a_ = nullptr, *b_ = nullptr, *tmp_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *wide_[2] = {nullptr, nullptr};   // temporaries per branch
   size_t cap_big_ = 0, cap_small_ = 0;
 };
 

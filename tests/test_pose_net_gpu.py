@@ -165,6 +165,65 @@ def test_conv_tile_random_shapes(hip_ctx, math):
         assert (y[..., :4] == -7.0).all() and (y[..., 4 + co:] == -7.0).all(), msg
 
 
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["1", "4", "0", "auto"])
+def test_conv_pair_equals_two_calls(hip_ctx, math, mode):
+    """st_conv2d_nhwc_*_pair -- two convolutions of one geometry, different operands, in one launch where the tile kernel runs
+    (the two branches of a stage) -- gives exactly what the two single calls give: different inputs / channel slices,
+    different weights, different output counts under one cout_pad, every kernel choice."""
+    from scannertools_amd._native import ConvOperands
+    ctx = hip_ctx if mode == "auto" else _mode_ctx(mode)
+    for (n, h, w, ci, k, co_a, co_b) in ((2, 46, 82, 32, 7, 128, 128), (3, 23, 31, 48, 3, 100, 128), (1, 9, 13, 16, 1, 38, 19), (2, 12, 20, 16, 7, 38, 19)):
+        g = torch.Generator().manual_seed(h * w + k)
+        cop = (max(co_a, co_b) + 63) // 64 * 64
+        xa = torch.randn((n, h, w, ci + 16), generator=g).cuda()
+        xb = torch.randn((n, h, w, ci), generator=g).cuda()
+        ys, ws, ops, keep = [], [], [], []
+        for x, xoff, co, yoff in ((xa, 16, co_a, 0), (xb, 0, co_b, 4)):
+            wt = torch.zeros((cop, k, k, ci))
+            wt[:co] = torch.randn((co, k, k, ci), generator=g) * float(np.sqrt(2.0 / (ci * k * k)))
+            b = torch.zeros((cop,))
+            b[:co] = torch.randn((co,), generator=g) * 0.1
+            wt, b = wt.cuda(), b.cuda()
+            ctx._bind()
+            if math == "bf16x3":
+                wq = torch.empty((ctx._L.st_conv_bf16x3_packed_bytes(cop, k, k, ci),), dtype=torch.uint8, device="cuda")
+                ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wt.data_ptr()), cop, k, k, ci, ctypes.c_void_p(wq.data_ptr())))
+                wmain, wtile = wq, None
+            else:
+                nb = ctx._L.st_conv_f32_tile_bytes(cop, k, k, ci)
+                wtile = torch.empty((nb,), dtype=torch.uint8, device="cuda") if nb else None
+                if nb:
+                    ctx._check(ctx._L.st_conv_pack_weights_f32_tile(ctx._h, ctypes.c_void_p(wt.data_ptr()), cop, k, k, ci, ctypes.c_void_p(wtile.data_ptr())))
+                wmain = wt
+            y1 = torch.full((n, h, w, co + 8), -7.0, device="cuda")
+            y2 = torch.full((n, h, w, co + 8), -7.0, device="cuda")
+            vp = ctypes.c_void_p
+            if math == "bf16x3":
+                ctx._check(ctx._L.st_conv2d_nhwc_bf16x3(ctx._h, vp(x.data_ptr()), n, h, w, ci, x.shape[3], xoff, vp(wmain.data_ptr()), vp(b.data_ptr()),
+                                                        k, k, co, cop, 1, vp(y1.data_ptr()), co + 8, yoff))
+            else:
+                ctx._check(ctx._L.st_conv2d_nhwc_f32_tiled(ctx._h, vp(x.data_ptr()), n, h, w, ci, x.shape[3], xoff, vp(wmain.data_ptr()),
+                                                           vp(wtile.data_ptr()) if wtile is not None else None, vp(b.data_ptr()),
+                                                           k, k, co, cop, 1, vp(y1.data_ptr()), co + 8, yoff))
+            o = ConvOperands()
+            o.x, o.x_stride, o.x_offset = x.data_ptr(), x.shape[3], xoff
+            o.w, o.w_tile = wmain.data_ptr(), (wtile.data_ptr() if wtile is not None else None)
+            o.bias, o.cout = b.data_ptr(), co
+            o.y, o.y_stride, o.y_offset = y2.data_ptr(), co + 8, yoff
+            ys.append((y1, y2)); ops.append(o); keep.append((wt, b, wmain, wtile))
+        fn = ctx._L.st_conv2d_nhwc_bf16x3_pair if math == "bf16x3" else ctx._L.st_conv2d_nhwc_f32_pair
+        ctx._check(fn(ctx._h, n, h, w, ci, k, k, cop, 1, ctypes.byref(ops[0]), ctypes.byref(ops[1])))
+        torch.cuda.synchronize()
+        for y1, y2 in ys:
+            assert torch.equal(y1, y2), (n, h, w, ci, k, co_a, co_b)
+    # refusals: a null operand set, a bad slice in the second one
+    assert fn(ctx._h, 1, 4, 4, 16, 3, 3, 64, 1, ctypes.byref(ops[0]), None) != 0
+    bad = ConvOperands.from_buffer_copy(ops[1])
+    bad.y_offset = 10 ** 6
+    assert fn(ctx._h, n, h, w, ci, k, k, cop, 1, ctypes.byref(ops[0]), ctypes.byref(bad)) != 0
+
+
 def test_maxpool_and_layout(hip_ctx):
     g = torch.Generator().manual_seed(2)
     x = torch.randn((2, 3, 10, 14), generator=g).cuda()
