@@ -27,6 +27,7 @@
 // Round 4: 3x3 / 7x7 layers with whole 128-channel output blocks run on the spatial-tile kernels further down
 // (k_conv_tile_f32, k_conv_tile_bf16x3: the tile's input region held in LDS across the taps, weights in operand order from L1);
 // the per-tap kernels here keep the 1x1 layers, the 64-channel-output layers and maps no tile shape fits.
+#include <cstdlib>
 #include <cstring>
 
 #include "st_internal.h"
@@ -476,7 +477,9 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x3_tile(const float* _
 // NW: waves per workgroup -- 4 (128 pixels, region <= 400 pixels, two workgroups per CU; the instance in use) or 8 (256 pixels,
 // region <= 800, one per CU; level with it from 16 frames per call on, behind it below -- not instantiated); the same bits, the
 // accumulation order does not depend on the tile
-template <int KS, int NW>
+// MT: 32-pixel instruction tiles per wave -- 2 (a wave owns 64 pixels x 64 channels) or 1 (32 x 64: half the serial work per
+// wave and twice the workgroups, for launches of a few frames)
+template <int KS, int NW, int MT = 2>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a) {
   const ConvTileOperands& o = a.op[blockIdx.z];
   constexpr int T = KS * KS, THREADS = NW * 64;
@@ -527,12 +530,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
     }
   };
 
-  // the wave's 64 pixels x 64 output channels: 2 x 2 instruction tiles
-  const int wm = (wv >> 1) * 64;
+  // the wave's 32 MT pixels x 64 output channels: MT x 2 instruction tiles
+  const int wm = (wv >> 1) * 32 * MT;
   const int npix = a.th * a.tw;
-  int abase[2];
+  int abase[MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
     int p = wm + 32 * i + l31;
     if (p >= npix) p = npix - 1;   // rows of the instruction tile beyond the spatial tile: computed, never stored
     const int ty = p / a.tw;
@@ -541,15 +544,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
   // weights of (slice, tap) q for this wave: 6 x 1 KB, lane-contiguous
   const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(o.w3t) + ((size_t)blockIdx.y * S * T) * 768 + (wv & 1) * 384 + lane;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 na[3][2], nb[2][2][3];   // pixels of the next tap; weights of the next two taps (a tap's 768 matrix cycles do not cover an L2 round trip)
+  uint4 na[3][MT], nb[2][2][3];   // pixels of the next tap; weights of the next two taps (a tap's 768 matrix cycles do not cover an L2 round trip)
   auto loadB = [&](int stage, int q) {
     const uint4* __restrict__ src = wq + (size_t)q * 768;
 #pragma unroll
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
   };
   auto readA = [&](int buf, int tapoff) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
       // recomputed per tap: hoisted out of the slice loop, the 2 T offsets do not fit the registers, and their scratch reloads
       // would wait (vmcnt) for the weight loads just issued
       int ab = abase[i];
@@ -584,41 +587,38 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
     const bool more = s + 1 < S;   // uniform
 #pragma clang loop unroll(full)
     for (int tap = 0; tap < T; ++tap) {
-      bf16x8 af[3][2], bfr[3][2];
+      bf16x8 af[3][MT], bfr[3][2];
 #pragma unroll
-      for (int sp = 0; sp < 3; ++sp)
+      for (int sp = 0; sp < 3; ++sp) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          af[sp][i] = __builtin_bit_cast(bf16x8, na[sp][i]);
-          bfr[sp][i] = __builtin_bit_cast(bf16x8, nb[0][i][sp]);
-          nb[0][i][sp] = nb[1][i][sp];
+        for (int i = 0; i < MT; ++i) af[sp][i] = __builtin_bit_cast(bf16x8, na[sp][i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bfr[sp][j] = __builtin_bit_cast(bf16x8, nb[0][j][sp]);
+          nb[0][j][sp] = nb[1][j][sp];
         }
-      // The tap's 24 matrix instructions, each followed by ONE piece of the work for later taps, pinned in this order
-      // (sched_barrier): a matrix instruction occupies the pipe for 32 cycles after it issues, so the wave's own loads and
-      // address arithmetic placed behind it are free, while the same instructions in one clump at the head of the tap leave the pipe
-      // to the SIMD's other wave alone.  Pieces: 0-5 the six weight loads of tap + 2 (unconditional: the last two taps
-      // re-request the last tap's weights, so the code is straight-line and the three operand sets rotate by renaming),
-      // 6-11 the six region reads of tap + 1, 12 the request of a region item of the next slice, 13-17 its split and stores.
+      }
+      // The tap's 12 MT matrix instructions, each followed by ONE piece (two where there are more pieces than instructions) of
+      // the work for later taps, pinned in this order (sched_barrier): a matrix instruction occupies the pipe for 32 cycles
+      // after it issues, so the wave's own loads and address arithmetic placed behind it are free, while the same
+      // instructions in one clump at the head of the tap leave the pipe to the SIMD's other wave alone.  Pieces: 0-5 the six
+      // weight loads of tap + 2 (unconditional: the last two taps re-request the last tap's weights, so the code is
+      // straight-line and the three operand sets rotate by renaming), then the 3 MT region reads of tap + 1, the request of a
+      // region item of the next slice, its split and stores (5).
       const int q2 = s * T + tap + 2;
       const uint4* __restrict__ wsrc = wq + (size_t)(q2 < nq ? q2 : nq - 1) * 768;
-      int ao[2] = {0, 0};
+      int ao[MT] = {};
       const bool item_load = tap % IGAP == 0 && tap / IGAP < CT_ITEMS;   // constants after unrolling
       const bool item_store = tap >= ILAT && (tap - ILAT) % IGAP == 0 && (tap - ILAT) / IGAP < CT_ITEMS;
       const int li = item_load ? tap / IGAP : 0, si = item_store ? (tap - ILAT) / IGAP : 0;
       unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < 24; ++k) {
-        const int term = k >> 2, i = (k >> 1) & 1, j = k & 1;
-        const int sa = (term == 0 || term == 1 || term == 4) ? 0 : (term == 5 ? 2 : 1);
-        const int sb = (term == 0 || term == 2 || term == 5) ? 0 : (term == 4 ? 2 : 1);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sa][i], bfr[sb][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k < 6) {
-          nb[1][k / 3][k % 3] = wsrc[k * 64];
-        } else if (k < 12) {
+      constexpr int NMF = 12 * MT, PA = 6, PI = PA + 3 * MT, NPIECE = PI + 6;
+      auto piece = [&](int p) {
+        if (p < PA) {
+          nb[1][p / 3][p % 3] = wsrc[p * 64];
+        } else if (p < PI) {
           if (tap + 1 < T) {
-            const int i2 = (k - 6) / 3, sp = (k - 6) % 3;
+            const int i2 = (p - PA) / 3, sp = (p - PA) % 3;
             if (sp == 0) {
               int rw = a.rw, ab = abase[i2];
               asm volatile("" : "+s"(rw));   // recomputed per tap: hoisted out of the slice loop the 2 T offsets do not fit the
@@ -627,17 +627,29 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
             }
             na[sp][i2] = *reinterpret_cast<const uint4*>(&Ar[buf][sp][0] + ao[i2]);
           }
-        } else if (k == 12) {
+        } else if (p == PI) {
           if (item_load && more)
             rg[li % NRG] = (inb >> li) & 1 ? *reinterpret_cast<const float4*>(ximg + goff[li] + 16 * (s + 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else if (item_store && more && ((exists >> si) & 1)) {
           const float4 v = rg[si % NRG];
-          if (k == 13) split3(v.x, v.y, h0, m0, l0);
-          if (k == 14) split3(v.z, v.w, h1, m1, l1);
-          if (k == 15) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][0][0] + loff[si]) = make_uint2(h0, h1);
-          if (k == 16) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][1][0] + loff[si]) = make_uint2(m0, m1);
-          if (k == 17) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][2][0] + loff[si]) = make_uint2(l0, l1);
+          if (p == PI + 1) split3(v.x, v.y, h0, m0, l0);
+          if (p == PI + 2) split3(v.z, v.w, h1, m1, l1);
+          if (p == PI + 3) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][0][0] + loff[si]) = make_uint2(h0, h1);
+          if (p == PI + 4) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][1][0] + loff[si]) = make_uint2(m0, m1);
+          if (p == PI + 5) *reinterpret_cast<uint2*>(&Ar[buf ^ 1][2][0] + loff[si]) = make_uint2(l0, l1);
         }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NMF; ++k) {
+        const int term = k / (2 * MT), i = (k >> 1) % MT, j = k & 1;
+        const int sa = (term == 0 || term == 1 || term == 4) ? 0 : (term == 5 ? 2 : 1);
+        const int sb = (term == 0 || term == 2 || term == 5) ? 0 : (term == 4 ? 2 : 1);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sa][i], bfr[sb][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // pieces in order, spread evenly over the instructions (dependent ones -- split before store -- stay in sequence)
+#pragma unroll
+        for (int p2 = k * NPIECE / NMF; p2 < (k + 1) * NPIECE / NMF; ++p2) piece(p2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_bf16x3(ConvTileArgs a)
   // bias (+ ReLU), float32 store of the pixels inside the tile and the image
   const int wn = (wv & 1) * 64;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_f32_tile(const float* __re
   }
 }
 
-template <int KS, int NW>
+template <int KS, int NW, int MT = 2>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
   const ConvTileOperands& o = a.op[blockIdx.z];
   constexpr int T = KS * KS, THREADS = NW * 64, CTF_RPS = NW == 8 ? 818 : 418;   // plane strides = 2 mod 16
@@ -736,11 +748,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
     }
   };
 
-  const int wm = (wv >> 1) * 64;
+  const int wm = (wv >> 1) * 32 * MT;
   const int npix = a.th * a.tw;
-  int abase[2];
+  int abase[MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
     int p = wm + 32 * i + l31;
     if (p >= npix) p = npix - 1;
     const int ty = p / a.tw;
@@ -748,15 +760,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
   }
   const uint4* __restrict__ wq = reinterpret_cast<const uint4*>(o.w3t) + ((size_t)blockIdx.y * S * T) * 512 + (wv & 1) * 256 + lane;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float na[2][8];      // pixels of the next tap: [instruction tile][step]
+  float na[MT][8];     // pixels of the next tap: [instruction tile][step]
   uint4 nb[2][2];      // weights of the next tap: [column tile][4-step group]
   auto loadB = [&](int q) {
     const uint4* __restrict__ src = wq + (size_t)q * 512;
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
   };
   auto readA = [&](int buf, int tapoff) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
       int ab = abase[i];
       asm volatile("" : "+v"(ab));
       const float* __restrict__ src = &Af[buf][0][0] + ab + tapoff;
@@ -788,35 +800,33 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
     const bool more = s + 1 < S;   // uniform
 #pragma clang loop unroll(full)
     for (int tap = 0; tap < T; ++tap) {
-      float af[2][8], bfr[2][8];
+      float af[MT][8], bfr[2][8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          af[i][kk] = na[i][kk];
-          const uint4 v = nb[i][kk >> 2];
-          bfr[i][kk] = __uint_as_float((kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w);
+        for (int i = 0; i < MT; ++i) af[i][kk] = na[i][kk];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 v = nb[j][kk >> 2];
+          bfr[j][kk] = __uint_as_float((kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w);
         }
-      // 32 matrix instructions, each followed by one pinned piece of the work for the next tap (k_conv_tile_bf16x3): 0-3 the
-      // four weight loads of tap + 1 (unconditional, clamped), 4-19 the sixteen region reads of tap + 1, 20 the request of a
-      // region item of the next slice, 21 its four stores
+      }
+      // 16 MT matrix instructions with the pieces of the work for the next tap spread between them in order
+      // (k_conv_tile_bf16x3): the four weight loads of tap + 1 (unconditional, clamped), the 8 MT region reads of tap + 1, the
+      // request of a region item of the next slice, its four stores
       const int q1 = s * T + tap + 1;
       const uint4* __restrict__ wsrc = wq + (size_t)(q1 < nq ? q1 : nq - 1) * 512;
-      const float* asrc[2] = {nullptr, nullptr};
+      const float* asrc[MT] = {};
       const bool item_load = tap % IGAP == 0 && tap / IGAP < CT_ITEMS;   // constants after unrolling
       const bool item_store = tap >= ILAT && (tap - ILAT) % IGAP == 0 && (tap - ILAT) / IGAP < CT_ITEMS;
       const int li = item_load ? tap / IGAP : 0, si = item_store ? (tap - ILAT) / IGAP : 0;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int kk = k >> 2, i = (k >> 1) & 1, j = k & 1;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bfr[j][kk], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k < 4) {
-          nb[k >> 1][k & 1] = wsrc[k * 64];
-        } else if (k < 20) {
+      constexpr int NMF = 16 * MT, PA = 4, PI = PA + 8 * MT, NPIECE = PI + 2;
+      auto piece = [&](int p) {
+        if (p < PA) {
+          nb[p >> 1][p & 1] = wsrc[p * 64];
+        } else if (p < PI) {
           if (tap + 1 < T) {
-            const int i2 = (k - 4) >> 3, k2 = (k - 4) & 7;
+            const int i2 = (p - PA) >> 3, k2 = (p - PA) & 7;
             if (k2 == 0) {
               int rw = a.rw, ab = abase[i2];
               asm volatile("" : "+s"(rw));   // recomputed per tap (see k_conv_tile_bf16x3)
@@ -825,12 +835,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
             }
             na[i2][k2] = asrc[i2][2 * k2 * CTF_RPS];
           }
-        } else if (k == 20) {
+        } else if (p == PI) {
           if (item_load && more)
             rg[li % NRG] = (inb >> li) & 1 ? *reinterpret_cast<const float4*>(ximg + goff[li] + 16 * (s + 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (k == 21) {
+        } else {
           if (item_store && more) stash_from(buf ^ 1, si, rg[si % NRG]);
         }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NMF; ++k) {
+        const int kk = k / (2 * MT), i = (k >> 1) % MT, j = k & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bfr[j][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p2 = k * NPIECE / NMF; p2 < (k + 1) * NPIECE / NMF; ++p2) piece(p2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -840,7 +859,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_tile_f32(ConvTileArgs a) {
 
   const int wn = (wv & 1) * 64;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -883,30 +902,38 @@ bool conv_tile_plan(int h, int w, int ks, int maxpx, int rpmax, int* th, int* tw
 
 bool conv_tile_weights(int kh, int kw, int cout_pad, int cin) { return kh == kw && (kh == 3 || kh == 7) && cout_pad % 128 == 0 && cin % 16 == 0; }
 
-// Which kernel a 3x3 / 7x7 layer with whole 128-channel output blocks runs on: 8 = the 8-wave tile kernel (256-pixel tiles, one
-// workgroup per CU) when its launch fills three quarters of the chip, else 4 = the 4-wave instance (128-pixel tiles, two per
-// CU: twice the workgroups -- 46x82, 7x7, 128 -> 128, 5 frames: bf16x3 0.20 against 0.36 ms (per-tap kernel 0.44), float32
-// 0.42 against 0.77 (0.62); from 16 frames on the two are equal), 0 = the per-tap kernel (no tile shape fits).  Fills the
-// geometry of `ta`.  Every choice accumulates an output in the same order, so none changes a bit; ST_CONV_TILE=0 forces the
-// per-tap kernel, 1 the 8-wave tile kernel wherever a tile shape exists, 4 the 4-wave one.  The 8-wave instance exists for the
-// float32 instruction only (`allow8`): there it is 2.7 % ahead over the network at 32 frames per call (247 against 240
-// frames/s); in bf16x3 the 4-wave instance is level or ahead at every size (419 against 416), and each instance of that kernel
-// is half a minute of compile time.
+// Which kernel a 3x3 / 7x7 layer with whole 128-channel output blocks runs on, by launch size: 8 = the 8-wave tile kernel (256-pixel
+// tiles, one workgroup per CU; float32 only, `allow8`: there it is 2.7 % ahead over the network at 32 frames per call, in
+// bf16x3 the 4-wave instance is level or ahead at every size) when its launch fills three quarters of the chip; else 4 = the
+// 4-wave instance (128-pixel tiles, two per CU: 46x82, 7x7, 128 -> 128, 5 frames: bf16x3 0.20 against 0.36 ms (per-tap kernel
+// 0.44), float32 0.42 against 0.77 (0.62)); else, when even that leaves CUs idle, 41 = four waves with ONE 32-pixel instruction
+// tile each (64-pixel tiles: half the serial work per wave, twice the workgroups; 1 frame: bf16x3 0.10 against 0.17 ms);
+// 0 = the per-tap kernel (no tile shape fits).  Fills the geometry of `ta`.  Every choice accumulates an output in the same
+// order, so none changes a bit; ST_CONV_TILE=0 forces the per-tap kernel, 1 / 4 / 41 the instance of that name wherever a
+// tile shape exists.
 int conv_tile_choose(st_ctx* ctx, int n, int h, int w, int kh, int kw, int cout_pad, int cin, bool allow8, ConvTileArgs* ta) {
   if (ctx->conv_tile == 0 || !conv_tile_weights(kh, kw, cout_pad, cin)) return 0;
-  int th8 = 0, tw8 = 0, th4 = 0, tw4 = 0;
-  double e8 = 0, e4 = 0;
+  int th8 = 0, tw8 = 0, th4 = 0, tw4 = 0, th2 = 0, tw2 = 0;
+  double e8 = 0, e4 = 0, e2 = 0;
   const bool ok8 = allow8 && conv_tile_plan(h, w, kh, 256, CT_RPMAX, &th8, &tw8, &e8);
   const bool ok4 = conv_tile_plan(h, w, kh, 128, CT_RPMAX / 2, &th4, &tw4, &e4);
+  const bool ok2 = conv_tile_plan(h, w, kh, 64, CT_RPMAX / 2, &th2, &tw2, &e2);   // 4 waves x one 32-pixel instruction tile
   auto wgs = [&](int th, int tw) { return (long long)n * ((w + tw - 1) / tw) * ((h + th - 1) / th) * (cout_pad / 128); };
+  // below this many 4-wave workgroups per 100 CUs a wave takes one 32-pixel instruction tile instead of two (measured over the
+  // network, frames per call 1 / 2 / 5 / 8: bf16x3 129 / 230 / 304 / 400 frames/s without, 162 / 279 / 332 / 399 with; float32
+  // 68 / 126 / 161 / 236 and 102 / 183 / 184 / 235); ST_CONV_MT1_PCT moves the line (experiments)
+  static const int mt1_pct = getenv("ST_CONV_MT1_PCT") ? atoi(getenv("ST_CONV_MT1_PCT")) : 150;
   int nw = 0;
   if (ctx->conv_tile == 1) nw = ok8 ? 8 : (ok4 ? 4 : 0);
   else if (ctx->conv_tile == 4) nw = ok4 ? 4 : (ok8 ? 8 : 0);
+  else if (ctx->conv_tile == 41) nw = ok2 ? 41 : (ok4 ? 4 : 0);
   else if (ok8 && wgs(th8, tw8) >= (long long)ctx->num_cus * 3 / 4) nw = 8;
+  else if (ok4 && (!ok2 || wgs(th4, tw4) * 100 >= (long long)ctx->num_cus * mt1_pct)) nw = 4;
+  else if (ok2) nw = 41;
   else if (ok4) nw = 4;
   else if (ok8) nw = 8;
   if (!nw) return 0;
-  const int th = nw == 8 ? th8 : th4, tw = nw == 8 ? tw8 : tw4;
+  const int th = nw == 8 ? th8 : (nw == 4 ? th4 : th2), tw = nw == 8 ? tw8 : (nw == 4 ? tw4 : tw2);
   ta->n = n; ta->h = h; ta->wd = w; ta->cin = cin; ta->pad = kh / 2;
   ta->th = th; ta->tw = tw; ta->rw = tw + kh - 1; ta->rp = (th + kh - 1) * (tw + kh - 1);
   ta->tiles_x = (w + tw - 1) / tw; ta->tiles_y = (h + th - 1) / th;
@@ -1014,11 +1041,15 @@ int conv_launch(st_ctx* ctx, bool f32, int n, int h, int w, int cin, int kh, int
     st_timed t(ctx, ST_K_CONV);
     if (f32) {
       if (kh == 7 && nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<7, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+      else if (kh == 7 && nw == 41) hipLaunchKernelGGL((k_conv_tile_f32<7, 4, 1>), tgrid, dim3(256), 0, ctx->stream, ta);
       else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_f32<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
       else if (nw == 8) hipLaunchKernelGGL((k_conv_tile_f32<3, 8>), tgrid, dim3(512), 0, ctx->stream, ta);
+      else if (nw == 41) hipLaunchKernelGGL((k_conv_tile_f32<3, 4, 1>), tgrid, dim3(256), 0, ctx->stream, ta);
       else hipLaunchKernelGGL((k_conv_tile_f32<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     } else {
-      if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+      if (kh == 7 && nw == 41) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4, 1>), tgrid, dim3(256), 0, ctx->stream, ta);
+      else if (kh == 7) hipLaunchKernelGGL((k_conv_tile_bf16x3<7, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
+      else if (nw == 41) hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4, 1>), tgrid, dim3(256), 0, ctx->stream, ta);
       else hipLaunchKernelGGL((k_conv_tile_bf16x3<3, 4>), tgrid, dim3(256), 0, ctx->stream, ta);
     }
     ST_HIP(ctx, hipGetLastError());

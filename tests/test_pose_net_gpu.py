@@ -57,6 +57,8 @@ def _conv(hip_ctx, x_nhwc, cin, xoff, wt, b, relu, cout_total=None, yoff=0, math
     y = torch.full((n, h, w, ys), -7.0, dtype=torch.float32, device="cuda")
     if math.endswith("_pertap"):
         hip_ctx, math = _pertap_ctx(), math[:-7]
+    elif math.endswith("_tile41"):
+        hip_ctx, math = _mode_ctx("41"), math[:-7]   # 4 waves x one 32-pixel instruction tile (bf16x3; float32: the 4-wave instance)
     elif math.endswith("_tile4"):
         hip_ctx, math = _mode_ctx("4"), math[:-6]
     else:
@@ -162,6 +164,7 @@ def test_conv_tile_random_shapes(hip_ctx, math):
         assert float((got - ref).abs().max()) <= 2e-5 * scale, msg
         assert torch.equal(y, yp), msg    # the per-tap kernels accumulate in the tile kernels' order: the same bits
         assert torch.equal(y, _conv(hip_ctx, x.cuda(), ci, xoff, wt, b, 1, cout_total=ys, yoff=4, math=math + "_tile4")), msg
+        assert torch.equal(y, _conv(hip_ctx, x.cuda(), ci, xoff, wt, b, 1, cout_total=ys, yoff=4, math=math + "_tile41")), msg
         assert (y[..., :4] == -7.0).all() and (y[..., 4 + co:] == -7.0).all(), msg
 
 
@@ -264,13 +267,13 @@ def test_network_bits_do_not_depend_on_the_kernel_choice(hip_ctx, math):
     g = torch.Generator().manual_seed(33)
     x = torch.rand((6, 3, 96, 128), generator=g) - 0.5
     outs = {}
-    for name, ctx in (("auto", hip_ctx), ("tile", _mode_ctx("1")), ("pertap", _mode_ctx("0")), ("tile4", _mode_ctx("4"))):
+    for name, ctx in (("auto", hip_ctx), ("tile", _mode_ctx("1")), ("pertap", _mode_ctx("0")), ("tile4", _mode_ctx("4")), ("tile41", _mode_ctx("41"))):
         net = pose_net.PoseNet(ctx, seed=8, math=math)
         outs[name] = net.forward(x.cuda()).cpu()
         if name == "auto":
             outs["single"] = net.forward(x[2:3].cuda()).cpu()
         del net
-    assert torch.equal(outs["auto"], outs["tile"]) and torch.equal(outs["auto"], outs["pertap"]) and torch.equal(outs["auto"], outs["tile4"])
+    assert torch.equal(outs["auto"], outs["tile"]) and torch.equal(outs["auto"], outs["pertap"]) and torch.equal(outs["auto"], outs["tile4"]) and torch.equal(outs["auto"], outs["tile41"])
     assert torch.equal(outs["single"][0], outs["auto"][2])
 
 
