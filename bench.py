@@ -433,6 +433,25 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                     "parity": {"what": "same network on a 1x3x48x80 input vs torch float32 on the CPU",
                                "max_abs": float((got3 - ref5).abs().max()), "ref_max_abs": float(ref5.abs().max()),
                                "max_abs_vs_f32_kernels": float((got3 - got5).abs().max())}}
+                # the chain at the call sizes a drop-in graph uses (the reference's test: batch=5; a single frame), both arithmetics
+                small5 = {}
+                for nb_s in (1, 5):
+                    fr_s = fr5[:nb_s]
+                    for tag, nt in (("f32", net), ("bf16x3", net3)):
+                        def step_s():
+                            m_, j_ = nt.detect(ctx.cpm2_input(fr_s, sc5))
+                            return ctx.cpm2_limb_scores(m_, j_)
+                        step_s()
+                        sync()
+                        t0 = time.perf_counter()
+                        for _ in range(4):
+                            step_s()
+                        sync()
+                        small5["%s_frames_per_call_%d" % (tag, nb_s)] = nb_s * 4 / (time.perf_counter() - t0)
+                small5["what"] = ("frames/s of the same chain at 1 and 5 frames per call (the reference's test runs the op with batch=5): "
+                                  "the library then runs smaller tile instances and pairs the two branches of a stage in one launch; "
+                                  "a frame's maps are the same bits at every call size")
+                out["config5_pose_conv_stack"]["small_calls"] = small5
                 del net3
             except Exception as e:  # auxiliary record
                 out["config5_pose_conv_stack"]["bf16x3"] = {"error": repr(e)}
