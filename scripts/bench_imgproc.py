@@ -9,7 +9,7 @@ ctx = HipContext(0)
 n, h, w = int(os.environ.get("N", 64)), 1080, 1920
 g = torch.Generator(device="cuda").manual_seed(0)
 frames = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
-for k in (3, 5, 15):
+for k in (3, 5, 7, 9, 11, 13, 15, 17):
     out = ctx.box_blur(frames, k)
     ctx.timing_enable([_native.K_BLUR_OP]); ctx.timing_reset()
     for _ in range(10):

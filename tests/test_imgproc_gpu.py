@@ -13,7 +13,7 @@ from util import random_frames, texture_stream
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 15, 31])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 11, 15, 31])
 @pytest.mark.parametrize("h,w", [(37, 53), (64, 344), (120, 683)])
 def test_box_blur_matches_oracle(hip_ctx, h, w, k):
     frames = random_frames(h + w + k, 3, h, w)
@@ -28,7 +28,7 @@ def test_box_blur_shapes(hip_ctx, h, w):
     """Frames smaller than the window (no interior at all), the reference test clip's size, 1080p;
     rows that are not dword aligned (3*w % 4 != 0)."""
     frames = random_frames(h * w, 2, h, w)
-    for k in (3, 7):
+    for k in (3, 7, 9, 11):
         got = hip_ctx.box_blur(torch.from_numpy(frames).cuda(), k).cpu().numpy()
         for i in range(2):
             np.testing.assert_array_equal(got[i], oracle.box_blur(frames[i], k))
