@@ -51,23 +51,31 @@ inline void result_error(Result* r, const char* fmt, ...) {
 }
 #define RESULT_ERROR(result__, ...) ::scanner::result_error((result__), __VA_ARGS__)
 
-// glog-style fatal logging as the reference kernels use it (LOG(FATAL) << ..., LOG_IF(FATAL, c))
-struct FatalStream {
+// glog-style logging as the reference kernels use it (LOG(FATAL) << ..., LOG_IF(FATAL, c), LOG(WARNING) << ...):
+// every severity prints to stderr, FATAL aborts.
+struct LogStream {
   std::string text;
   bool active;
-  explicit FatalStream(bool a) : active(a) {}
-  template <typename T> FatalStream& operator<<(const T& v) { if (active) append(v); return *this; }
+  int severity;
+  LogStream(bool a, int sev) : active(a), severity(sev) {}
+  template <typename T> LogStream& operator<<(const T& v) { if (active) append(v); return *this; }
   void append(const char* s) { text += s; }
   void append(const std::string& s) { text += s; }
   template <typename T> void append(const T& v) { text += std::to_string(v); }
-  ~FatalStream() {
-    if (active) { fprintf(stderr, "FATAL: %s\n", text.c_str()); abort(); }
+  ~LogStream() {
+    if (!active) return;
+    static const char* const names[4] = {"INFO", "WARNING", "ERROR", "FATAL"};
+    fprintf(stderr, "%s: %s\n", names[severity < 0 || severity > 3 ? 3 : severity], text.c_str());
+    if (severity >= 3) abort();
   }
 };
 #ifndef LOG
+#define INFO 0
+#define WARNING 1
+#define ERROR 2
 #define FATAL 3
-#define LOG(severity) ::scanner::FatalStream(true)
-#define LOG_IF(severity, cond) ::scanner::FatalStream(static_cast<bool>(cond))
+#define LOG(severity) ::scanner::LogStream(true, severity)
+#define LOG_IF(severity, cond) ::scanner::LogStream(static_cast<bool>(cond), severity)
 #endif
 
 }  // namespace scanner

@@ -20,5 +20,7 @@ void delete_buffer(DeviceHandle device, u8* buffer);  // releases one reference
 void memcpy_buffer(u8* dest, DeviceHandle dest_device, const u8* src, DeviceHandle src_device, size_t size);
 // shim-only introspection used by the tests: live allocations / references per device type
 size_t shim_live_buffers(DeviceType type);
+size_t shim_dev_pool_bytes();          // bytes idle in the device-buffer pool
+size_t shim_dev_pool_drain(int device);  // give them back to the driver (all devices if < 0); bytes released
 
 }  // namespace scanner

@@ -90,12 +90,61 @@ void host_free(u8* p) {
 
 // Device buffers come from a pool too (Scanner's workers allocate element buffers from pooled blocks, not from the
 // driver): a hipMalloc + hipFree pair per execute() costs tens of microseconds, which is a tenth of a single-pair
-// OpticalFlow call.  Same reuse rule as the host pool; capped.
+// OpticalFlow call.  Same reuse rule as the host pool.  The pool is bounded (SCANNER_SHIM_DEV_POOL_MB, default 4096; 0
+// turns it off), drained when the driver runs out of memory (a job that changes its batch or frame size, or shares the GPU
+// with another allocator, must not die while idle blocks sit here) and at process exit.
+// Ownership rule (Scanner's own for its pooled element buffers): whoever frees a buffer has finished with it -- a kernel's
+// execute() returns with its inputs consumed and its outputs complete (every kernel class of this library synchronises
+// its stream before it returns), so no queued work touches a block when it comes back here.  hipFree would ALSO have
+// synchronised the whole device; a pooled block does not, deliberately: a device-wide wait at every free would serialise
+// the concurrent kernel instances of one process (pipeline_instances_per_node > 1).  SCANNER_SHIM_DEV_POOL_SYNC=1
+// restores hipFree's guarantee (hipDeviceSynchronize before a block is pooled) for code that does not keep the rule.
 struct DevBlock { u8* p; size_t size; int device; };
 std::vector<DevBlock> g_dev_pool;                   // free blocks
 std::map<uintptr_t, DevBlock> g_dev_live;           // blocks handed out
 size_t g_dev_pooled_bytes = 0;
-constexpr size_t kDevPoolCap = (size_t)16 << 30;
+
+size_t dev_pool_cap() {
+  static const size_t cap = [] {
+    const char* e = getenv("SCANNER_SHIM_DEV_POOL_MB");
+    const long long mb = e && *e ? atoll(e) : 4096;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+  }();
+  return cap;
+}
+
+// Returns every pooled block of `device` (any device if < 0) to the driver; the number of bytes released.
+size_t drain_dev_pool(int device) {
+  std::vector<DevBlock> out;
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    for (size_t i = 0; i < g_dev_pool.size();) {
+      if (device < 0 || g_dev_pool[i].device == device) {
+        out.push_back(g_dev_pool[i]);
+        g_dev_pooled_bytes -= g_dev_pool[i].size;
+        g_dev_pool.erase(g_dev_pool.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+  }
+  size_t bytes = 0;
+  for (auto& b : out) {
+    (void)hipSetDevice(b.device);
+    (void)hipFree(b.p);
+    bytes += b.size;
+  }
+  return bytes;
+}
+
+struct DevPoolAtExit {
+  ~DevPoolAtExit() {
+    // the HIP runtime may already be shutting down: release what it still lets us release, ignore the rest
+    int n = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0) (void)drain_dev_pool(-1);
+    (void)hipGetLastError();
+  }
+} g_dev_pool_at_exit;
 
 u8* raw_alloc(DeviceHandle device, size_t size) {
   void* p = nullptr;
@@ -114,7 +163,20 @@ u8* raw_alloc(DeviceHandle device, size_t size) {
       }
     }
     LOG_IF(FATAL, hipSetDevice(device.id) != hipSuccess) << "hipSetDevice failed";
-    LOG_IF(FATAL, hipMalloc(&p, size) != hipSuccess) << "hipMalloc failed";
+    hipError_t e = hipMalloc(&p, size);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      // out of memory with idle blocks in the pool: give them back (this device's first, then every device's -- another
+      // device's blocks do not help this allocation, but a second failure is fatal and must not be avoidable)
+      if (drain_dev_pool(device.id) > 0) e = hipMalloc(&p, size);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)drain_dev_pool(-1);
+        (void)hipSetDevice(device.id);
+        e = hipMalloc(&p, size);
+      }
+    }
+    LOG_IF(FATAL, e != hipSuccess) << "hipMalloc of " << size << " bytes failed: " << hipGetErrorString(e);
     std::lock_guard<std::mutex> lk(g_mem_mutex);
     g_dev_live[(uintptr_t)p] = DevBlock{(u8*)p, size, device.id};
   } else {
@@ -126,26 +188,37 @@ u8* raw_alloc(DeviceHandle device, size_t size) {
 void raw_free(DeviceHandle device, u8* p) {
   if (device.type == DeviceType::GPU) {
     DevBlock b{p, 0, device.id};
+    bool pool = false;
     {
       std::lock_guard<std::mutex> lk(g_mem_mutex);
       auto it = g_dev_live.find((uintptr_t)p);
       if (it != g_dev_live.end()) {
         b = it->second;
         g_dev_live.erase(it);
-        if (g_dev_pooled_bytes + b.size <= kDevPoolCap) {
-          g_dev_pool.push_back(b);
-          g_dev_pooled_bytes += b.size;
-          return;
-        }
+        pool = b.size <= dev_pool_cap() && g_dev_pooled_bytes + b.size <= dev_pool_cap();
       }
     }
     (void)hipSetDevice(device.id);
+    if (pool) {
+      static const bool sync_on_free = [] { const char* e = getenv("SCANNER_SHIM_DEV_POOL_SYNC"); return e && *e && *e != '0'; }();
+      if (sync_on_free) (void)hipDeviceSynchronize();  // hipFree's guarantee, on request (see above)
+      std::lock_guard<std::mutex> lk(g_mem_mutex);
+      g_dev_pool.push_back(b);
+      g_dev_pooled_bytes += b.size;
+      return;
+    }
     (void)hipFree(p);
   } else {
     host_free(p);
   }
 }
 }  // namespace
+
+size_t shim_dev_pool_bytes() {
+  std::lock_guard<std::mutex> lk(g_mem_mutex);
+  return g_dev_pooled_bytes;
+}
+size_t shim_dev_pool_drain(int device) { return drain_dev_pool(device); }
 
 u8* new_block_buffer(DeviceHandle device, size_t size, i32 refs) {
   u8* p = raw_alloc(device, size);
@@ -569,3 +642,7 @@ SHIM_EXPORT double stshim_last_steady_seconds(int* rows) {
 }
 
 SHIM_EXPORT size_t stshim_live_buffers(int device_type) { return shim_live_buffers((DeviceType)device_type); }
+
+// Device-buffer pool: bytes idle in it / give them back to the driver (all devices if device < 0); returns bytes released.
+SHIM_EXPORT size_t stshim_dev_pool_bytes() { return shim_dev_pool_bytes(); }
+SHIM_EXPORT size_t stshim_dev_pool_drain(int device) { return shim_dev_pool_drain(device); }

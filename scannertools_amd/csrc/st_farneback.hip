@@ -1257,6 +1257,9 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
 // before consuming any (memory-level parallelism): um_issue computes the gather address and
 // issues the 2 R0 loads (float4 + float) and the 6 R1 loads (four float4 + two 8-byte pairs of
 // channel 4); um_finish does the arithmetic, bit-identical to update_matrices_px.
+#ifndef ST_ABLATE
+#define ST_ABLATE 0
+#endif
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct UmLoads {
@@ -1289,12 +1292,17 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   const unsigned single = 16u * (unsigned)np;  // byte offset of the channel-4 plane
   L.q = ldf4(R0, 16u * o);
   L.qs = ldf(R0, single + 4u * o);
-  L.t0 = ldf4(R1, 16u * gi);
-  L.t1 = ldf4(R1, 16u * gi + 16u);
+  // ST_ABLATE 16 / 64 (experiments, wrong results): what perfect lane sharing (no second-column loads) and a perfect
+  // row carry (no top-row loads) would save -- the upper bound of any texel-reuse scheme (profiles/NOTES.md, round 5)
+  if (!(ST_ABLATE & 64)) {
+    L.t0 = ldf4(R1, 16u * gi);
+    if (ST_ABLATE & 16) L.t1 = L.t0; else L.t1 = ldf4(R1, 16u * gi + 16u);
+  }
   L.b0 = ldf4(R1, 16u * gb);
-  L.b1 = ldf4(R1, 16u * gb + 16u);
-  L.ts = ldf2(R1, single + 4u * gi);
+  if (ST_ABLATE & 16) L.b1 = L.b0; else L.b1 = ldf4(R1, 16u * gb + 16u);
+  if (!(ST_ABLATE & 64)) L.ts = ldf2(R1, single + 4u * gi);
   L.bs = ldf2(R1, single + 4u * gb);
+  if (ST_ABLATE & 64) { L.t0 = L.b0; L.t1 = L.b1; L.ts = L.bs; }
 }
 
 __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x, int y, float2 f, float m[5]) {
@@ -1720,9 +1728,7 @@ __global__ __launch_bounds__(B2_T, WAVES) void k_blur_update_v2(BlurArgs a) {
 // ST_ABLATE (build-time bit mask, experiments only -- results are then meaningless): 4 = k_flow_iter3
 // without its expansion loads.  Timing a build with a part removed shows what that part costs in place
 // (profiles/README.md lists the round-2 ablations of the previous kernel generation).
-#ifndef ST_ABLATE
-#define ST_ABLATE 0
-#endif
+
 #ifndef ST_EXP_D
 #define ST_EXP_D 1  // gather queue depth of k_flow_iter3 (experiments)
 #endif

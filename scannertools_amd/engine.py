@@ -100,6 +100,10 @@ def _load_op_library(path):
         L.stshim_profiler_intervals.restype = ci
         L.stshim_profiler_intervals.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         L.stshim_live_buffers.argtypes = [ci]
+        L.stshim_dev_pool_bytes.restype = sz
+        L.stshim_dev_pool_bytes.argtypes = []
+        L.stshim_dev_pool_drain.restype = sz
+        L.stshim_dev_pool_drain.argtypes = [ci]
         _LIBS[path] = L
     return _LIBS[path]
 
@@ -726,3 +730,11 @@ class Client:
 
     def live_device_buffers(self):
         return _imgproc().stshim_live_buffers(DeviceType.GPU)
+
+    def device_pool_bytes(self):
+        """Bytes idle in the engine's device-buffer pool (scanner_shim/shim.cpp)."""
+        return _imgproc().stshim_dev_pool_bytes()
+
+    def drain_device_pool(self, device=-1):
+        """Returns the pool's idle blocks to the driver (all devices by default); bytes released."""
+        return _imgproc().stshim_dev_pool_drain(device)

@@ -15,13 +15,13 @@ def _run(sc, name, suffix, build):
     return out
 
 
-def compute_histograms(sc, videos, device=DeviceType.GPU, batch=64):
-    """old/histograms.py:10-15: Histogram(frame, device, batch); rows read with
-    scannertools_amd.types.histograms (3 x int32[16])."""
+def compute_histograms(sc, videos, device=DeviceType.GPU, batch=1):
+    """old/histograms.py:10-15: Histogram(frame, device, batch), ``batch=1`` by default as there; rows read with
+    scannertools_amd.types.histograms (3 x int32[16]).  ``batch=64`` and up is what fills the GPU from one instance."""
     return [_run(sc, v, 'hist', lambda f: sc.ops.Histogram(frame=f, device=device, batch=batch)) for v in videos]
 
 
-def compute_hsv_histograms(sc, videos, device=DeviceType.GPU, batch=64):
+def compute_hsv_histograms(sc, videos, device=DeviceType.GPU, batch=1):
     """old/histograms.py:32-37: RGB -> HSV conversion, then Histogram.  The reference's
     ConvertToHSVCPP op is cv::cvtColor(COLOR_RGB2HSV) (old/cpp_ops/imgproc.cpp:41): one pass of the
     ConvertColor op of this library with the same code."""
@@ -31,13 +31,17 @@ def compute_hsv_histograms(sc, videos, device=DeviceType.GPU, batch=64):
     return [_run(sc, v, 'hsv_hist', build) for v in videos]
 
 
-def compute_flow_histograms(sc, videos, device=DeviceType.GPU, batch=32, width=426, height=240):
+def compute_flow_histograms(sc, videos, device=DeviceType.GPU, batch=None, width=426, height=240, hist_device=None):
     """old/histograms.py:63-78: Resize(426 x 240) -> OpticalFlow -> FlowHistogram; rows read with
-    scannertools_amd.types.flow_histograms (2 x int32[64])."""
+    scannertools_amd.types.flow_histograms (2 x int32[64]).  No op gets a ``batch=`` by default, as there; the reference
+    runs FlowHistogram on ``DeviceType.CPU`` (:76-78) -- pass ``hist_device=DeviceType.CPU`` for that placement (the
+    flow field then crosses PCIe); the default keeps it on the device the flow was computed on."""
+    kw = {} if batch is None else {'batch': batch}
+
     def build(f):
-        small = sc.ops.Resize(frame=f, device=device, width=width, height=height, batch=batch)
-        flow = sc.ops.OpticalFlow(frame=small, device=device, batch=batch)
-        return sc.ops.FlowHistogram(flow=flow, device=device, batch=batch)
+        small = sc.ops.Resize(frame=f, device=device, width=width, height=height, **kw)
+        flow = sc.ops.OpticalFlow(frame=small, device=device, **kw)
+        return sc.ops.FlowHistogram(flow=flow, device=hist_device if hist_device is not None else device, **kw)
     return [_run(sc, v, 'flow_hist', build) for v in videos]
 
 

@@ -9,12 +9,16 @@ anything with the same ``io/ops/streams/run`` surface) and returns one flow stre
 from .engine import CacheMode, DeviceType, NamedStream, NamedVideoStream, PerfParams
 
 
-def build_pipeline(sc, frame_sampled, device=DeviceType.GPU, batch=32):
-    """old/optical_flow.py:19-24."""
+def build_pipeline(sc, frame_sampled, device=DeviceType.GPU, batch=None):
+    """old/optical_flow.py:19-24.  As there, no ``batch=`` reaches the op by default: Scanner then hands the kernel one
+    row (one pair) per ``execute()``.  ``batch=N`` is the speed switch of this build (N pairs per call fill the GPU from
+    one kernel instance; without it a Scanner graph fills it with ``pipeline_instances_per_node`` -- DESIGN.md 4.9)."""
+    if batch is None:
+        return {'flow': sc.ops.OpticalFlow(frame=frame_sampled, device=device)}
     return {'flow': sc.ops.OpticalFlow(frame=frame_sampled, device=device, batch=batch)}
 
 
-def compute_flow(sc, videos, frames=None, device=DeviceType.GPU, batch=32, suffix='flow'):
+def compute_flow(sc, videos, frames=None, device=DeviceType.GPU, batch=None, suffix='flow'):
     """videos: names of ingested video streams; frames: optional list (one per video) of frame
     indices to sample (the reference's ``frames=`` argument, prelude.py:267-287).  Returns a list of
     NamedStream, one per video, whose rows are (h, w, 2) float32 flow fields: row i is the flow from

@@ -169,27 +169,112 @@ def layers_from_prototxt(path):
 
 
 def names_from_prototxt(path):
-    """Checks that the prototxt describes the network the kernels implement -- the same 92 convolutions in the same order
-    with the same channel counts, kernel sizes and activations, pooling after conv1_2 / conv2_2 / conv3_4, stage inputs
-    concat(L1, L2, features) -- and returns its layer names in all_layers() order (a model with other layer NAMES and
-    the same structure is usable).  Raises ValueError naming the first difference."""
+    """Checks that the prototxt describes the network the kernels implement and returns its layer names in all_layers()
+    order (a model with other layer NAMES and the same structure is usable).  The layers are identified by walking the
+    blobs from the input, not by their position in the file: the published ``pose_deploy_linevec.prototxt`` ([EXT])
+    interleaves the two branches of a stage layer by layer (``conv5_1_CPM_L1``, ``conv5_1_CPM_L2``, ``conv5_2_CPM_L1`` ...)
+    where all_layers() lists branch L1, then L2.  Trunk = the single chain of convolutions / poolings from the input to
+    the blob two convolutions read; a stage = the two chains behind that blob, told apart by their output counts (38 = L1,
+    19 = L2); next stage input = the Concat of (L1, L2, features), in that order (the order the weights are packed for).
+    Raises ValueError naming the first difference."""
     convs, pools = layers_from_prototxt(path)
     arch = all_layers()
     if len(convs) != len(arch):
         raise ValueError("prototxt %s describes %d convolutions, the kernels implement %d" % (path, len(convs), len(arch)))
-    for (pname, ci, co, k, relu, _, _), (aname, aci, aco, ak, arelu) in zip(convs, arch):
+    if len(pools) != 3:
+        raise ValueError("prototxt %s has %d pooling layers, the kernels implement 3" % (path, len(pools)))
+    net = parse_prototxt(open(path).read())
+    readers, pool_of, concats, alias = {}, {}, [], {}
+    layers = net.get("layer", []) + net.get("layers", [])
+    for layer in layers:      # a ReLU that is not in place renames its blob
+        if str(layer.get("type", [""])[0]) in ("ReLU", "RELU") and layer["top"][0] != layer["bottom"][0]:
+            alias[layer["top"][0]] = layer["bottom"][0]
+
+    def blob(b):
+        while b in alias:
+            b = alias[b]
+        return b
+
+    for c in convs:
+        readers.setdefault(blob(c[5]), []).append(c)
+    for layer in layers:
+        typ = str(layer.get("type", [""])[0])
+        if typ in ("Pooling", "POOLING"):
+            pool_of[blob(layer["bottom"][0])] = layer["top"][0]
+        elif typ in ("Concat", "CONCAT"):
+            concats.append(([blob(b) for b in layer.get("bottom", [])], layer["top"][0]))
+
+    def expect(conv, spec):
+        aname, aci, aco, ak, arelu = spec
+        pname, ci, co, k, relu = conv[:5]
         if (ci, co, k, relu) != (aci, aco, ak, arelu):
             raise ValueError("prototxt layer %s is a %dx%d convolution %d -> %d (relu %d); the kernels implement %s as %dx%d %d -> %d (relu %d)"
                              % (pname, k, k, ci, co, relu, aname, ak, ak, aci, aco, arelu))
-    if len(pools) != 3:
-        raise ValueError("prototxt %s has %d pooling layers, the kernels implement 3" % (path, len(pools)))
-    return [c[0] for c in convs]
+
+    def only_reader(blob, after):
+        rs = readers.get(blob, [])
+        if len(rs) != 1:
+            raise ValueError("prototxt %s: %d convolutions read blob %r behind %s; the kernels implement a single chain there" % (path, len(rs), blob, after))
+        return rs[0]
+
+    it = iter(arch)
+    names = []
+    if "input" in net:
+        cur = net["input"][0]
+    else:
+        cur = next((l["top"][0] for l in layers if str(l.get("type", [""])[0]) == "Input"), None)
+    last = "the input"
+    for l in TRUNK:
+        if l == "pool":
+            if cur not in pool_of:
+                raise ValueError("prototxt %s: no pooling layer behind %s; the kernels pool there" % (path, last))
+            cur = pool_of[cur]
+        else:
+            if cur in pool_of and readers.get(cur) is None:
+                raise ValueError("prototxt %s pools behind %s; the kernels do not" % (path, last))
+            c = only_reader(cur, last)
+            expect(c, next(it))
+            names.append(c[0])
+            cur, last = c[6], c[0]
+    feat = cur
+    src = feat
+    for st in range(1, 7):
+        heads = readers.get(src, [])
+        if len(heads) != 2:
+            raise ValueError("prototxt %s: %d convolutions read the input of stage %d (blob %r); the kernels implement two branches" % (path, len(heads), st, src))
+        depth = len(branch_layers(st, 1))
+        chains = []
+        for head in heads:
+            chain = [head]
+            while len(chain) < depth:
+                chain.append(only_reader(chain[-1][6], chain[-1][0]))
+            chains.append(chain)
+        by_out = {ch[-1][2]: ch for ch in chains}
+        if set(by_out) != {N_PAF, N_HEAT}:
+            raise ValueError("prototxt %s: the branches of stage %d end in %s outputs; the kernels implement %d (L1) and %d (L2)"
+                             % (path, st, sorted(ch[-1][2] for ch in chains), N_PAF, N_HEAT))
+        for n in (N_PAF, N_HEAT):
+            for c in by_out[n]:
+                expect(c, next(it))
+                names.append(c[0])
+        if st < 6:
+            want = [by_out[N_PAF][-1][6], by_out[N_HEAT][-1][6], feat]
+            cat = [top for bottoms, top in concats if sorted(bottoms) == sorted(want)]
+            if not cat:
+                raise ValueError("prototxt %s: no Concat of the two branches of stage %d and the features" % (path, st))
+            order = next(bottoms for bottoms, top in concats if top == cat[0])
+            if order != want:
+                raise ValueError("prototxt %s: stage %d's input concatenates %s; the kernels implement the order (L1, L2, features) = %s" % (path, st + 1, order, want))
+            src = cat[0]
+    return names
 
 
-def write_prototxt(path, names=None):
+def write_prototxt(path, names=None, interleaved=False):
     """The deploy description of the built-in architecture in the published model's naming (pose_deploy_linevec.prototxt, [EXT])
     -- input, trunk with ReLU and pooling layers, six two-branch stages with their concatenations; used by tests and the
-    benchmark next to write_caffemodel."""
+    benchmark next to write_caffemodel.  ``names`` are given in all_layers() order.  ``interleaved=True`` writes the two
+    branches of a stage layer by layer (L1's first, L2's first, L1's second ...), the order of the published file; the
+    default writes branch L1, then branch L2."""
     names = names or caffe_layer_names()
     it = iter(names)
     out = ['name: "pose"', 'input: "image"', "input_dim: 1", "input_dim: 3", "input_dim: 368", "input_dim: 656"]
@@ -214,14 +299,18 @@ def write_prototxt(path, names=None):
     feat = cur
     for st in range(1, 7):
         src = feat if st == 1 else "concat_stage%d" % st
-        ends = []
+        ends, entries = [], []
         for br, n in (("L1", N_PAF), ("L2", N_HEAT)):
-            cur = src
+            cur, mine = src, []
             for (ci, co, k, r) in branch_layers(st, n):
                 name = next(it)
-                conv(name, cur, name, co, k, r)
+                mine.append((name, cur, name, co, k, r))
                 cur = name
             ends.append(cur)
+            entries.append(mine)
+        order = [e for pair in zip(*entries) for e in pair] if interleaved else entries[0] + entries[1]
+        for e in order:
+            conv(*e)
         if st < 6:
             out.append('layer { name: "concat_stage%d" type: "Concat" bottom: "%s" bottom: "%s" bottom: "%s" top: "concat_stage%d" concat_param { axis: 1 } }'
                        % (st + 1, ends[0], ends[1], feat, st + 1))

@@ -96,7 +96,16 @@ class OpenPoseKernelHIPImpl : public BatchedKernel, public VideoKernel {
     // the deploy description beside the weights (OpenPose's own file layout), when the directory holds it
     std::string proto = args_.model_directory + "/pose/coco/pose_deploy_linevec.prototxt", probe;
     if (!pose::read_file(proto, &probe)) proto.clear();
-    if (!net_.load(args_.model_directory + "/pose/coco/pose_iter_440000.caffemodel", &err, proto)) RESULT_ERROR(&valid_, "OpenPose: %s", err.c_str());
+    const std::string model = args_.model_directory + "/pose/coco/pose_iter_440000.caffemodel";
+    bool loaded = net_.load(model, &err, proto);
+    if (!loaded && !proto.empty()) {
+      // The description was found by probing, not named by the caller (OpenPoseArgs has no field for it): a file this
+      // reader cannot follow must not make a model unusable that loads by the published layer names.
+      std::string err2;
+      loaded = net_.load(model, &err2);
+      if (loaded) LOG(WARNING) << "OpenPose: ignoring " << proto << " (" << err << "); weights loaded by the published layer names";
+    }
+    if (!loaded) RESULT_ERROR(&valid_, "OpenPose: %s", err.c_str());
     for (int c = 0; c < 57; ++c) chan_[c] = c < pose::kHeat ? pose::kOffHeat + c : pose::kOffPaf + (c - pose::kHeat);
   }
   ~OpenPoseKernelHIPImpl() {

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <map>
 #include <string>
@@ -163,12 +164,18 @@ inline std::vector<LayerSpec> all_layers() {
 // implement ONE architecture; what the file is used for is (i) refusing a description of another network and (ii) the
 // layer NAMES the weights are looked up by (scannertools_amd/pose_net.py: names_from_prototxt does the same check with
 // the channel counts walked through the blobs).
-struct ProtoConv {
-  std::string name;
+struct ProtoLayer {
+  std::string name, type;
+  std::vector<std::string> bottoms, tops;
   int cout = 0, k = 1;
+  bool conv() const { return type == "Convolution" || type == "CONVOLUTION"; }
+  bool relu() const { return type == "ReLU" || type == "RELU"; }
+  bool pool() const { return type == "Pooling" || type == "POOLING"; }
+  bool concat() const { return type == "Concat" || type == "CONCAT"; }
 };
 
-inline bool prototxt_convolutions_impl(const std::string& text, std::vector<ProtoConv>* out, std::string* err) {
+// Every layer of the description in file order (name, type, blobs, convolution parameters) and the net-level `input:`.
+inline bool prototxt_layers_impl(const std::string& text, std::vector<ProtoLayer>* out, std::string* net_input, std::string* err) {
   // tokens: identifiers / numbers, quoted strings, '{', '}', ':'; '#' starts a comment
   std::vector<std::string> tok;
   for (size_t i = 0; i < text.size();) {
@@ -191,8 +198,7 @@ inline bool prototxt_convolutions_impl(const std::string& text, std::vector<Prot
   }
   // walk the nesting: path of open message fields; remember the fields of the current top-level layer
   std::vector<std::string> path;
-  ProtoConv cur;
-  std::string type;
+  ProtoLayer cur;
   for (size_t i = 0; i < tok.size(); ++i) {
     const std::string& t = tok[i];
     if (t == "}") {
@@ -200,9 +206,8 @@ inline bool prototxt_convolutions_impl(const std::string& text, std::vector<Prot
       const bool layer_end = path.size() == 1 && (path[0] == "layer" || path[0] == "layers");
       path.pop_back();
       if (layer_end) {
-        if (type == "Convolution" || type == "CONVOLUTION") out->push_back(cur);
-        cur = ProtoConv();
-        type.clear();
+        out->push_back(cur);
+        cur = ProtoLayer();
       }
       continue;
     }
@@ -219,8 +224,11 @@ inline bool prototxt_convolutions_impl(const std::string& text, std::vector<Prot
     std::string v = tok[j];
     if (!v.empty() && v[0] == '"') v = v.substr(1);
     const bool in_layer = !path.empty() && (path[0] == "layer" || path[0] == "layers");
+    if (path.empty() && t == "input" && net_input->empty()) *net_input = v;
     if (in_layer && path.size() == 1 && t == "name") cur.name = v;
-    if (in_layer && path.size() == 1 && t == "type") type = v;
+    if (in_layer && path.size() == 1 && t == "type") cur.type = v;
+    if (in_layer && path.size() == 1 && t == "bottom") cur.bottoms.push_back(v);
+    if (in_layer && path.size() == 1 && t == "top") cur.tops.push_back(v);
     if (in_layer && path.size() == 2 && path[1] == "convolution_param") {
       if (t == "num_output") cur.cout = atoi(v.c_str());
       if (t == "kernel_size" || t == "kernel_h") cur.k = atoi(v.c_str());
@@ -232,26 +240,128 @@ inline bool prototxt_convolutions_impl(const std::string& text, std::vector<Prot
 }
 
 // Names of the 92 convolutions of `path` in all_layers() order; false (with the first difference in *err) if the file is
-// unreadable or describes another network.
+// unreadable or describes another network.  The layers are identified by walking the blobs from the input, NOT by their
+// position in the file: the published pose_deploy_linevec.prototxt ([EXT]) interleaves the two branches of a stage layer
+// by layer (conv5_1_CPM_L1, conv5_1_CPM_L2, conv5_2_CPM_L1 ...) where all_layers() lists branch L1, then branch L2.
+// Trunk = the single chain of convolutions / poolings from the input to the blob two convolutions read; a stage = the two
+// chains behind that blob, told apart by their output counts (38 = L1, 19 = L2); the next stage reads the Concat of
+// (L1, L2, features) in that order -- the order load() packs the weights for.
 inline bool prototxt_layer_names(const std::string& path, std::vector<std::string>* names, std::string* err) try {
   std::string text;
   if (!read_file(path, &text)) { *err = "cannot read " + path; return false; }
-  std::vector<ProtoConv> convs;
-  if (!prototxt_convolutions_impl(text, &convs, err)) { *err += " (" + path + ")"; return false; }
+  std::vector<ProtoLayer> layers;
+  std::string cur;
+  if (!prototxt_layers_impl(text, &layers, &cur, err)) { *err += " (" + path + ")"; return false; }
   const std::vector<LayerSpec> arch = all_layers();
-  if (convs.size() != arch.size()) {
-    *err = "prototxt " + path + " describes " + std::to_string(convs.size()) + " convolutions, the kernels implement " + std::to_string(arch.size());
+  size_t nconv = 0;
+  for (auto& l : layers) nconv += l.conv();
+  if (nconv != arch.size()) {
+    *err = "prototxt " + path + " describes " + std::to_string(nconv) + " convolutions, the kernels implement " + std::to_string(arch.size());
     return false;
   }
-  names->clear();
-  for (size_t i = 0; i < arch.size(); ++i) {
-    if (convs[i].cout != arch[i].cout || convs[i].k != arch[i].k) {
-      *err = "prototxt layer " + convs[i].name + " is a " + std::to_string(convs[i].k) + "x" + std::to_string(convs[i].k) + " convolution with " +
-             std::to_string(convs[i].cout) + " outputs; the kernels implement " + arch[i].name + " as " + std::to_string(arch[i].k) + "x" +
-             std::to_string(arch[i].k) + " with " + std::to_string(arch[i].cout);
+  std::map<std::string, std::string> alias, pool_of;   // a ReLU that is not in place renames its blob
+  for (auto& l : layers)
+    if (l.relu() && !l.bottoms.empty() && !l.tops.empty() && l.tops[0] != l.bottoms[0]) alias[l.tops[0]] = l.bottoms[0];
+  auto blob = [&](std::string b) {
+    for (int guard = 0; guard < 1000 && alias.count(b); ++guard) b = alias[b];
+    return b;
+  };
+  std::map<std::string, std::vector<const ProtoLayer*>> readers;
+  std::vector<const ProtoLayer*> concats;
+  for (auto& l : layers) {
+    if ((l.conv() || l.pool() || l.concat()) && (l.bottoms.empty() || l.tops.empty())) {
+      *err = "prototxt layer " + l.name + " names no bottom / top blob (" + path + ")";
       return false;
     }
-    names->push_back(convs[i].name);
+    if (l.conv()) readers[blob(l.bottoms[0])].push_back(&l);
+    if (l.pool()) pool_of[blob(l.bottoms[0])] = l.tops[0];
+    if (l.concat()) concats.push_back(&l);
+    if (cur.empty() && l.type == "Input" && !l.tops.empty()) cur = l.tops[0];
+  }
+  auto matches = [&](const ProtoLayer& c, const LayerSpec& a) {
+    if (c.cout == a.cout && c.k == a.k) return true;
+    *err = "prototxt layer " + c.name + " is a " + std::to_string(c.k) + "x" + std::to_string(c.k) + " convolution with " + std::to_string(c.cout) +
+           " outputs; the kernels implement " + a.name + " as " + std::to_string(a.k) + "x" + std::to_string(a.k) + " with " + std::to_string(a.cout);
+    return false;
+  };
+  auto only_reader = [&](const std::string& b, const std::string& after) -> const ProtoLayer* {
+    auto it = readers.find(b);
+    const size_t n = it == readers.end() ? 0 : it->second.size();
+    if (n == 1) return it->second[0];
+    *err = "prototxt " + path + ": " + std::to_string(n) + " convolutions read blob " + b + " behind " + after + "; the kernels implement a single chain there";
+    return nullptr;
+  };
+  names->clear();
+  const std::vector<LayerSpec> trunk = trunk_layers();
+  std::string last = "the input";
+  for (size_t i = 0; i < trunk.size(); ++i) {
+    const ProtoLayer* c = only_reader(cur, last);
+    if (!c || !matches(*c, trunk[i])) return false;
+    names->push_back(c->name);
+    cur = c->tops[0];
+    last = c->name;
+    const bool pooled = pool_of.count(cur) && !readers.count(cur);
+    if (pooled != pool_after((int)i)) {
+      *err = "prototxt " + path + (pooled ? " pools behind " : " does not pool behind ") + last + "; the kernels " + (pooled ? "do not" : "do");
+      return false;
+    }
+    if (pooled) cur = pool_of[cur];
+  }
+  const std::string feat = cur;
+  std::string src = feat;
+  for (int st = 1; st <= 6; ++st) {
+    auto it = readers.find(src);
+    const size_t nh = it == readers.end() ? 0 : it->second.size();
+    if (nh != 2) {
+      *err = "prototxt " + path + ": " + std::to_string(nh) + " convolutions read the input of stage " + std::to_string(st) + " (blob " + src + "); the kernels implement two branches";
+      return false;
+    }
+    const size_t depth = branch_layers(st, 1).size();
+    std::vector<const ProtoLayer*> chain[2];
+    for (int b = 0; b < 2; ++b) {
+      chain[b].push_back(it->second[b]);
+      while (chain[b].size() < depth) {
+        const ProtoLayer* nx = only_reader(chain[b].back()->tops[0], chain[b].back()->name);
+        if (!nx) return false;
+        chain[b].push_back(nx);
+      }
+    }
+    const int o0 = chain[0].back()->cout, o1 = chain[1].back()->cout;
+    if (!((o0 == kPaf && o1 == kHeat) || (o0 == kHeat && o1 == kPaf))) {
+      *err = "prototxt " + path + ": the branches of stage " + std::to_string(st) + " end in " + std::to_string(o0) + " and " + std::to_string(o1) +
+             " outputs; the kernels implement " + std::to_string(kPaf) + " (L1) and " + std::to_string(kHeat) + " (L2)";
+      return false;
+    }
+    const std::vector<const ProtoLayer*>* by_branch[2] = {o0 == kPaf ? &chain[0] : &chain[1], o0 == kPaf ? &chain[1] : &chain[0]};
+    for (int br = 1; br <= 2; ++br) {
+      const std::vector<LayerSpec> spec = branch_layers(st, br);
+      for (size_t i = 0; i < depth; ++i) {
+        if (!matches(*(*by_branch[br - 1])[i], spec[i])) return false;
+        names->push_back((*by_branch[br - 1])[i]->name);
+      }
+    }
+    if (st < 6) {
+      const std::vector<std::string> want = {by_branch[0]->back()->tops[0], by_branch[1]->back()->tops[0], feat};
+      const ProtoLayer* cat = nullptr;
+      for (auto* c : concats) {
+        std::vector<std::string> got;
+        for (auto& b : c->bottoms) got.push_back(blob(b));
+        std::vector<std::string> a = got, w = want;
+        std::sort(a.begin(), a.end());
+        std::sort(w.begin(), w.end());
+        if (a != w) continue;
+        cat = c;
+        if (got != want) {
+          *err = "prototxt " + path + ": " + c->name + " concatenates (" + got[0] + ", " + got[1] + ", " + got[2] + "); the kernels implement the order (L1, L2, features)";
+          return false;
+        }
+      }
+      if (!cat) {
+        *err = "prototxt " + path + ": no Concat of the two branches of stage " + std::to_string(st) + " and the features";
+        return false;
+      }
+      src = cat->tops[0];
+    }
   }
   return true;
 } catch (const std::exception& e) {

@@ -496,6 +496,34 @@ def test_prototxt_is_read_and_checked(tmp_path):
     assert pose_net.check_prototxt(proto2, model) == 92
     with pytest.raises(ValueError, match="L00_conv1_1|no weights"):
         pose_net.check_prototxt(proto, model)            # the published names are not in that file
+    # the published file's layout: the two branches of a stage interleaved layer by layer (conv5_1_CPM_L1, conv5_1_CPM_L2,
+    # conv5_2_CPM_L1 ...) -- the layers are found by walking the blobs, not by their position in the file
+    inter, inter2 = tmp_path / "interleaved.prototxt", tmp_path / "interleaved_renamed.prototxt"
+    pose_net.write_prototxt(inter, interleaved=True)
+    lines = inter.read_text().splitlines()
+    at = next(i for i, ln in enumerate(lines) if '"conv5_1_CPM_L1"' in ln and "Convolution" in ln)
+    assert '"conv5_1_CPM_L2"' in lines[at + 2] and '"conv5_2_CPM_L1"' in lines[at + 4]
+    assert pose_net.names_from_prototxt(inter) == pose_net.caffe_layer_names() and pose_net.check_prototxt(inter) == 92
+    pose_net.write_prototxt(inter2, names=renamed, interleaved=True)
+    assert pose_net.names_from_prototxt(inter2) == renamed and pose_net.check_prototxt(inter2, model) == 92
+    # ... with the L2 branch written first, and a ReLU that is not in place
+    swapped = tmp_path / "swapped.prototxt"
+    blocks = inter.read_text().splitlines()
+    l1 = next(i for i, ln in enumerate(blocks) if '"Mconv1_stage4_L1"' in ln and "Convolution" in ln)
+    blocks[l1:l1 + 4] = blocks[l1 + 2:l1 + 4] + blocks[l1:l1 + 2]
+    txt = "\n".join(blocks).replace('name: "relu_conv3_2" type: "ReLU" bottom: "conv3_2" top: "conv3_2"', 'name: "relu_conv3_2" type: "ReLU" bottom: "conv3_2" top: "conv3_2_relu"')
+    txt = txt.replace('name: "conv3_3" type: "Convolution" bottom: "conv3_2"', 'name: "conv3_3" type: "Convolution" bottom: "conv3_2_relu"')
+    assert "conv3_2_relu" in txt
+    swapped.write_text(txt + "\n")
+    assert pose_net.names_from_prototxt(swapped) == pose_net.caffe_layer_names() and pose_net.check_prototxt(swapped) == 92
+    # the stage input concatenated in another order than the weights are packed for: refused, not silently mis-bound
+    catswap = tmp_path / "catswap.prototxt"
+    catswap.write_text(inter.read_text().replace('bottom: "conv5_5_CPM_L1" bottom: "conv5_5_CPM_L2" bottom: "conv4_4_CPM"',
+                                                 'bottom: "conv5_5_CPM_L2" bottom: "conv5_5_CPM_L1" bottom: "conv4_4_CPM"'))
+    assert catswap.read_text() != inter.read_text()
+    for check in (pose_net.names_from_prototxt, pose_net.check_prototxt):
+        with pytest.raises(ValueError, match="order"):
+            check(catswap)
     # another network: one layer fewer / another kernel size / another width
     text = proto.read_text()
     short = tmp_path / "short.prototxt"
