@@ -198,6 +198,62 @@ def timed_flow_hist(torch, ctx, _native, batches, B, bins, steps, warmup, barrie
     return dt, launches, ms
 
 
+def concurrent_instances(torch, device, frames, h, w, bins, ks=(1, 2, 4, 8), pairs=(1, 8)):
+    """Aggregate frames/s of K concurrent kernel instances (K contexts, K streams, K host threads) each making
+    Histogram + OpticalFlow calls of b pairs, one stream sync per call."""
+    from scannertools_amd.hip import HipContext
+    rec = {"what": "K instances x (Histogram + OpticalFlow of b pairs per call, st_ctx_sync after every call: the kernel classes' "
+                   "execute()), K host threads, one context and one stream each, 1080p device frames; frames/s over all instances"}
+    nfr = len(frames)
+    for b in pairs:
+        if b + 1 > nfr:
+            continue
+        calls = max(12, 96 // b)
+        by_k = {}
+        for K in ks:
+            ctxs = [HipContext(device.index) for _ in range(K)]
+            flows = [torch.empty((b, h, w, 2), dtype=torch.float32, device=device) for _ in range(K)]
+            hists = [torch.empty((b, 3, bins), dtype=torch.int32, device=device) for _ in range(K)]
+            barrier, done, errors = threading.Barrier(K + 1), [0.0] * K, []
+
+            def worker(k):
+                try:
+                    stream = torch.cuda.Stream(device)
+                    with torch.cuda.stream(stream):
+                        for i in range(calls + 2):
+                            if i == 2:          # two warm-up calls (scratch allocation), then all instances start together
+                                barrier.wait()
+                            j = (i * b + 7 * k) % (nfr - b)
+                            ctxs[k].histogram(frames[j:j + b], bins, out=hists[k])
+                            ctxs[k].optical_flow(frames[j:j + b + 1], out=flows[k])
+                            ctxs[k].sync()
+                    done[k] = time.perf_counter()
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(repr(e))
+                    barrier.abort()
+
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+            for t in th:
+                t.start()
+            try:
+                barrier.wait()
+            except threading.BrokenBarrierError:
+                pass
+            t0 = time.perf_counter()
+            for t in th:
+                t.join()
+            for c in ctxs:
+                c.close()
+            del flows, hists
+            if errors:
+                by_k["K_%d" % K] = {"error": errors[0]}
+                break
+            dt = max(done) - t0
+            by_k["K_%d" % K] = {"frames_per_s": K * calls * b / dt, "ms_per_call": dt / calls * 1e3}
+        rec["pairs_per_call_%d" % b] = by_k
+    return rec
+
+
 def extras(torch, ctx, _native, device, args, batches, hist_out):
     """Records that are not `value`: each has its own timed loop, run after the headline."""
     out = {}
@@ -291,6 +347,16 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         torch.cuda.empty_cache()
     except Exception as e:  # auxiliary record
         out["optical_flow_small_batches"] = {"error": repr(e)}
+
+    # (iv-b) what an UNCHANGED reference graph gets with pipeline_instances_per_node = K (scannertools/tests/test_all.py:45,231):
+    # K kernel instances in one process, each with its own context and stream on its own host thread, each call ending in
+    # a stream sync as OpticalFlowKernelHIP::execute / HistogramKernelHIP::execute do.  1 pair per call is the reference's
+    # own pattern (no batch= on the op), 8 pairs a modest batch=.
+    try:
+        out["concurrent_instances"] = concurrent_instances(torch, device, batches[0], h, w, bins)
+        torch.cuda.empty_cache()
+    except Exception as e:  # auxiliary record
+        out["concurrent_instances"] = {"error": repr(e)}
 
     try:
         # (i) config 4: OpticalFlow at 4K, batch 32 (BASELINE.json configs[3])
@@ -624,10 +690,9 @@ def run_rank(args):
             dt = float(t.item())
             # the same evidence fields as the real line: the collective's own count of ranks, one device per rank, every
             # rank's time
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (rank, "cpu:%d" % rank, my_ms))
-            gathered.sort()
-            devices, rank_ms = [g_[1] for g_ in gathered], [g_[2] for g_ in gathered]
+            from scannertools_amd.sharding import rank_table
+            table = rank_table("cpu:%d" % rank, args.batch * args.steps, my_ms, "bench.py --dry-run", require_distinct=True)
+            devices, rank_ms = [t_["device"] for t_ in table], [t_["ms"] for t_ in table]
             one = torch.ones(1, dtype=torch.int32)
             ones = [torch.zeros_like(one) for _ in range(world)]
             dist.all_gather(ones, one)
@@ -692,19 +757,14 @@ def run_rank(args):
 
     # multi-GPU evidence: what the collective library itself saw (an all_gather of one int per rank), the PCI bus id of
     # every rank's device, and every rank's own time per step
-    def device_id_string(dev):
-        pr = torch.cuda.get_device_properties(dev)
-        bus = getattr(pr, "pci_bus_id", None)
-        if bus is not None:
-            return "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), bus, getattr(pr, "pci_device_id", 0))
-        return str(getattr(pr, "uuid", dev))
-    my_dev, my_ms = device_id_string(device), dt_rank / args.steps * 1e3
+    from scannertools_amd.sharding import device_id_string, rank_table
+    my_dev, my_ms = device_id_string(torch, device), dt_rank / args.steps * 1e3
     rccl_world, devices, rank_ms = 1, [my_dev], [my_ms]
     if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (rank, my_dev, my_ms))
-        gathered.sort()
-        devices, rank_ms = [g_[1] for g_ in gathered], [g_[2] for g_ in gathered]
+        # rank 0 prints the table on stderr; N ranks on fewer than N devices is an error on every rank unless the run is
+        # the declared self-test (ST_BENCH_SHARE_GPU=1)
+        table = rank_table(my_dev, B * args.steps, my_ms, "bench.py", require_distinct=not share)
+        devices, rank_ms = [t_["device"] for t_ in table], [t_["ms"] for t_ in table]
         one = torch.ones(1, dtype=torch.int32, device="cpu" if share else device)
         ones = [torch.zeros_like(one) for _ in range(world)]
         dist.all_gather(ones, one)
@@ -788,6 +848,7 @@ def run_rank(args):
             "devices": devices,
             "distinct_devices": len(set(devices)),
             "ms_per_step_by_rank": rank_ms,
+            "frames_by_rank": [B * args.steps] * world,
             "flow_whole_path_frac_of_peak": fps / world * flow_model_bytes / 1e9 / HBM_PEAK_GBS,
             "data": "synthetic",
             "config": {

@@ -168,3 +168,42 @@ def gather_rows(local, n_total, dst=0, group=None):
         if rank != dst:
             return None
     return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(world)], dim=0)
+
+
+def device_id_string(torch, dev):
+    """PCI bus id of a torch device (domain:bus:device), or its uuid where the properties carry no bus id."""
+    pr = torch.cuda.get_device_properties(dev)
+    bus = getattr(pr, "pci_bus_id", None)
+    if bus is not None:
+        return "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), bus, getattr(pr, "pci_device_id", 0))
+    return str(getattr(pr, "uuid", dev))
+
+
+def rank_table(device, frames, ms, what="", require_distinct=False, stream=None):
+    """The per-rank evidence of a multi-GPU run: every rank contributes (its device id, the frames it processed, its own
+    time in ms); returns the list of {"rank", "device", "frames", "ms"} in rank order ON EVERY RANK, prints it as a table on
+    rank 0 (stderr by default, so that a launcher's single JSON line stays alone on stdout), and -- when
+    `require_distinct` -- raises RuntimeError on every rank if two ranks ran on the same device (a mis-set
+    LOCAL_RANK / visible-device mask would otherwise produce a plausible-looking "N GPU" number from fewer GPUs).
+    Works without a process group (one row)."""
+    import torch.distributed as dist
+    rank, world = 0, 1
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    mine = (rank, str(device), int(frames), float(ms))
+    rows = [mine]
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        rows.sort()
+    table = [{"rank": r, "device": d, "frames": f, "ms": m} for r, d, f, m in rows]
+    if rank == 0:
+        out = stream or sys.stderr
+        out.write("%s%d rank(s)\n  rank  device            frames        ms\n" % (what + ": " if what else "", world))
+        for t in table:
+            out.write("  %4d  %-16s %7d  %9.3f\n" % (t["rank"], t["device"], t["frames"], t["ms"]))
+        out.flush()
+    distinct = len({t["device"] for t in table})
+    if require_distinct and distinct != world:
+        raise RuntimeError("%d ranks ran on %d distinct device(s): %s" % (world, distinct, [t["device"] for t in table]))
+    return table

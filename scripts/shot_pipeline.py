@@ -120,10 +120,13 @@ def main():
     a, b = shard_range(n, rank, world)
     ctx = HipContext(local)
     hist, t_hist = shard_histograms(torch, ctx, dev, a, b, h, w, args.bins, args.chunk, cuts, seed=99 + rank)
+    t_hist_rank = t_hist
     if world > 1:
         t = torch.tensor([t_hist], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_hist = float(t.item())
+    from scannertools_amd.sharding import device_id_string, rank_table
+    table = rank_table(device_id_string(torch, dev), b - a, t_hist_rank * 1e3, "shot_pipeline.py", require_distinct=world > 1 and not share)
     full = gather_rows(hist.cpu() if share and world > 1 else hist, n, dst=0)
     if full is not None and not full.is_cuda:
         full = full.to(dev)
@@ -143,6 +146,7 @@ def main():
         print(json.dumps({"frames": n, "resolution": [w, h], "n_gpus": world, "bins": args.bins,
                           "histogram_frames_per_s": n / t_hist, "shot_boundaries_s": t_sb_dev, "shot_boundaries_host_s": t_sb,
                           "pipeline_frames_per_s": n / (t_hist + t_sb_dev),
+                          "ranks": table, "distinct_devices": len({t_["device"] for t_ in table}),
                           "boundaries": res[0], "planted": cuts,
                           # the detector is a 2.5-sigma outlier test over +-500 frames: windows without a
                           # cut also flag noise peaks (so does the reference); every planted cut must be found
@@ -173,10 +177,12 @@ def dry_run(args):
         shot = int(np.searchsorted(cuts, i, side="right"))
         base = np.random.default_rng(shot).multinomial(px, np.random.default_rng(100 + shot).dirichlet(np.ones(args.bins)), 3)
         rows[i - a] = base + np.random.default_rng(10000 + i).integers(-2, 3, (3, args.bins))
+    from scannertools_amd.sharding import rank_table
+    table = rank_table("cpu:%d" % rank, b - a, 0.0, "shot_pipeline.py --dry-run", require_distinct=True)
     full = gather_rows(torch.from_numpy(rows), n, dst=0)
     if rank == 0:
         res = shot_boundaries(None, list(full.numpy()))
-        print(json.dumps({"dry_run": True, "frames": n, "n_gpus": world, "bins": args.bins, "boundaries": res[0],
+        print(json.dumps({"dry_run": True, "frames": n, "n_gpus": world, "bins": args.bins, "ranks": table, "boundaries": res[0],
                           "planted": cuts, "planted_found": all(c in res[0] for c in cuts)}), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from scannertools_amd.sharding import gather_rows, shard_range  # noqa: E402
+from scannertools_amd.sharding import gather_rows, rank_table, shard_range  # noqa: E402
 from scannertools_amd.shot_detection import shot_boundaries  # noqa: E402
 
 
@@ -27,6 +27,15 @@ def main():
         np.save(out_path, np.array(res[0], np.int64))
     else:
         assert full is None
+    # the per-rank evidence table: one row per rank in rank order on every rank; ranks that report the same device are an
+    # error on EVERY rank (no rank may go on to print a plausible "2 GPU" line)
+    table = rank_table("dev:%d" % rank, b - a, 1.5 * (rank + 1), "worker", require_distinct=True)
+    assert [t["rank"] for t in table] == list(range(world)) and [t["frames"] for t in table] == [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    try:
+        rank_table("dev:0", b - a, 1.0, "worker (same device)", require_distinct=True)
+        raise AssertionError("two ranks on one device went unnoticed")
+    except RuntimeError as e:
+        assert "distinct" in str(e)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -172,6 +172,19 @@ def test_shot_pipeline_eight_ranks():
     assert r.returncode == 0, r.stderr
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 8 and line["frames"] == 2003 and line["planted_found"] is True
+    # ... and at BASELINE config 3's own size: 10 000 frames = 1 250 per rank, the per-rank table on rank 0's stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shot_pipeline.py"), "--gpus", "8", "--dry-run",
+                        "--frames", "10000", "--height", "16", "--width", "24", "--cuts", "8"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["frames"] == 10000 and line["planted_found"] is True
+    assert [t["frames"] for t in line["ranks"]] == [1250] * 8 and len({t["device"] for t in line["ranks"]}) == 8
+    assert "8 rank(s)" in r.stderr and r.stderr.count("1250") >= 8
+    from scannertools_amd.sharding import flow_shard
+    for rk in range(8):     # the OpticalFlow shards of the same stream: 1 250 rows + 1 halo frame (none behind the last)
+        rows, frames = flow_shard(10000, rk, 8)
+        assert rows == (1250 * rk, 1250 * (rk + 1)) and frames == (1250 * rk, min(10000, 1250 * (rk + 1) + 1))
 
 
 def test_shot_pipeline_starts_its_own_ranks():
