@@ -1055,6 +1055,57 @@ __global__ __launch_bounds__(768) void k_pyr_roles(PyrFusedArgs a) {
   else pyr_role_run<2>(a, srow);
 }
 
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+// Loads address an expansion as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
+// compiler can use the SGPR-base addressing form (one VGPR per address, no 64-bit VALU math).
+// Buffer addressing: (resource over a uniform base) + (per-thread byte offset, VGPR) + (uniform byte offset, SGPR).  A
+// thread that walks down one column keeps ONE constant offset register and the row enters through the scalar operand:
+// no vector arithmetic per access (the global_load form needs base + offset assembled per access once the row term is
+// not foldable).  Raw buffers: stride 0, range-checked against `bytes` (out-of-range reads return 0, writes are dropped).
+typedef float f4v16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes), 0x00020000);
+}
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+// AUX: cache policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
+__device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, AUX);
+}
+// 16-byte store: NO scalar offset operand.  Measured on gfx950 (round 5, scripts/diag_polyexp2.py): buffer_store_dwordx4 with
+// an SGPR soffset, followed one scalar instruction later by a vector write to the first two data registers, stores the NEW
+// contents of those registers when the memory pipe is backed up (several workgroups per compute unit) -- the compiler's
+// hazard recogniser inserts wait states for >64-bit store data only when soffset is NOT a register (the documented rule).
+// With the row folded into the vector offset the store is the case the compiler protects.
+template <int AUX = 0>
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  u4 q;
+  q.x = __builtin_bit_cast(unsigned, v.x); q.y = __builtin_bit_cast(unsigned, v.y);
+  q.z = __builtin_bit_cast(unsigned, v.z); q.w = __builtin_bit_cast(unsigned, v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)voff, 0, AUX);
+}
+
+__device__ __forceinline__ float ldf(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ f2u ldf2(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// build-time experiment switches (0 in the product; ST_ABLATE is described above k_flow_iter3)
+#ifndef ST_ABLATE
+#define ST_ABLATE 0
+#endif
+#ifndef ST_F3_BUFSTORE
+#define ST_F3_BUFSTORE 0  // k_flow_iter3: unconditional buffer stores of the flow rows (experiment)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
@@ -1075,10 +1126,26 @@ constexpr int PE_RB = 4;     // rows per barrier
 constexpr int PE_OUT = 240;
 
 // One (strip bx, segment by) of frame z of one level; A carries the coefficients (a.c)
+//
+// Addressing and control flow (round 5; a tenth of the kernel's vector instructions were addresses, not arithmetic, and
+// every batch ended waiting for its own stores):
+// (i) LDS layout [pixel][row of the batch][sum] with a pixel stride of 13 words (odd: no bank conflicts): the 33 values
+//     the horizontal pass reads for a row lie within 142 words of ONE per-thread base, inside the 8-bit immediate offsets
+//     of ds_read2_b32 (before: three planes 1 KB apart -- 12 address additions per pixel); 26 KB per workgroup, six
+//     workgroups per compute unit as before.
+// (ii) Source and output rows through buffer instructions: the thread's column is a constant vector offset, the row the
+//     scalar offset (the 16-byte store takes the row in its vector offset: see bst4).
+// (iii) No branch around the horizontal pass and its stores: a lane or row that must not write is given an offset / a
+//     resource the range check rejects.  With the same eight stores behind the four prefetch loads on every path the
+//     compiler's wait for the prefetched rows counts them exactly (vmcnt(8..11)); with a branch it has to assume none
+//     was issued and waits for the batch's own stores (vmcnt retires in order).
+// Same values, same operations in the same order: bit-identical results.  Measured per 257 frames of 1080p, same box:
+// 4.38 -> 4.25 (i, ii) -> 4.21 ms (iii).
 template <int N, class A>
 __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict__ img, float* __restrict__ Rbase, int h, int w,
                                              int rows_per_seg, int bx, int by, int z) {
-  __shared__ float sv[2][PE_RB][3][256];
+  constexpr int PXW = 3 * PE_RB + 1;   // words per pixel: PE_RB rows x 3 sums + 1 pad
+  __shared__ float sv[2][256 * PXW];
   const int tid = threadIdx.x;
   const int np = h * w;
   const float* __restrict__ I = img + (size_t)z * (size_t)np;
@@ -1088,11 +1155,19 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
   const int y0 = by * rows_per_seg;
   const int y1 = min(h, y0 + rows_per_seg);
   const bool writer = tid >= N && tid < N + PE_OUT && x < w;
+  const unsigned voff = 4u * (unsigned)xc;                 // byte offset of this thread's column in a source row
+  const unsigned xo = writer ? (unsigned)x : 0u;           // output column (only writers store)
+  // non-writers: beyond any resource's range (the range check covers the vector offset only, not the scalar one)
+  const unsigned xo16 = writer ? 16u * xo : 0xf0000000u, xo4 = writer ? 4u * xo : 0xf0000000u;
+  const __amdgpu_buffer_rsrc_t Rnull = st_rsrc(R, 0);
+  const __amdgpu_buffer_rsrc_t Ib = st_rsrc(I, 4 * (size_t)np), Rb = st_rsrc(R, 20 * (size_t)np);
+  auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
+  auto src = [&](int row) { return bld1(Ib, voff, 4u * (unsigned)w * (unsigned)d_clamp(row, 0, h - 1)); };  // row: uniform
 
   // ring[j] = source row (y - N + j) of this column for the batch starting at row y
   float ring[2 * N + PE_RB];
 #pragma unroll
-  for (int j = 0; j < 2 * N + PE_RB; ++j) ring[j] = I[d_clamp(y0 - N + j, 0, h - 1) * w + xc];
+  for (int j = 0; j < 2 * N + PE_RB; ++j) ring[j] = src(y0 - N + j);
 
   int buf = 0;
   for (int y = y0; y < y1; y += PE_RB) {
@@ -1109,12 +1184,13 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
         float t2 = r1 + a.c.xg[k] * p;
         r0 = t0; r1 = t2; r2 = t1;
       }
-      sv[buf][r][0][tid] = r0; sv[buf][r][1][tid] = r1; sv[buf][r][2][tid] = r2;
+      float* __restrict__ d = &sv[buf][tid * PXW + 3 * r];
+      d[0] = r0; d[1] = r1; d[2] = r2;
     }
     // prefetch the next batch's new source rows while the exchange is in flight
     float nxt[PE_RB];
 #pragma unroll
-    for (int r = 0; r < PE_RB; ++r) nxt[r] = I[d_clamp(y + PE_RB + N + r, 0, h - 1) * w + xc];
+    for (int r = 0; r < PE_RB; ++r) nxt[r] = src(y + PE_RB + N + r);
     __syncthreads();
     // Consume the prefetched rows BEFORE this batch's stores are issued: vmcnt retires in order
     // and counts stores, so waiting for these loads after the stores would also wait for the
@@ -1124,36 +1200,40 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
 #pragma unroll
     for (int r = 0; r < PE_RB; ++r) ring[2 * N + r] = nxt[r];
     __builtin_amdgcn_sched_barrier(0);
-    if (writer) {
+    {
+      // Straight line: every thread runs the horizontal pass and every store instruction is issued on every path --
+      // a lane that must not write (halo columns, columns beyond the frame) carries a vector offset beyond the resource's
+      // range and a row beyond the segment a null resource, so the hardware drops the store.  With the same eight stores
+      // behind the four prefetch loads on every path the compiler's vmcnt for the prefetched rows is exact (it waits
+      // for the loads, not for this batch's stores; with a branch around the stores it must assume there were none).
+      const unsigned pix0 = opaque(writer ? (unsigned)(tid - N) * PXW : 0u);
 #pragma unroll
       for (int r = 0; r < PE_RB; ++r) {
-        if (y + r < y1) {
-          const float(*s)[256] = sv[buf][r];
-          float g0 = a.c.g[0];
-          double b1 = s[0][tid] * g0, b2 = 0, b3 = s[1][tid] * g0, b4 = 0, b5 = s[2][tid] * g0, b6 = 0;
+        const float* __restrict__ s = &sv[buf][pix0 + 3 * r];
+        float g0 = a.c.g[0];
+        const float cx = s[N * PXW], cy = s[N * PXW + 1], cz = s[N * PXW + 2];
+        double b1 = cx * g0, b2 = 0, b3 = cy * g0, b4 = 0, b5 = cz * g0, b6 = 0;
 #pragma unroll
-          for (int k = 1; k <= N; ++k) {
-            const float p0 = s[0][tid + k], m0 = s[0][tid - k];
-            const float p1 = s[1][tid + k], m1 = s[1][tid - k];
-            const float p2 = s[2][tid + k], m2 = s[2][tid - k];
-            double tg = p0 + m0;
-            g0 = a.c.g[k];
-            // tg and the taps are float-valued, so tg*tap is exact in double and the fused form
-            // rounds exactly like the reference's separate multiply and add (one DP op instead of two)
-            b1 = __builtin_fma(tg, (double)g0, b1);
-            b4 = __builtin_fma(tg, (double)a.c.xxg[k], b4);
-            b2 += (p0 - m0) * a.c.xg[k];
-            b3 += (p1 + m1) * g0;
-            b6 += (p1 - m1) * a.c.xg[k];
-            b5 += (p2 + m2) * g0;
-          }
-          const int o = (y + r) * w + x;
-          // R layout: channels 0..3 as one float4 per pixel, channel 4 as a plane behind them
-          reinterpret_cast<float4*>(R)[o] = make_float4((float)(b3 * a.c.ig11), (float)(b2 * a.c.ig11),
-                                                        (float)(b1 * a.c.ig03 + b5 * a.c.ig33),
-                                                        (float)(b1 * a.c.ig03 + b4 * a.c.ig33));
-          R[4 * (size_t)np + o] = (float)(b6 * a.c.ig55);
+        for (int k = 1; k <= N; ++k) {
+          const float* __restrict__ pp = s + (N + k) * PXW;
+          const float* __restrict__ mm = s + (N - k) * PXW;
+          const float p0 = pp[0], m0 = mm[0];
+          const float p1 = pp[1], m1 = mm[1];
+          const float p2 = pp[2], m2 = mm[2];
+          double tg = p0 + m0;
+          g0 = a.c.g[k];
+          b1 = __builtin_fma(tg, (double)g0, b1);
+          b4 = __builtin_fma(tg, (double)a.c.xxg[k], b4);
+          b2 += (p0 - m0) * a.c.xg[k];
+          b3 += (p1 + m1) * g0;
+          b6 += (p1 - m1) * a.c.xg[k];
+          b5 += (p2 + m2) * g0;
         }
+        const bool row_ok = y + r < y1;                                  // uniform
+        const unsigned rowo = (unsigned)(y + r) * (unsigned)w;
+        bst4(row_ok ? Rb : Rnull, xo16 + 16u * rowo, make_float4((float)(b3 * a.c.ig11), (float)(b2 * a.c.ig11),
+                                                                                  (float)(b1 * a.c.ig03 + b5 * a.c.ig33), (float)(b1 * a.c.ig03 + b4 * a.c.ig33)));
+        bst1(row_ok ? Rb : Rnull, xo4, 16u * (unsigned)np + 4u * rowo, (float)(b6 * a.c.ig55));
       }
     }
     buf ^= 1;
@@ -1257,10 +1337,6 @@ __device__ __forceinline__ void update_matrices_px(const float* __restrict__ R0,
 // before consuming any (memory-level parallelism): um_issue computes the gather address and
 // issues the 2 R0 loads (float4 + float) and the 6 R1 loads (four float4 + two 8-byte pairs of
 // channel 4); um_finish does the arithmetic, bit-identical to update_matrices_px.
-#ifndef ST_ABLATE
-#define ST_ABLATE 0
-#endif
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct UmLoads {
   float4 q;            // R0 channels 0..3
@@ -1269,18 +1345,7 @@ struct UmLoads {
   f2u ts, bs;          // R1 channel 4 at (gi, gi+1) and (gi+w, gi+w+1)
 };
 
-// Loads address an expansion as (uniform base pointer) + (unsigned 32-bit BYTE offset) so that the
-// compiler can use the SGPR-base addressing form (one VGPR per address, no 64-bit VALU math).
-__device__ __forceinline__ float ldf(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ f2u ldf2(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const f2u*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-
+__device__ __forceinline__ void um_gather(const float* __restrict__ R1, unsigned single, unsigned gi, unsigned gb, UmLoads& L);
 __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const float* __restrict__ R1, int np, int h,
                                          int w, int x, int y, float2 f, UmLoads& L) {
   float fx = x + f.x, fy = y + f.y;
@@ -1292,14 +1357,20 @@ __device__ __forceinline__ void um_issue(const float* __restrict__ R0, const flo
   const unsigned single = 16u * (unsigned)np;  // byte offset of the channel-4 plane
   L.q = ldf4(R0, 16u * o);
   L.qs = ldf(R0, single + 4u * o);
+  um_gather(R1, single, gi, gb, L);
+}
+
+// the six R1 loads of the bilinear footprint; the second column's texel is addressed from a base pointer 16 bytes on
+// (uniform arithmetic) rather than by adding 16 to the per-lane offset (a vector instruction per load)
+__device__ __forceinline__ void um_gather(const float* __restrict__ R1, unsigned single, unsigned gi, unsigned gb, UmLoads& L) {
   // ST_ABLATE 16 / 64 (experiments, wrong results): what perfect lane sharing (no second-column loads) and a perfect
   // row carry (no top-row loads) would save -- the upper bound of any texel-reuse scheme (profiles/NOTES.md, round 5)
   if (!(ST_ABLATE & 64)) {
     L.t0 = ldf4(R1, 16u * gi);
-    if (ST_ABLATE & 16) L.t1 = L.t0; else L.t1 = ldf4(R1, 16u * gi + 16u);
+    if (ST_ABLATE & 16) L.t1 = L.t0; else L.t1 = ldf4(R1 + 4, 16u * gi);
   }
   L.b0 = ldf4(R1, 16u * gb);
-  if (ST_ABLATE & 16) L.b1 = L.b0; else L.b1 = ldf4(R1, 16u * gb + 16u);
+  if (ST_ABLATE & 16) L.b1 = L.b0; else L.b1 = ldf4(R1 + 4, 16u * gb);
   if (!(ST_ABLATE & 64)) L.ts = ldf2(R1, single + 4u * gi);
   L.bs = ldf2(R1, single + 4u * gb);
   if (ST_ABLATE & 64) { L.t0 = L.b0; L.t1 = L.b1; L.ts = L.bs; }
@@ -2000,7 +2071,8 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   // paired flow stores (even widths): writer k = tid - HALO stores pixels (2 j, 2 j + 1) of rows 4 hh .. 4 hh + 3 of a group,
   // j = k mod (OUT / 2), hh = k / (OUT / 2)
   typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
-  const int pair_k = tid - B2_HALO, pair_j = pair_k % (B2_OUT / 2);
+  const bool pair_tid = tid >= B2_HALO && tid < B2_T - B2_HALO;
+  const int pair_k = pair_tid ? tid - B2_HALO : 0, pair_j = pair_k % (B2_OUT / 2);
   const int pair_r0 = (pair_k / (B2_OUT / 2)) * (F3_GROUP / 2);
   const int pair_x = (int)bx * B2_OUT + 2 * pair_j;
   const int pair_pos = f3_pos(B2_HALO + 2 * pair_j);
@@ -2017,6 +2089,9 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? st_gl(a.flow_ptrs[pr]) : a.flow_out + (size_t)pr * 2 * (size_t)np;
+#if ST_F3_BUFSTORE
+  const __amdgpu_buffer_rsrc_t foutb = st_rsrc(fout, 8 * (size_t)np);
+#endif
   const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
   // ring slot s holds M of source row y0 - M + s (clamped), s = 0 .. 14; slot 15 takes the first entering row
@@ -2103,12 +2178,38 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
       const int yg = ybase + g * F3_GROUP;
       if (yg >= y1) break;  // uniform over the workgroup
       // ---- flow rows of the PREVIOUS group go out ahead of this group's loads
+#if ST_F3_BUFSTORE
+      {
+        // Even widths: a thread stores TWO adjacent pixels (16 bytes) of four of the eight rows -- half as many
+        // vector-memory instructions as one pixel per thread and row.  EVERY lane issues the four stores on EVERY path
+        // (first group of a segment, odd widths, lanes without an output pair: an offset the buffer's range check rejects),
+        // so that the waits of the UpdateMatrices that follows count them exactly; behind a branch the compiler must
+        // assume none was issued, and its vmcnt for the second row's gathers then also waits for the stores' own
+        // acknowledgements (vmcnt retires in order).
+        const unsigned pvo = (yg > y0 && !(w & 1) && pair_tid && pair_x < w) ? 8u * (unsigned)pair_x : 0xf0000000u;
+#pragma unroll
+        for (int r = 0; r < F3_GROUP / 2; ++r) {
+          const int rr = pair_r0 + r;
+          const float2 fa = Fs[rr][pair_pos], fb = Fs[rr][pair_pos + 1];
+          bst4<2>(foutb, pvo + 8u * (unsigned)((yg - F3_GROUP + rr) * w), make_float4(fa.x, fa.y, fb.x, fb.y));   // non-temporal
+        }
+        if ((w & 1) && yg > y0 && writer) {
+#pragma unroll
+          for (int r = 0; r < F3_GROUP; ++r) {
+            const float2 fv = Fs[r][vpos];
+            f2v v2;
+            v2.x = fv.x; v2.y = fv.y;
+            __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)));
+          }
+        }
+      }
+#else
       if (yg > y0) {
         if (!(w & 1)) {
           // even widths: a thread stores TWO adjacent pixels (16 bytes) of four of the eight rows -- half as many
           // vector-memory instructions as one pixel per thread and row (the texture-address unit is this kernel's
           // busiest resource, and an instruction costs it the same whatever its width)
-          if (pair_x < w && tid >= B2_HALO && tid < B2_T - B2_HALO) {
+          if (pair_x < w && pair_tid) {
 #pragma unroll
             for (int r = 0; r < F3_GROUP / 2; ++r) {
               const int rr = pair_r0 + r;
@@ -2129,6 +2230,7 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
           }
         }
       }
+#endif
       // ---- phase 1: GROUP / RB batches back to back
       // phase 1 carries the loads: a wave in it goes ahead of the co-resident wave's phase-2 arithmetic, so
       // that the gathers are in flight as early as possible (measured: -3 % on the launch)
