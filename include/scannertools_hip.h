@@ -51,6 +51,8 @@ int st_device_count(int* count);
  * expansions, matrices).  Replaces the per-instance state of the reference GPU wrappers
  * (streams_, planes_, flow_finders_, grayscale_; histogram_kernel_gpu.cpp:71-75,
  * optical_flow_kernel_gpu.cpp:101-107). */
+/* ST_ERR_UNSUPPORTED: the device is not a gfx950-class part (the kernels are compiled for gfx950 and sized for its 160 KB
+ * of LDS per workgroup); ST_ERR_INVALID: no such device. */
 int st_ctx_create(int device_id, st_ctx** out_ctx);
 int st_ctx_destroy(st_ctx* ctx);
 /* Borrow an external hipStream_t (e.g. torch's current stream).  NULL is the HIP default
@@ -307,7 +309,7 @@ int st_cpm2_limb_scores(st_ctx* ctx, const float* const* heatmaps_dev, const flo
                         float* scores_dev);
 
 /* Convolution stack of the pose network (what the Caffe forward pass behind the reference's CPM2 op
- * computes, scannertools_caffe_cpp/cpm2_kernel.cpp:8-52 / caffe_kernel.cpp; layer list: DESIGN.md section 9).
+ * computes, scannertools_caffe_cpp/cpm2_kernel.cpp:8-52 / caffe_kernel.cpp; layer list: profiles/NOTES.md, Part II section 9).
  * float32 throughout, as in the reference.  Activations are NHWC float32 device arrays whose channel count
  * (x_stride / y_stride floats per pixel) is a multiple of 4; a call reads cin channels from channel
  * x_offset on and writes cout channels from channel y_offset on, so concatenations need no copy.
@@ -353,6 +355,10 @@ int st_conv2d_nhwc_bf16x3_pair(st_ctx* ctx, int n, int h, int w, int cin, int kh
  * cout_pad a multiple of 128, which also get the operand-order copy the spatial-tile kernel reads -- the library picks
  * the kernel per call; both kernels add the same products in the same order, so the result does not depend on the choice). */
 long long st_conv_bf16x3_packed_bytes(int cout_pad, int kh, int kw, int cin);
+/* out_bytes: the size of the buffer behind out_dev; less than st_conv_bf16x3_packed_bytes(...) is ST_ERR_INVALID (nothing is
+ * written).  st_conv_pack_weights_bf16x3 is the same call without the check: the caller vouches for the size. */
+int st_conv_pack_weights_bf16x3_n(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev,
+                                  size_t out_bytes);
 int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev);
 int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,
                           const void* w3_dev, const float* bias_dev, int kh, int kw, int cout, int cout_pad, int relu,

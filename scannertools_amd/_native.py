@@ -132,6 +132,7 @@ SIGNATURES = {
     "st_conv_pack_weights_f32_tile": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "st_conv2d_nhwc_f32_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "st_conv_pack_weights_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "st_conv_pack_weights_bf16x3_n": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t]),
     "st_conv2d_nhwc_f32_pair": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(ConvOperands), _c.POINTER(ConvOperands)]),
     "st_conv2d_nhwc_bf16x3_pair": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(ConvOperands), _c.POINTER(ConvOperands)]),
     "st_conv2d_nhwc_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i]),

@@ -41,6 +41,8 @@ ST_EXPORT int st_device_count(int* count) {
   return ST_OK;
 }
 
+static constexpr size_t kMinLdsBytes = 160 * 1024;  // gfx950
+
 ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (!out_ctx) return ST_ERR_INVALID;
   *out_ctx = nullptr;
@@ -64,7 +66,17 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (const char* e = getenv("ST_PYR_ROLES")) c->pyr_roles = atoi(e);
   if (const char* e = getenv("ST_CONV_TILE")) c->conv_tile = atoi(e);
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    c->num_cus = prop.multiProcessorCount;
+    // The library is compiled for gfx950 and its kernels are sized for that chip's 160 KB of LDS per workgroup (the Histogram
+    // counters take 96 KB, the role-split flow iteration 129 / 158 KB, the convolution tiles up to 104 KB): a device with less
+    // is refused here, once, instead of failing at some later launch.
+    if (prop.sharedMemPerBlock < kMinLdsBytes) {
+      (void)hipStreamDestroy(c->own_stream);
+      delete c;
+      return ST_ERR_UNSUPPORTED;
+    }
+  }
   *out_ctx = c;
   return ST_OK;
 }

@@ -5,7 +5,7 @@
 //
 // What it replaces: the Caffe forward pass behind the reference's CPM2 op
 // (/root/reference/scannertools_caffe/scannertools_caffe_cpp/cpm2_kernel.cpp:8-52 -> CaffeKernel::execute,
-// caffe_kernel.cpp) for the layers of the OpenPose COCO model.  The reference
+// caffe_kernel.cpp) for the layers of the OpenPose COCO model (profiles/NOTES.md, Part II section 9).  The reference
 // computes in float32 (Caffe), so this does too: v_mfma_f32_32x32x2_f32, f32 operands, f32
 // accumulation -- bit for bit a k-ordered fmaf chain -- at the f32 matrix rate (157 TFLOP/s peak).
 //
@@ -639,10 +639,13 @@ ST_EXPORT long long st_conv_bf16x3_packed_bytes(int cout_pad, int kh, int kw, in
   return conv_tile_weights(kh, kw, cout_pad, cin) ? 2 * one : one;   // + the tile-order copy for k_conv_tile_bf16x3
 }
 
-ST_EXPORT int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev) {
+ST_EXPORT int st_conv_pack_weights_bf16x3_n(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev,
+                                            size_t out_bytes) {
   ST_TRY(st_enter(ctx));
   if (!w_dev || !out_dev || cout_pad <= 0 || kh <= 0 || kw <= 0 || cin <= 0 || cin % 16 || ((uintptr_t)out_dev & 15))
     return st_set_error(ctx, ST_ERR_INVALID, "conv pack: bad arguments (cin a multiple of 16, 16-byte aligned output)");
+  if ((long long)out_bytes < st_conv_bf16x3_packed_bytes(cout_pad, kh, kw, cin))
+    return st_set_error(ctx, ST_ERR_INVALID, "conv pack: the output buffer is smaller than st_conv_bf16x3_packed_bytes() for this layer");
   const long long total = (long long)cout_pad * kh * kw * (cin / 2);
   long long bx = (total + 255) / 256;
   if (bx > 65536) bx = 65536;
@@ -651,6 +654,12 @@ ST_EXPORT int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int c
     st_conv_tile_pack_bf16x3(ctx, (unsigned)bx, w_dev, cout_pad, kh * kw, cin, (unsigned*)out_dev + (size_t)total * 3);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
+}
+
+// The entry point without a size: the caller vouches for st_conv_bf16x3_packed_bytes() bytes behind out_dev.
+ST_EXPORT int st_conv_pack_weights_bf16x3(st_ctx* ctx, const float* w_dev, int cout_pad, int kh, int kw, int cin, void* out_dev) {
+  const long long need = st_conv_bf16x3_packed_bytes(cout_pad, kh, kw, cin);
+  return st_conv_pack_weights_bf16x3_n(ctx, w_dev, cout_pad, kh, kw, cin, out_dev, need > 0 ? (size_t)need : 0);
 }
 
 ST_EXPORT int st_conv2d_nhwc_bf16x3(st_ctx* ctx, const float* x_dev, int n, int h, int w, int cin, int x_stride, int x_offset,

@@ -6,7 +6,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // bf16x3 on a SPATIAL tile (round 4).  k_conv_nhwc_bf16x3 pulls, per 16-channel slice of one tap, 8 KB of float32
 // pixels and 12 KB of split weights through the L1 for a 128 x 128 tile -- 31 B per clock and CU at full matrix rate,
-// more than a CU's miss queue sustains; its matrix pipe is busy 43 % of the time.  A 7x7 layer fetches
+// more than a CU's miss queue sustains; its matrix pipe is busy 43 % of the time (profiles/NOTES.md II 4.11).  A 7x7 layer fetches
 // every input pixel 49 times that way.  Here a workgroup owns TH x TW <= 32 NW output pixels of ONE image and 128 output
 // channels:
 //   * per 16-channel slice the input REGION (TH + K - 1) x (TW + K - 1) of the tile is split into its three bf16 planes

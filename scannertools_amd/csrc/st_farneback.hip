@@ -1102,9 +1102,7 @@ __device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned 
 #ifndef ST_ABLATE
 #define ST_ABLATE 0
 #endif
-#ifndef ST_F3_BUFSTORE
-#define ST_F3_BUFSTORE 0  // k_flow_iter3: unconditional buffer stores of the flow rows (experiment)
-#endif
+
 
 // ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
@@ -2089,9 +2087,6 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   const float* __restrict__ fin = a.flow_in ? a.flow_in + (size_t)pr * 2 * (size_t)np : nullptr;
   const float* __restrict__ C = a.coarse ? a.coarse + (size_t)pr * 2 * (size_t)a.ch * a.cw : nullptr;
   float* fout = a.flow_ptrs ? st_gl(a.flow_ptrs[pr]) : a.flow_out + (size_t)pr * 2 * (size_t)np;
-#if ST_F3_BUFSTORE
-  const __amdgpu_buffer_rsrc_t foutb = st_rsrc(fout, 8 * (size_t)np);
-#endif
   const CoarseX cx = (MODE == FLOW_COARSE || MODE == FLOW_COARSE2) ? coarse_x(a, xc) : CoarseX{0, 1.f, 0.f, false};
 
   // ring slot s holds M of source row y0 - M + s (clamped), s = 0 .. 14; slot 15 takes the first entering row
@@ -2178,32 +2173,6 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
       const int yg = ybase + g * F3_GROUP;
       if (yg >= y1) break;  // uniform over the workgroup
       // ---- flow rows of the PREVIOUS group go out ahead of this group's loads
-#if ST_F3_BUFSTORE
-      {
-        // Even widths: a thread stores TWO adjacent pixels (16 bytes) of four of the eight rows -- half as many
-        // vector-memory instructions as one pixel per thread and row.  EVERY lane issues the four stores on EVERY path
-        // (first group of a segment, odd widths, lanes without an output pair: an offset the buffer's range check rejects),
-        // so that the waits of the UpdateMatrices that follows count them exactly; behind a branch the compiler must
-        // assume none was issued, and its vmcnt for the second row's gathers then also waits for the stores' own
-        // acknowledgements (vmcnt retires in order).
-        const unsigned pvo = (yg > y0 && !(w & 1) && pair_tid && pair_x < w) ? 8u * (unsigned)pair_x : 0xf0000000u;
-#pragma unroll
-        for (int r = 0; r < F3_GROUP / 2; ++r) {
-          const int rr = pair_r0 + r;
-          const float2 fa = Fs[rr][pair_pos], fb = Fs[rr][pair_pos + 1];
-          bst4<2>(foutb, pvo + 8u * (unsigned)((yg - F3_GROUP + rr) * w), make_float4(fa.x, fa.y, fb.x, fb.y));   // non-temporal
-        }
-        if ((w & 1) && yg > y0 && writer) {
-#pragma unroll
-          for (int r = 0; r < F3_GROUP; ++r) {
-            const float2 fv = Fs[r][vpos];
-            f2v v2;
-            v2.x = fv.x; v2.y = fv.y;
-            __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(fout + 2 * (size_t)((yg - F3_GROUP + r) * w + x)));
-          }
-        }
-      }
-#else
       if (yg > y0) {
         if (!(w & 1)) {
           // even widths: a thread stores TWO adjacent pixels (16 bytes) of four of the eight rows -- half as many
@@ -2230,7 +2199,6 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
           }
         }
       }
-#endif
       // ---- phase 1: GROUP / RB batches back to back
       // phase 1 carries the loads: a wave in it goes ahead of the co-resident wave's phase-2 arithmetic, so
       // that the gathers are in flight as early as possible (measured: -3 % on the launch)

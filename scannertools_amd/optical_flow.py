@@ -12,7 +12,7 @@ from .engine import CacheMode, DeviceType, NamedStream, NamedVideoStream, PerfPa
 def build_pipeline(sc, frame_sampled, device=DeviceType.GPU, batch=None):
     """old/optical_flow.py:19-24.  As there, no ``batch=`` reaches the op by default: Scanner then hands the kernel one
     row (one pair) per ``execute()``.  ``batch=N`` is the speed switch of this build (N pairs per call fill the GPU from
-    one kernel instance; without it a Scanner graph fills it with ``pipeline_instances_per_node`` -- DESIGN.md 4.9)."""
+    one kernel instance; without it a Scanner graph fills it with ``pipeline_instances_per_node`` -- DESIGN.md 7)."""
     if batch is None:
         return {'flow': sc.ops.OpticalFlow(frame=frame_sampled, device=device)}
     return {'flow': sc.ops.OpticalFlow(frame=frame_sampled, device=device, batch=batch)}

@@ -16,7 +16,7 @@ PAF | heat maps | 7 zero channels] (the features first so that every read starts
 first layer's weights of stages 2..6 are permuted to match), that the branches write their slices of, so
 no concatenation pass exists.  Output: (n, H/8, W/8, 57) = 19 heat maps followed by 38
 part-affinity planes, the channel order ``cpm2_output_kernel_cpu.cpp:84-88`` indexes (the reference then
-up-samples x8 and runs NMS inside the Caffe fork; not built -- DESIGN.md section 9).
+up-samples x8 and runs NMS inside the Caffe fork; not built -- profiles/NOTES.md, Part II section 9).
 """
 import ctypes
 
@@ -483,8 +483,8 @@ class PoseNet:
             ctx._bind()
             for name, (wp, _) in self.packed.items():
                 w3 = torch.empty((ctx._L.st_conv_bf16x3_packed_bytes(wp.shape[0], wp.shape[1], wp.shape[2], wp.shape[3]),), dtype=torch.uint8, device=self.device)
-                ctx._check(ctx._L.st_conv_pack_weights_bf16x3(ctx._h, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], wp.shape[1], wp.shape[2],
-                                                              wp.shape[3], ctypes.c_void_p(w3.data_ptr())))
+                ctx._check(ctx._L.st_conv_pack_weights_bf16x3_n(ctx._h, ctypes.c_void_p(wp.data_ptr()), wp.shape[0], wp.shape[1], wp.shape[2],
+                                                                wp.shape[3], ctypes.c_void_p(w3.data_ptr()), w3.numel()))
                 self.packed3[name] = w3
             torch.cuda.synchronize(self.device)
         self.packed_tile = {}   # name -> float32 weights in the spatial-tile kernel's operand order (3x3 / 7x7 layers with 128-channel blocks)

@@ -558,8 +558,9 @@ class Net {
     }
     if (!p.w3) {
       void* w3 = nullptr;
-      if (hipMalloc(&w3, (size_t)st_conv_bf16x3_packed_bytes(p.cout_pad, l.k, l.k, p.cin_pad)) != hipSuccess) return ST_ERR_HIP;
-      const int st = st_conv_pack_weights_bf16x3(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, w3);
+      const size_t w3_bytes = (size_t)st_conv_bf16x3_packed_bytes(p.cout_pad, l.k, l.k, p.cin_pad);
+      if (hipMalloc(&w3, w3_bytes) != hipSuccess) return ST_ERR_HIP;
+      const int st = st_conv_pack_weights_bf16x3_n(ctx, p.w, p.cout_pad, l.k, l.k, p.cin_pad, w3, w3_bytes);
       if (st != ST_OK) {  // an unpacked buffer must never be mistaken for packed weights by the next call
         (void)hipFree(w3);
         return st;

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # The round's committed bench line: bash scripts/final_bench.sh <tag>   (run on the GPU box; copy gpurun_out/bench_<tag>.json to profiles/<tag>_bench.json)
 cd "$GRAFT_REPO_ROOT"
 tag=${1:-final}

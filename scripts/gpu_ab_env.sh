@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # A/B of environment-selected kernel variants: bash scripts/gpu_ab_env.sh "VAR1=a VAR2=b" "VAR1=c" ...
 # Each argument is one configuration (space-separated env assignments); prints the bench's key numbers.
 cd "$GRAFT_REPO_ROOT"

@@ -1,8 +1,9 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Per-kernel-class times of one headline step for experimental library builds (scripts/build_variant.sh):
 #   bash scripts/gpu_ab_kernels.sh default nt1 ...     ("default" = the production library)
 set -u
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "$GRAFT_REPO_ROOT"
 for name in "$@"; do
   lib=""
   [ "$name" != "default" ] && lib="$PWD/scannertools_amd/lib_exp_$name/libscannertools_hip.so"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # A/B of experimental library builds (scripts/build_variant.sh): bash scripts/gpu_ab_lib.sh default nt1 nt3 ...
 # "default" = the production library; every other name = scannertools_amd/lib_exp_<name>.  Optional env BENCH_ARGS.
 cd "$GRAFT_REPO_ROOT"

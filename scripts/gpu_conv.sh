@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Convolution kernel: per-layer timing, then counter passes over one layer shape (default: the stages' 7x7 128->128).
 #   bash scripts/gpu_conv.sh [H W CIN COUT K]
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # small-batch sweep over an environment knob: bash scripts/gpu_small_sweep.sh VAR "v1 v2 ..." "batches"
 cd "$GRAFT_REPO_ROOT"
 var=$1; vals=$2; batches=${3:-"1 2 4 8"}

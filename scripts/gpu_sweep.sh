@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Batch-size sweep of the bench (frames/s through OpticalFlow + Histogram): bash scripts/gpu_sweep.sh
 cd "$GRAFT_REPO_ROOT"
 for b in 1 2 4 8 16 32 64 128 256; do

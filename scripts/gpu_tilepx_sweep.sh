@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # tile-kernel threshold sweep at mid batch sizes: bash scripts/gpu_tilepx_sweep.sh
 cd "$GRAFT_REPO_ROOT"
 for b in 4 8 16 32 64; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Counter passes restricted to the flow-iteration kernel (fast: other kernels are not instrumented).
 # usage: bash scripts/pmc_iter.sh <tag> [lib variant name | default] [kernel regex]
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Wider counter set for one kernel of the bench: bash scripts/pmc_kernel.sh <tag> <kernel regex>
 set -u
 tag=$1; rx=$2

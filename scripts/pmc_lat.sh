@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Latency / front-end view of the flow-iteration kernel (separate counter-only passes; pmc_summary.py averages per
 # kernel and grid size).  usage: bash scripts/pmc_lat.sh <tag> [extra bench args]
 set -u

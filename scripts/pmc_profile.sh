@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Collect PMC counters for bench.py in separate passes (never combined with tracing domains).
 # usage: scripts/pmc_profile.sh <tag> [bench args...]   (run on the GPU box, from the repo root)
 set -u

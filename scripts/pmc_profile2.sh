@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Focused PMC passes (latency / TA / L2 view). usage: scripts/pmc_profile2.sh <tag> [bench args]
 set -u
 tag=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Counters of the small-call kernels: bash scripts/pmc_small.sh <pairs per call> [kernel regex]
 # (bench.py --batch <pairs>, event-free; separate --pmc passes, counters only)
 set -u

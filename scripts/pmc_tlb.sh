@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_tlb; mkdir -p $out

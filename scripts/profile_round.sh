@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Round profile: the bench line, rocprofv3 --kernel-trace --stats of the SAME command, and PMC
 # passes (separate runs, counters only) for HBM traffic.  Run on the GPU box from the repo root:
 #   bash scripts/profile_round.sh <tag>

@@ -1,7 +1,8 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Records the tolerance tier of every flow field of tests/test_fuzz_gpu.py::test_fuzz_optical_flow (run on a GPU box):
 #   bash scripts/record_flow_tiers.sh > tests/golden/flow_fuzz_tiers.json
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "$GRAFT_REPO_ROOT"
 ST_RECORD_FLOW_TIERS=1 python -m pytest tests/test_fuzz_gpu.py -q -m gpu -k "test_fuzz_optical_flow and default" -s 2>/dev/null | python -c "
 import json, sys, ast
 out = {}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Kernel-trace durations of the Histogram kernel at N frames per launch beside its HIP-event figure:
 #   bash scripts/trace_hist.sh <tag> [N ...]      (on the GPU box; writes gpurun_out/th_<tag>_<N>.txt)
 tag=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root when not run through gpurun
 # Kernel trace of small-batch steps: bash scripts/trace_small.sh <batch> [steps]
 # prints the per-kernel stats table and the timeline of one step (scripts/rocpd_timeline.py)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"

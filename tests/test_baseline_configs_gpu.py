@@ -1,6 +1,6 @@
 """GPU: parity at the BASELINE.json configurations THEMSELVES (not only at their resolutions): the batch sizes, frame
 counts and network geometry the configurations name, each against the oracle (or torch float arithmetic on the CPU for
-the pose network, whose parity target it is: DESIGN.md 4.11) on a sample, plus the size-independent properties.
+the pose network, whose parity target it is: DESIGN.md 4.8) on a sample, plus the size-independent properties.
 
   config 1  Histogram, 256 bins, 1000 host-resident 1080p frames through the DeviceType::CPU registration
   config 2  (the headline: covered by bench.py's own `parity` block and tests/test_flow_gpu.py's 1080p cases)

@@ -453,6 +453,17 @@ def test_pose_entry_points_reject_bad_arguments_and_accept_empty_batches(hip_ctx
     assert L.st_conv_pack_weights_bf16x3(h, vp(w.data_ptr()), 64, 3, 3, 24, vp(w3.data_ptr())) == _native.ST_ERR_INVALID
     assert L.st_conv_pack_weights_bf16x3(h, vp(w.data_ptr()), 64, 3, 3, 32, vp(w3.data_ptr() + 2)) == _native.ST_ERR_INVALID
     assert L.st_conv_pack_weights_bf16x3(h, None, 64, 3, 3, 32, vp(w3.data_ptr())) == _native.ST_ERR_INVALID
+    # the size-checked entry point: a buffer sized by the 6-bytes-per-weight rule is too small for a layer that also gets the
+    # spatial-tile kernel's copy (3x3 / 7x7 with 128-channel output blocks: 12 bytes per weight) -- refused, nothing written
+    need64, need128 = L.st_conv_bf16x3_packed_bytes(64, 3, 3, 32), L.st_conv_bf16x3_packed_bytes(128, 3, 3, 32)
+    assert need64 == 64 * 9 * 32 * 6 and need128 == 128 * 9 * 32 * 12
+    w128 = torch.randn((128, 3, 3, 32), device="cuda")
+    big = torch.full((need128 + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    assert L.st_conv_pack_weights_bf16x3_n(h, vp(w128.data_ptr()), 128, 3, 3, 32, vp(big.data_ptr()), 128 * 9 * 32 * 6) == _native.ST_ERR_INVALID
+    assert b"smaller" in L.st_ctx_last_error(h) and bool((big == 0xAB).all())
+    assert L.st_conv_pack_weights_bf16x3_n(h, vp(w128.data_ptr()), 128, 3, 3, 32, vp(big.data_ptr()), need128) == 0
+    torch.cuda.synchronize()
+    assert bool((big[need128:] == 0xAB).all()) and not bool((big[:need128] == 0xAB).all())
 
     def conv3(cin=32, xs=32, xoff=0, k=3, cout=64, cop=64, ys=64, yoff=0, wp=None):
         return L.st_conv2d_nhwc_bf16x3(h, vp(x.data_ptr()), 1, 4, 4, cin, xs, xoff, vp(w3.data_ptr()) if wp is None else wp, vp(b.data_ptr()), k, k, cout, cop, 1,
