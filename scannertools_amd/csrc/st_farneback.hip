@@ -1104,6 +1104,7 @@ __device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned 
 #endif
 
 
+
 // ---------------------------------------------------------------------------------------------
 // A4: polynomial expansion.  Each thread owns one column of a 256-wide strip and marches down
 // a vertical segment keeping the 2N+1 source rows of its column in registers; the three
