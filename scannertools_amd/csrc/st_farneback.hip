@@ -2977,7 +2977,12 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   return ST_OK;
 }
 
+// k_polyexp addresses a frame's expansion through 32-bit buffer offsets: 20 bytes per pixel must stay below 4 GB
+// (214 M pixels; a 4K frame is 8.3 M)
+static bool polyexp_frame_fits(int h, int w) { return (unsigned long long)h * (unsigned long long)w * 20ull < 0xf0000000ull; }
+
 int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R) {
+  if (!polyexp_frame_fits(h, w)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 200 M pixels are not supported");
   PolyArgs a;
   a.img = img; a.R = R; a.h = h; a.w = w;
   poly_prepare(poly_n, poly_sigma, &a.c);
@@ -3004,6 +3009,7 @@ int launch_polyexp_ml(st_ctx* ctx, float* const* imgs, const LevelGeom* geom, fl
   for (int i = 0; i < nk; ++i) {
     const LevelGeom& g = geom[ks[i]];
     PolyLevel& l = a.lv[i];
+    if (!polyexp_frame_fits(g.lh, g.lw)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 200 M pixels are not supported");
     l.img = imgs[ks[i]]; l.R = R[ks[i]]; l.h = g.lh; l.w = g.lw;
     l.strips = (g.lw + PE_OUT - 1) / PE_OUT;
     l.rows_per_seg = polyexp_rows(ctx, g.lh, l.strips, n, poly_n);
