@@ -331,11 +331,13 @@ Element* output_at(EngineOutputs* o, int col, int i) {
   return e && i < (int)e->size() ? &(*e)[i] : nullptr;
 }
 
-double g_last_execute_seconds = 0.0;  // wall time spent inside execute() by the last stshim_run_frames
+// per calling thread: the engine entry points run concurrently from several threads (one per kernel instance), and each
+// thread reads the figures of ITS last call
+thread_local double g_last_execute_seconds = 0.0;  // wall time spent inside execute() by the last stshim_run_frames
 // the same without the run's first execute() call (a fresh kernel instance allocates its device scratch there), and
 // the rows those later calls covered: the steady state of a kernel instance that lives for a whole job
-double g_last_steady_seconds = 0.0;
-int g_last_steady_rows = 0;
+thread_local double g_last_steady_seconds = 0.0;
+thread_local int g_last_steady_rows = 0;
 
 void set_err(char* err, size_t n, const std::string& s) {
   if (err && n) { strncpy(err, s.c_str(), n - 1); err[n - 1] = 0; }
