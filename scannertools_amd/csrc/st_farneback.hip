@@ -1156,8 +1156,10 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
   const bool writer = tid >= N && tid < N + PE_OUT && x < w;
   const unsigned voff = 4u * (unsigned)xc;                 // byte offset of this thread's column in a source row
   const unsigned xo = writer ? (unsigned)x : 0u;           // output column (only writers store)
-  // non-writers: beyond any resource's range (the range check covers the vector offset only, not the scalar one)
-  const unsigned xo16 = writer ? 16u * xo : 0xf0000000u, xo4 = writer ? 4u * xo : 0xf0000000u;
+  // non-writers: beyond any resource's range (the range check covers the vector offset only, not the scalar one).  The row
+  // term is added to it for the 16-byte store: with frames of at most 2^26 pixels (polyexp_frame_fits) 0x80000000 + 16 np
+  // stays below 2^32 and above the 20 np bytes of the resource, so the sum can neither wrap nor come back into range
+  const unsigned xo16 = writer ? 16u * xo : 0x80000000u, xo4 = writer ? 4u * xo : 0x80000000u;
   const __amdgpu_buffer_rsrc_t Rnull = st_rsrc(R, 0);
   const __amdgpu_buffer_rsrc_t Ib = st_rsrc(I, 4 * (size_t)np), Rb = st_rsrc(R, 20 * (size_t)np);
   auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
@@ -2977,12 +2979,13 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   return ST_OK;
 }
 
-// k_polyexp addresses a frame's expansion through 32-bit buffer offsets: 20 bytes per pixel must stay below 4 GB
-// (214 M pixels; a 4K frame is 8.3 M)
-static bool polyexp_frame_fits(int h, int w) { return (unsigned long long)h * (unsigned long long)w * 20ull < 0xf0000000ull; }
+// k_polyexp addresses a frame's expansion through 32-bit buffer offsets and rejects unwanted stores with an offset of 2^31:
+// frames of at most 2^26 pixels (64 M; a 4K frame is 8.3 M) keep every sum of offsets below 2^32 and every rejected one
+// above the resource's 20 np bytes
+static bool polyexp_frame_fits(int h, int w) { return (unsigned long long)h * (unsigned long long)w <= (1ull << 26); }
 
 int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R) {
-  if (!polyexp_frame_fits(h, w)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 200 M pixels are not supported");
+  if (!polyexp_frame_fits(h, w)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 64 M pixels are not supported");
   PolyArgs a;
   a.img = img; a.R = R; a.h = h; a.w = w;
   poly_prepare(poly_n, poly_sigma, &a.c);
@@ -3009,7 +3012,7 @@ int launch_polyexp_ml(st_ctx* ctx, float* const* imgs, const LevelGeom* geom, fl
   for (int i = 0; i < nk; ++i) {
     const LevelGeom& g = geom[ks[i]];
     PolyLevel& l = a.lv[i];
-    if (!polyexp_frame_fits(g.lh, g.lw)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 200 M pixels are not supported");
+    if (!polyexp_frame_fits(g.lh, g.lw)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 64 M pixels are not supported");
     l.img = imgs[ks[i]]; l.R = R[ks[i]]; l.h = g.lh; l.w = g.lw;
     l.strips = (g.lw + PE_OUT - 1) / PE_OUT;
     l.rows_per_seg = polyexp_rows(ctx, g.lh, l.strips, n, poly_n);
