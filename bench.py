@@ -759,12 +759,12 @@ def run_rank(args):
     # every rank's device, and every rank's own time per step
     from scannertools_amd.sharding import device_id_string, rank_table
     my_dev, my_ms = device_id_string(torch, device), dt_rank / args.steps * 1e3
-    rccl_world, devices, rank_ms = 1, [my_dev], [my_ms]
+    rccl_world, devices, rank_ms, rank_frames = 1, [my_dev], [my_ms], [B * args.steps]
     if world > 1:
         # rank 0 prints the table on stderr; N ranks on fewer than N devices is an error on every rank unless the run is
         # the declared self-test (ST_BENCH_SHARE_GPU=1)
         table = rank_table(my_dev, B * args.steps, my_ms, "bench.py", require_distinct=not share)
-        devices, rank_ms = [t_["device"] for t_ in table], [t_["ms"] for t_ in table]
+        devices, rank_ms, rank_frames = [t_["device"] for t_ in table], [t_["ms"] for t_ in table], [t_["frames"] for t_ in table]
         one = torch.ones(1, dtype=torch.int32, device="cpu" if share else device)
         ones = [torch.zeros_like(one) for _ in range(world)]
         dist.all_gather(ones, one)
@@ -848,7 +848,7 @@ def run_rank(args):
             "devices": devices,
             "distinct_devices": len(set(devices)),
             "ms_per_step_by_rank": rank_ms,
-            "frames_by_rank": [B * args.steps] * world,
+            "frames_by_rank": rank_frames,
             "flow_whole_path_frac_of_peak": fps / world * flow_model_bytes / 1e9 / HBM_PEAK_GBS,
             "data": "synthetic",
             "config": {

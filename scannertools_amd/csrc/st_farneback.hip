@@ -1419,6 +1419,46 @@ __device__ __forceinline__ void um_finish(const UmLoads& L, int h, int w, int x,
   m[4] = r6 * r2 + r5 * r3;
 }
 
+#if ST_ABLATE & 128
+// ST_ABLATE 128 (experiment, wrong results): the ceiling of "R1 rows kept on chip" (round-5 verdict, item 1) -- the six
+// per-lane R1 gathers of a pixel replaced by ONE coalesced fill (16 + 4 bytes of the row below, written to a 3-row x
+// 272-column window in LDS) and six LDS reads at the gather's column / row offsets.  No barrier orders the fill against
+// the reads and the window never tracks the flow: the values are garbage, the instruction mix is the scheme's best case.
+// ST_ABLATE 256 adds a workgroup barrier per row batch (what a 3-row window needs to be correct).
+constexpr int RW_COLS = 256 + 16;  // B2_T + 16
+struct RWin { float4* q; float* s; int xb; };
+__device__ __forceinline__ void um_issue_win(const float* __restrict__ R0, const float* __restrict__ R1, int np, int h,
+                                             int w, int x, int y, UmLoads& L) {
+  const unsigned o = (unsigned)(y * w + x);
+  const unsigned single = 16u * (unsigned)np;
+  L.q = ldf4(R0, 16u * o);
+  L.qs = ldf(R0, single + 4u * o);
+  const unsigned of = (unsigned)(min(y + 1, h - 1) * w + x);
+  L.t0 = ldf4(R1, 16u * of);
+  L.ts.x = ldf(R1, single + 4u * of);
+}
+__device__ __forceinline__ void um_fill_win(const UmLoads& L, const RWin& win, int slot, int tid) {
+  win.q[slot * RW_COLS + tid + 8] = L.t0;
+  win.s[slot * RW_COLS + tid + 8] = L.ts.x;
+}
+__device__ __forceinline__ void um_gather_win(const UmLoads& L, const RWin& win, int slot, int h, int w, int x, int y,
+                                              float2 f, UmLoads& G) {
+  const float fx = x + f.x, fy = y + f.y;
+  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  const int c = d_clamp(x1 - win.xb, 0, RW_COLS - 2);
+  const int d = d_clamp(y1 - y + 1, 0, 1);
+  int s0 = slot + 1 + d; s0 = s0 >= 3 ? s0 - 3 : s0;
+  int s1 = s0 + 1; s1 = s1 >= 3 ? s1 - 3 : s1;
+  G.q = L.q; G.qs = L.qs;
+  const float4* q0 = win.q + s0 * RW_COLS + c;
+  const float4* q1 = win.q + s1 * RW_COLS + c;
+  G.t0 = q0[0]; G.t1 = q0[1]; G.b0 = q1[0]; G.b1 = q1[1];
+  const float* p0 = win.s + s0 * RW_COLS + c;
+  const float* p1 = win.s + s1 * RW_COLS + c;
+  G.ts.x = p0[0]; G.ts.y = p0[1]; G.bs.x = p1[0]; G.bs.y = p1[1];
+}
+#endif
+
 // Initial matrices of a level; the flow is zero (coarsest level), a given field, or the
 // previous level's flow resized with INTER_LINEAR and multiplied by 1/pyr_scale.
 struct UMArgs {
@@ -2057,6 +2097,11 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   static_assert(W == F3_RING - 1 && F3_GROUP % RB == 0 && M <= B2_HALO, "ring of 16 = window of 15 + the entering row");
   __shared__ float Vs[F3_GROUP][5][F3_PADW];
   __shared__ float2 Fs[F3_GROUP][F3_PADW];
+#if ST_ABLATE & 128
+  __shared__ float4 Rw4[3 * RW_COLS];
+  __shared__ float Rw1[3 * RW_COLS];
+  int wslot = 0;
+#endif
   const int tid = threadIdx.x;
   const int h = a.h, w = a.w;
   const int np = h * w;
@@ -2069,6 +2114,9 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
   const int y1 = min(h, y0 + a.rows_per_seg);
   const bool writer = tid >= B2_HALO && tid < B2_T - B2_HALO && x < w;
   const int vpos = f3_pos(tid);
+#if ST_ABLATE & 128
+  const RWin win{Rw4, Rw1, (int)bx * B2_OUT - B2_HALO - 8};
+#endif
   // paired flow stores (even widths): writer k = tid - HALO stores pixels (2 j, 2 j + 1) of rows 4 hh .. 4 hh + 3 of a group,
   // j = k mod (OUT / 2), hh = k / (OUT / 2)
   typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
@@ -2214,7 +2262,18 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
         for (int r = 0; r < RB; ++r) {
           const int t = g * F3_GROUP + bb * RB + r;  // row of the 16-row period: compile-time constant
           float m[5];
+#if ST_ABLATE & 128
+          {
+            UmLoads G;
+            um_fill_win(L[q][r], win, wslot, tid);
+            if ((ST_ABLATE & 256) && r == 0) __syncthreads();
+            um_gather_win(L[q][r], win, wslot, h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fcur[q][r], G);
+            wslot = wslot == 2 ? 0 : wslot + 1;
+            um_finish(G, h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fcur[q][r], m);
+          }
+#else
           um_finish(L[q][r], h, w, xc, d_clamp(ybb + r + M + 1, 0, h - 1), fcur[q][r], m);
+#endif
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             Vs[bb * RB + r][c][vpos] = (float)vs[c];
@@ -2228,7 +2287,11 @@ __global__ __launch_bounds__(B2_T, 2) void k_flow_iter3(IterArgs a) {
             L[q][r].t0 = L[q][r].t1 = L[q][r].b0 = L[q][r].b1 = L[q][r].q;
             L[q][r].ts.x = L[q][r].ts.y = L[q][r].bs.x = L[q][r].bs.y = m[3];
           } else {
+#if ST_ABLATE & 128
+            um_issue_win(R0, R1, np, h, w, xc, d_clamp(ybb + D * RB + r + M + 1, 0, h - 1), L[q][r]);
+#else
             um_issue(R0, R1, np, h, w, xc, d_clamp(ybb + D * RB + r + M + 1, 0, h - 1), fcur[q][r], L[q][r]);
+#endif
           }
         }
         // flows: the loads requested one batch ago become vectors now and the next rows are requested --

@@ -190,7 +190,12 @@ def rank_table(device, frames, ms, what="", require_distinct=False, stream=None)
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
-    mine = (rank, str(device), int(frames), float(ms))
+    # bus ids repeat from host to host: the device id is qualified by the host name, so that a valid multi-node launch
+    # (same domain:bus:device on two machines) is not mistaken for two ranks on one GPU
+    dev = str(device)
+    if "@" not in dev:
+        dev = "%s@%s" % (dev, socket.gethostname())
+    mine = (rank, dev, int(frames), float(ms))
     rows = [mine]
     if world > 1:
         rows = [None] * world
@@ -199,9 +204,9 @@ def rank_table(device, frames, ms, what="", require_distinct=False, stream=None)
     table = [{"rank": r, "device": d, "frames": f, "ms": m} for r, d, f, m in rows]
     if rank == 0:
         out = stream or sys.stderr
-        out.write("%s%d rank(s)\n  rank  device            frames        ms\n" % (what + ": " if what else "", world))
+        out.write("%s%d rank(s)\n  rank  device                            frames        ms\n" % (what + ": " if what else "", world))
         for t in table:
-            out.write("  %4d  %-16s %7d  %9.3f\n" % (t["rank"], t["device"], t["frames"], t["ms"]))
+            out.write("  %4d  %-32s %7d  %9.3f\n" % (t["rank"], t["device"], t["frames"], t["ms"]))
         out.flush()
     distinct = len({t["device"] for t in table})
     if require_distinct and distinct != world:

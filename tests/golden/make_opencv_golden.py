@@ -51,6 +51,10 @@ def main():
              "480x640": translated_rgb_pair(6, 480, 640, 4, 3), "97x131": translated_rgb_pair(3, 97, 131, 1, -1)}
     st, _ = texture_stream(5, 2, 203, 317)
     cases["203x317"] = (st[0], st[1])
+    # motion that is not a whole-pixel shift: the pairs of tests/test_flow_motion_gpu.py (same seed), at its 480x640
+    from util import MOTION_KINDS, motion_pair
+    for kind in MOTION_KINDS:
+        cases["%s_480x640" % kind] = motion_pair(kind, 3, 480, 640)
     for key, (f0, f1) in cases.items():
         g0, g1 = cv2.cvtColor(f0, cv2.COLOR_BGR2GRAY), cv2.cvtColor(f1, cv2.COLOR_BGR2GRAY)
         out["fb_%s_f0" % key], out["fb_%s_f1" % key] = f0, f1
