@@ -84,6 +84,103 @@ def make_stream(torch, device, n, h, w, seed):
     return frames
 
 
+FLOW_CONTENT_KINDS = ("integer", "subpixel", "zoom", "rotate", "occlusion", "jump", "static", "noise")
+
+
+def make_stream_kind(torch, device, n, h, w, seed, kind):
+    """n RGB frames on the device under one KIND of motion (extra.flow_content; the headline stream is "integer" =
+    make_stream).  The reference op runs on decoded video (scannertools/tests/test_all.py:162-177): sub-pixel, zooming,
+    rotating, occluding motion -- every kind resamples one smooth texture through a per-frame backward map
+    (grid_sample, bicubic, reflected borders), adds the headline stream's +-2 grey levels of noise and rounds to uint8.
+      integer    whole-pixel random walk, steps in [-3, 3] (= make_stream)
+      subpixel   the same walk with real-valued steps
+      zoom       scale 1 + 0.1 sin(2 pi i / 64) about the centre (up to 1 % per frame)
+      rotate     angle 6 deg x sin(2 pi i / 128) about the centre (up to 0.29 deg = 5.6 px at the corners per frame)
+      occlusion  a 480 x 640 rectangle of another texture moving (+5.3, +2.2) px per frame (wrapping) over a background
+                 under a real-valued walk with steps in [-1.5, 1.5]
+      jump       whole-pixel walk with steps in [-24, 24] (wrapping texture)
+      static     one view, noise only
+      noise      independent uniform random bytes
+    """
+    assert kind in FLOW_CONTENT_KINDS, kind
+    if kind == "integer":
+        return make_stream(torch, device, n, h, w, seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=device)
+    if kind == "noise":
+        for i in range(n):
+            frames[i] = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device=device, generator=g)
+        return frames
+    F = torch.nn.functional
+    m = 32
+    H, W = h + 2 * m, w + 2 * m
+
+    def texture():
+        low = torch.rand((1, 3, H // 8 + 2, W // 8 + 2), device=device, generator=g)
+        t = F.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)
+        return (t - t.amin()) / (t.amax() - t.amin()) * 235.0 + 10.0
+
+    tex = texture()
+    fg = texture() if kind == "occlusion" else None
+    rng = np.random.default_rng(seed)
+    yy, xx = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
+                            torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
+    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
+
+    def sample(t, sy, sx):   # t (1,3,H,W) at texture pixel coordinates (sy, sx)
+        grid = torch.stack([sx / (W - 1) * 2 - 1, sy / (H - 1) * 2 - 1], -1)[None]
+        return F.grid_sample(t, grid, mode="bicubic", padding_mode="reflection", align_corners=True)[0].permute(1, 2, 0)
+
+    pos = np.zeros(2)
+    fpos = np.array([w * 0.3, h * 0.25])
+    for i in range(n):
+        if kind == "jump":
+            img = torch.roll(tex[0], (int(pos[1]), int(pos[0])), (1, 2))[:, m:m + h, m:m + w].permute(1, 2, 0)
+            pos = pos + rng.integers(-24, 25, 2)
+        elif kind == "static":
+            img = tex[0, :, m:m + h, m:m + w].permute(1, 2, 0)
+        elif kind == "subpixel":
+            img = sample(tex, yy + (m - pos[1]), xx + (m - pos[0]))
+            pos = np.clip(pos + rng.uniform(-3, 3, 2), -m, m)
+        elif kind == "zoom":
+            sc = 1.0 + 0.1 * np.sin(2 * np.pi * i / 64)
+            img = sample(tex, cy + (yy - cy) / sc + m, cx + (xx - cx) / sc + m)
+        elif kind == "rotate":
+            t = np.deg2rad(6.0) * np.sin(2 * np.pi * i / 128)
+            c_, s_ = float(np.cos(t)), float(np.sin(t))
+            img = sample(tex, cy + (yy - cy) * c_ - (xx - cx) * s_ + m, cx + (yy - cy) * s_ + (xx - cx) * c_ + m)
+        else:  # occlusion
+            img = sample(tex, yy + (m - pos[1]), xx + (m - pos[0]))
+            pos = np.clip(pos + rng.uniform(-1.5, 1.5, 2), -m, m)
+            ry, rx = (yy - fpos[1]) % h, (xx - fpos[0]) % w          # rectangle-local coordinates (wrapping)
+            inside = (ry < 480) & (rx < 640)
+            img = torch.where(inside[..., None], sample(fg, ry + m, rx + m), img)
+            fpos = fpos + np.array([5.3, 2.2])
+        noise = torch.randint(-2, 3, (h, w, 3), device=device, generator=g)
+        frames[i] = (img + noise).round_().clamp_(0, 255).to(torch.uint8)
+    return frames
+
+
+def fill_stream(torch, frames, seed, chunk=250):
+    """Fills `frames` (n,h,w,3 uint8, on the device) with ONE continuous stream of n distinct frames: make_stream's texture
+    under its integer random walk (the walk continues across chunks; every frame has its own noise)."""
+    n, h, w, _ = frames.shape
+    device = frames.device
+    g = torch.Generator(device=device).manual_seed(seed)
+    m = 32
+    low = torch.rand((1, 3, (h + 2 * m) // 8 + 2, (w + 2 * m) // 8 + 2), device=device, generator=g)
+    tex = torch.nn.functional.interpolate(low, size=(h + 2 * m, w + 2 * m), mode="bicubic", align_corners=False)[0]
+    tex = (tex - tex.amin()) / (tex.amax() - tex.amin()) * 235.0 + 10.0
+    rng = np.random.default_rng(seed)
+    pos = np.zeros(2, int)
+    for i in range(n):
+        oy, ox = m - pos[1], m - pos[0]
+        noise = torch.randint(-2, 3, (h, w, 3), device=device, generator=g)
+        frames[i] = (tex[:, oy:oy + h, ox:ox + w].permute(1, 2, 0) + noise).clamp_(0, 255).to(torch.uint8)
+        pos = np.clip(pos + rng.integers(-3, 4, 2), -m, m)
+    return frames
+
+
 def fb_geometry(h, w):
     from scannertools_amd.hip import fb_levels, fb_level_geom
     levels = fb_levels(h, w)
@@ -198,12 +295,15 @@ def timed_flow_hist(torch, ctx, _native, batches, B, bins, steps, warmup, barrie
     return dt, launches, ms
 
 
-def concurrent_instances(torch, device, frames, h, w, bins, ks=(1, 2, 4, 8), pairs=(1, 8)):
+def concurrent_instances(torch, device, frames, h, w, bins, ks=(1, 2, 4, 8), pairs=(1, 8), reps=3):
     """Aggregate frames/s of K concurrent kernel instances (K contexts, K streams, K host threads) each making
-    Histogram + OpticalFlow calls of b pairs, one stream sync per call."""
+    Histogram + OpticalFlow calls of b pairs, one stream sync per call.  Every cell is measured `reps` times (fresh
+    threads, the same contexts); the record carries the median and the range -- these figures move from run to run
+    (round 5: 8 pairs per call, K = 2: 5 951 in one run, 7 757 in another)."""
     from scannertools_amd.hip import HipContext
     rec = {"what": "K instances x (Histogram + OpticalFlow of b pairs per call, st_ctx_sync after every call: the kernel classes' "
-                   "execute()), K host threads, one context and one stream each, 1080p device frames; frames/s over all instances"}
+                   "execute()), K host threads, one context and one stream each, 1080p device frames; frames/s over all instances; "
+                   "median of %d repetitions, [min, max] beside it" % reps}
     nfr = len(frames)
     for b in pairs:
         if b + 1 > nfr:
@@ -214,44 +314,161 @@ def concurrent_instances(torch, device, frames, h, w, bins, ks=(1, 2, 4, 8), pai
             ctxs = [HipContext(device.index) for _ in range(K)]
             flows = [torch.empty((b, h, w, 2), dtype=torch.float32, device=device) for _ in range(K)]
             hists = [torch.empty((b, 3, bins), dtype=torch.int32, device=device) for _ in range(K)]
-            barrier, done, errors = threading.Barrier(K + 1), [0.0] * K, []
+            rates, errors = [], []
+            for rep in range(reps):
+                barrier, done = threading.Barrier(K + 1), [0.0] * K
 
-            def worker(k):
+                def worker(k):
+                    try:
+                        stream = torch.cuda.Stream(device)
+                        with torch.cuda.stream(stream):
+                            for i in range(calls + 2):
+                                if i == 2:          # two warm-up calls (scratch allocation), then all instances start together
+                                    barrier.wait()
+                                j = (i * b + 7 * k + 13 * rep) % (nfr - b)
+                                ctxs[k].histogram(frames[j:j + b], bins, out=hists[k])
+                                ctxs[k].optical_flow(frames[j:j + b + 1], out=flows[k])
+                                ctxs[k].sync()
+                        done[k] = time.perf_counter()
+                    except BaseException as e:  # noqa: BLE001
+                        errors.append(repr(e))
+                        barrier.abort()
+
+                th = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+                for t in th:
+                    t.start()
                 try:
-                    stream = torch.cuda.Stream(device)
-                    with torch.cuda.stream(stream):
-                        for i in range(calls + 2):
-                            if i == 2:          # two warm-up calls (scratch allocation), then all instances start together
-                                barrier.wait()
-                            j = (i * b + 7 * k) % (nfr - b)
-                            ctxs[k].histogram(frames[j:j + b], bins, out=hists[k])
-                            ctxs[k].optical_flow(frames[j:j + b + 1], out=flows[k])
-                            ctxs[k].sync()
-                    done[k] = time.perf_counter()
-                except BaseException as e:  # noqa: BLE001
-                    errors.append(repr(e))
-                    barrier.abort()
-
-            th = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
-            for t in th:
-                t.start()
-            try:
-                barrier.wait()
-            except threading.BrokenBarrierError:
-                pass
-            t0 = time.perf_counter()
-            for t in th:
-                t.join()
+                    barrier.wait()
+                except threading.BrokenBarrierError:
+                    pass
+                t0 = time.perf_counter()
+                for t in th:
+                    t.join()
+                if errors:
+                    break
+                rates.append(K * calls * b / (max(done) - t0))
             for c in ctxs:
                 c.close()
             del flows, hists
             if errors:
                 by_k["K_%d" % K] = {"error": errors[0]}
                 break
-            dt = max(done) - t0
-            by_k["K_%d" % K] = {"frames_per_s": K * calls * b / dt, "ms_per_call": dt / calls * 1e3}
+            med = float(np.median(rates))
+            by_k["K_%d" % K] = {"frames_per_s": med, "frames_per_s_range": [min(rates), max(rates)],
+                                "ms_per_call": K * b / med * 1e3}
         rec["pairs_per_call_%d" % b] = by_k
     return rec
+
+
+def flow_content(torch, ctx, _native, device, args, hist_out, steps=3):
+    """The headline step (Histogram on B frames + OpticalFlow on the B pairs) on streams of other KINDS of motion than the
+    headline's whole-pixel walk: frames/s, the flow-iteration kernel's time per launch, and what the estimated field looks
+    like (mean |flow|, the share of 64-pixel row runs whose gather stays in one source row).  One batch per kind, `steps`
+    timed steps after one warm-up."""
+    B, h, w, bins = args.batch, args.height, args.width, args.bins
+    rec = {"what": "256-pair step of the headline (Histogram + OpticalFlow, %dx%d) per kind of motion (bench.py: make_stream_kind); "
+                   "iter_avg_launch_ms = HIP-event time per k_flow_iter3 launch; parity per kind: tests/test_flow_motion_gpu.py" % (w, h)}
+    flow_out = torch.empty((B, h, w, 2), dtype=torch.float32, device=device)
+    sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+    for kind in FLOW_CONTENT_KINDS:
+        try:
+            fr = make_stream_kind(torch, device, B + 1, h, w, 7000 + FLOW_CONTENT_KINDS.index(kind), kind)
+            dt, launches, ms = timed_flow_hist(torch, ctx, _native, [fr], B, bins, steps, 1, sync, flow_out, hist_out)
+            fl = flow_out[:: max(B // 8, 1)]
+            mag = torch.linalg.vector_norm(fl, dim=-1)
+            # how coherent the R1 gather is: a wave covers 64 consecutive pixels of a row; its gather touches one source
+            # row pair when floor(y + fy) - y is the same for all of them
+            dy = torch.floor(fl[..., 1])[:, :, : (w // 64) * 64].reshape(fl.shape[0], h, w // 64, 64)
+            dx = torch.floor(fl[..., 0])[:, :, : (w // 64) * 64].reshape(fl.shape[0], h, w // 64, 64)
+            one_row = (dy.amax(-1) == dy.amin(-1)).float().mean()
+            one_col = (dx.amax(-1) == dx.amin(-1)).float().mean()
+            rec[kind] = {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3,
+                         "iter_avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                         "mean_abs_flow_px": float(mag.mean()), "p99_abs_flow_px": float(torch.quantile(mag.flatten()[::97], 0.99)),
+                         "waves_gathering_one_row": float(one_row), "waves_gathering_one_column_offset": float(one_col)}
+            del fr, fl, mag, dy, dx
+        except Exception as e:  # auxiliary record
+            rec[kind] = {"error": repr(e)}
+    del flow_out
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_shard(torch, ctx, frames, rows, lo, n_total, B, bins, flow_ring, hists, events=None):
+    """One rank's work on its shard of a stream -- the code path `--gpus N` shards with (scannertools_amd.sharding):
+    `rows` = [a, b) are the output rows the rank owns, `frames` its resident frames (rows + the halo frame of the
+    OpticalFlow stencil {0,1}), frame `lo` being frames[0].  Calls of B rows: Histogram on the rows' frames, OpticalFlow
+    on the rows' (clamped) pairs; flow fields are overwritten in a ring.  Returns the number of calls."""
+    from scannertools_amd.sharding import local_pairs
+    a, b = rows
+    calls = 0
+    for s0 in range(a, b, B):
+        s1 = min(s0 + B, b)
+        pairs = local_pairs((s0, s1), (lo, lo + len(frames)), n_total)          # indices into `frames`
+        f0, f1 = int(pairs.min()), int(pairs.max()) + 1
+        ctx.histogram(frames[s0 - lo:s1 - lo], bins, out=hists[s0 - a:s1 - a])
+        ctx.optical_flow(frames[f0:f1], pairs=pairs - f0, out=flow_ring[calls % len(flow_ring)][:s1 - s0])
+        if events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            events.append((s1 - a, ev))
+        calls += 1
+    return calls
+
+
+def stream_10k(torch, ctx, device, args, n=10000):
+    """The north star's own stream, once: n DISTINCT 1080p frames resident in HBM (62 GB), Histogram on all of them and
+    OpticalFlow on every row of the stream (Scanner's stencil {0,1}: n rows, the last one's window clamped to the edge
+    frame) in calls of B rows through the shard code of the multi-GPU path; frames/s overall and per ~1 000 frames
+    (drift), and the same for ONE rank's shard of an 8-GPU split (1 250 rows + 1 halo frame)."""
+    from scannertools_amd.sharding import flow_shard
+    B, h, w, bins = args.batch, args.height, args.width, args.bins
+    free, _ = torch.cuda.mem_get_info(device)
+    need = n * h * w * 3 + 2 * B * h * w * 8 + (24 << 30)
+    if free < need:
+        return {"skipped": "needs %.0f GB of free device memory, %.0f GB free" % (need / 1e9, free / 1e9)}
+    t0 = time.perf_counter()
+    frames = fill_stream(torch, torch.empty((n, h, w, 3), dtype=torch.uint8, device=device), 99)
+    torch.cuda.synchronize(device)
+    t_gen = time.perf_counter() - t0
+    ring = [torch.empty((B, h, w, 2), dtype=torch.float32, device=device) for _ in range(2)]
+    hists = torch.empty((n, 3, bins), dtype=torch.int32, device=device)
+    out = {"what": "%d distinct %dx%d frames resident (%.1f GB); Histogram (%d bins) on every frame + OpticalFlow on every row "
+                   "(stencil {0,1}, last window clamped) in calls of %d rows through sharding.flow_shard / local_pairs; flow "
+                   "fields overwritten in a ring of 2; inputs resident, no host transfer in the timed region" % (n, w, h, n * h * w * 3 / 1e9, bins, B),
+           "generation_s": t_gen}
+    for name, world in (("whole_stream_1_rank", 1), ("one_shard_of_8_ranks", 8)):
+        rows, fr = flow_shard(n, 0, world)
+        local = frames[fr[0]:fr[1]]
+        run_shard(torch, ctx, local[:min(len(local), B + 1)], (rows[0], min(rows[1], rows[0] + B)), fr[0], n, B, bins, ring, hists)  # warm-up
+        torch.cuda.synchronize(device)
+        best = None
+        for _rep in range(2):
+            events = []
+            start = torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            start.record()
+            calls = run_shard(torch, ctx, local, rows, fr[0], n, B, bins, ring, hists, events)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, calls, [(k, start.elapsed_time(ev)) for k, ev in events])
+        dt, calls, marks = best
+        # frames/s per ~1 000 rows: between the call boundaries nearest to every multiple of 1 000
+        per, last_k, last_ms = [], 0, 0.0
+        for k, ms in marks:
+            if k - last_k >= 1000 or k == marks[-1][0]:
+                per.append(round((k - last_k) / max(ms - last_ms, 1e-9) * 1e3, 1))
+                last_k, last_ms = k, ms
+        out[name] = {"rows": rows[1] - rows[0], "resident_frames": fr[1] - fr[0], "calls": calls, "seconds": dt,
+                     "frames_per_s": (rows[1] - rows[0]) / dt, "frames_per_s_per_1000_rows": per,
+                     "frames_per_s_by_event_clock": (rows[1] - rows[0]) / (marks[-1][1] * 1e-3)}
+    # the stream's own content check: distinct frames (no two consecutive histograms equal), the last row's clamped pair gives a zero field
+    hs = hists.cpu().numpy()
+    out["distinct_consecutive_histograms"] = bool((np.abs(np.diff(hs.astype(np.int64), axis=0)).sum((1, 2)) > 0).all())
+    del frames, ring, hists
+    torch.cuda.empty_cache()
+    return out
 
 
 def extras(torch, ctx, _native, device, args, batches, hist_out):
@@ -297,6 +514,13 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
                      "the same launch's duration in the committed rocprofv3 kernel trace (marker events around the launch, as "
                      "rounds 1-3 measured it, read 5-6 us more)")
     out["histogram_small_batches"] = small
+
+    # (iii-b) the headline step on other kinds of motion than the whole-pixel walk (round-5 verdict, item 2)
+    if not args.no_content:
+        try:
+            out["flow_content"] = flow_content(torch, ctx, _native, device, args, hist_out)
+        except Exception as e:  # auxiliary record
+            out["flow_content"] = {"error": repr(e)}
 
     # (iv) OpticalFlow at the batch sizes a drop-in graph uses: the reference creates the op with no batch= (one pair per
     # execute(): tests/test_all.py:166, old/histograms.py:70-72).  Two ways of calling, no HIP-event brackets in either:
@@ -659,6 +883,14 @@ def extras(torch, ctx, _native, device, args, batches, hist_out):
         out["host_fed"] = fed
     except Exception as e:  # the headline must not die on an auxiliary record
         out["host_fed"] = {"error": repr(e)}
+    # the north star's own stream: 10 000 distinct 1080p frames through both ops once (round-5 verdict, item 3)
+    if not args.no_stream10k:
+        try:
+            ctx.release_workspace()
+            torch.cuda.empty_cache()
+            out["stream_10k"] = stream_10k(torch, ctx, device, args)
+        except Exception as e:  # auxiliary record
+            out["stream_10k"] = {"error": repr(e)}
     return out
 
 
@@ -977,12 +1209,24 @@ def main():
     ap.add_argument("--no-4k", action="store_true")
     ap.add_argument("--no-pose", action="store_true", help="skip the pose-network extra (config 5)")
     ap.add_argument("--no-shots", action="store_true", help="skip the 10 000-frame shot-detection extra (config 3)")
+    ap.add_argument("--no-content", action="store_true", help="skip extra.flow_content (the step on other kinds of motion)")
+    ap.add_argument("--no-stream10k", action="store_true", help="skip extra.stream_10k (10 000 distinct resident frames: 62 GB)")
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=1)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test on CPU (gloo): rendezvous + barriers + reduction around a dummy step")
     args = ap.parse_args()
+
+    # The native libraries are not shipped to the GPU box (.gpurunignore): whoever runs first there compiles them.  In a child
+    # process, so that this one (which may still have to spawn its ranks) loads nothing; ranks under an external launcher
+    # leave it to local rank 0 and wait for the file lock.
+    if not args.dry_run:
+        import fcntl
+        import subprocess
+        with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.ensure_built()"], cwd=ROOT)
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:

@@ -44,6 +44,10 @@ enum st_status {
 typedef struct st_ctx st_ctx;
 
 int st_abi_version(void);
+/* "src=<first 16 hex digits of the sha256 over the library's sources, in the Makefile's order> host=<machine that compiled
+ * it> at=<UTC time>": which sources this binary was built from and where (no reference counterpart: build provenance, so
+ * that a test run can show it loaded a library compiled on the machine it runs on from the tree it runs in). */
+const char* st_build_info(void);
 const char* st_status_string(int status);
 int st_device_count(int* count);
 

@@ -86,6 +86,7 @@ _c = ctypes
 _vp, _i, _sz, _d = _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_double
 SIGNATURES = {
     "st_abi_version": (_i, []),
+    "st_build_info": (_c.c_char_p, []),
     "st_status_string": (_c.c_char_p, [_i]),
     "st_device_count": (_i, [_c.POINTER(_i)]),
     "st_ctx_create": (_i, [_i, _c.POINTER(_vp)]),
@@ -152,6 +153,24 @@ def build(verbose=False):
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=out)
     return LIB_PATH
+
+
+def source_hash():
+    """First 16 hex digits of the sha256 over the library's sources as the Makefile computes it (`make srchash`): what
+    st_build_info() of a library built from THIS tree reports."""
+    import hashlib
+    srcs = ["st_context.hip", "st_hist.hip", "st_farneback.hip", "st_flowvis.hip", "st_imgproc.hip", "st_pose.hip", "st_conv.hip",
+            "st_conv_tile_bf16x3.hip", "st_conv_tile_f32.hip", "st_internal.h", "st_conv_tile.h",
+            os.path.join("..", "..", "include", "scannertools_hip.h"), "Makefile"]
+    hsh = hashlib.sha256()
+    for f in srcs:
+        hsh.update(open(os.path.join(CSRC, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def build_info():
+    """{'src': ..., 'host': ..., 'at': ...} of the loaded library (st_build_info)."""
+    return dict(kv.split("=", 1) for kv in lib().st_build_info().decode().split(" "))
 
 
 def lib():

@@ -21,6 +21,17 @@ int st_enter(st_ctx* ctx) {
 
 ST_EXPORT int st_abi_version(void) { return ST_ABI_VERSION; }
 
+#ifndef ST_SRC_HASH
+#define ST_SRC_HASH "unknown"
+#endif
+#ifndef ST_BUILD_HOST
+#define ST_BUILD_HOST "unknown"
+#endif
+#ifndef ST_BUILD_TIME
+#define ST_BUILD_TIME "unknown"
+#endif
+ST_EXPORT const char* st_build_info(void) { return "src=" ST_SRC_HASH " host=" ST_BUILD_HOST " at=" ST_BUILD_TIME; }
+
 ST_EXPORT const char* st_status_string(int status) {
   switch (status) {
     case ST_OK: return "ok";

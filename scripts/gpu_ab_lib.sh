@@ -4,9 +4,19 @@ export GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"  
 # "default" = the production library; every other name = scannertools_amd/lib_exp_<name>.  Optional env BENCH_ARGS.
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/abl
-for name in "$@"; do
+# The .so files do not travel to the GPU box (.gpurunignore): the production library is built here first, and a variant given
+# as name=FLAGS (e.g. abl128=-DST_ABLATE=128) is built on the spot when its library is missing.
+python -c "import __graft_entry__ as g; g.ensure_built()"
+for item in "$@"; do
+  name="${item%%=*}"
   lib=""
-  [ "$name" != "default" ] && lib="$GRAFT_REPO_ROOT/scannertools_amd/lib_exp_$name/libscannertools_hip.so"
+  if [ "$name" != "default" ]; then
+    lib="$GRAFT_REPO_ROOT/scannertools_amd/lib_exp_$name/libscannertools_hip.so"
+    if [ ! -f "$lib" ]; then
+      flags=""; [ "$item" != "$name" ] && flags="${item#*=}"
+      bash scripts/build_variant.sh "$name" "$flags" > /dev/null || { echo "$name BUILD FAILED"; continue; }
+    fi
+  fi
   ST_HIP_LIB=$lib timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > gpurun_out/abl/$name.json 2> gpurun_out/abl/$name.err
   python - "$name" gpurun_out/abl/$name.json <<'PY'
 import json,sys

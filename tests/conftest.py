@@ -13,16 +13,12 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """Build the native libraries if a fresh checkout has none (hipcc cross-compiles without a GPU).
-    Built artefacts are git-ignored; normally __graft_entry__.build() has produced them already."""
-    lib = os.path.join(ROOT, "scannertools_amd", "lib")
-    need = [os.path.join(lib, "libscannertools_hip.so"), os.path.join(lib, "libscannertools_imgproc.so"),
-            os.path.join(ROOT, "oracle", "liboracle.so")]
-    if not all(os.path.exists(p) for p in need):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "scannertools_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "scannertools_amd", "scanner_kernels")], stdout=subprocess.DEVNULL)
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
+    """Build the native libraries when one is missing or the HIP library was made from other sources than this tree's
+    (hipcc cross-compiles without a GPU).  Built artefacts are git-ignored AND withheld from the GPU box
+    (.gpurunignore), so a GPU test session compiles what it tests on the machine it runs on;
+    tests/test_host.py::test_library_matches_the_tree and test_hist_gpu.py::test_library_was_built_here check it."""
+    import __graft_entry__ as g
+    g.ensure_built()
 
 
 @pytest.fixture(scope="session")

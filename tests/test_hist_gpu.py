@@ -160,3 +160,19 @@ def test_hist_alternative_kernels(env):
     e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT], env=e, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_library_was_built_here(hip_ctx):
+    """The library this session loaded was compiled ON THIS MACHINE from this tree's sources: the .so files are withheld
+    from the GPU box (.gpurunignore), so tests/conftest.py's session start ran the build (hipcc --offload-arch=gfx950 on
+    the target); its record sits beside the libraries."""
+    import json
+    import os
+    import socket
+    from scannertools_amd import _native
+    info = _native.build_info()
+    assert info["src"] == _native.source_hash()
+    assert info["host"] == socket.gethostname(), ("library compiled on %r, running on %r" % (info["host"], socket.gethostname()))
+    rec = json.load(open(os.path.join(os.path.dirname(_native.LIB_PATH), "build_record.json")))
+    assert rec["host"] == socket.gethostname() and rec["source_hash"] == info["src"]
+    print("built on target: %s in %.1f s (%s, %s cpus)" % (info, rec["seconds"], rec["jobs"], rec["cpus"]))

@@ -242,6 +242,23 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_native.SIGNATURES) == names
 
 
+def test_library_matches_the_tree():
+    """st_build_info: the library was made from exactly the sources of this tree (the Makefile hashes them into it), and
+    __graft_entry__.ensure_built() -- what conftest, smoke() and bench.py call first -- therefore leaves it alone."""
+    from scannertools_amd import _native
+    info = _native.build_info()
+    assert set(info) == {"src", "host", "at"}
+    assert info["src"] == _native.source_hash(), "libscannertools_hip.so was built from other sources: run make"
+    out = subprocess.check_output(["make", "-s", "--no-print-directory", "-C", os.path.join(ROOT, "scannertools_amd", "csrc"), "srchash"], text=True)
+    assert out.strip() == info["src"]
+
+
+def test_native_libraries_do_not_travel_to_the_gpu_box():
+    """The GPU box must compile what it tests: *.so is withheld from the snapshot (round-5 verdict, item 4)."""
+    ign = open(os.path.join(ROOT, ".gpurunignore")).read().split()
+    assert "*.so" in ign and "*.o" in ign
+
+
 def test_abi_host_only_entry_points():
     from scannertools_amd import _native
     import oracle
