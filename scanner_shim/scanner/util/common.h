@@ -65,17 +65,19 @@ struct LogStream {
   ~LogStream() {
     if (!active) return;
     static const char* const names[4] = {"INFO", "WARNING", "ERROR", "FATAL"};
-    fprintf(stderr, "%s: %s\n", names[severity < 0 || severity > 3 ? 3 : severity], text.c_str());
-    if (severity >= 3) abort();
+    // a severity outside the four is printed as such, it does not turn into FATAL
+    if (severity >= 0 && severity <= 3) fprintf(stderr, "%s: %s\n", names[severity], text.c_str());
+    else fprintf(stderr, "LOG(%d): %s\n", severity, text.c_str());
+    if (severity == 3) abort();
   }
 };
+// glog's spelling, LOG(INFO) / LOG_IF(FATAL, cond), by token pasting: the severities are ST_LOG_* constants, and the bare
+// words INFO / WARNING / ERROR / FATAL are NOT defined as macros (they would rewrite every later use of those identifiers --
+// enum values, generated protobuf code -- in each translation unit that includes this header).
+enum { ST_LOG_INFO = 0, ST_LOG_WARNING = 1, ST_LOG_ERROR = 2, ST_LOG_FATAL = 3 };
 #ifndef LOG
-#define INFO 0
-#define WARNING 1
-#define ERROR 2
-#define FATAL 3
-#define LOG(severity) ::scanner::LogStream(true, severity)
-#define LOG_IF(severity, cond) ::scanner::LogStream(static_cast<bool>(cond), severity)
+#define LOG(severity) ::scanner::LogStream(true, ::scanner::ST_LOG_##severity)
+#define LOG_IF(severity, cond) ::scanner::LogStream(static_cast<bool>(cond), ::scanner::ST_LOG_##severity)
 #endif
 
 }  // namespace scanner

@@ -90,9 +90,9 @@ void host_free(u8* p) {
 
 // Device buffers come from a pool too (Scanner's workers allocate element buffers from pooled blocks, not from the
 // driver): a hipMalloc + hipFree pair per execute() costs tens of microseconds, which is a tenth of a single-pair
-// OpticalFlow call.  Same reuse rule as the host pool.  The pool is bounded (SCANNER_SHIM_DEV_POOL_MB, default 4096; 0
-// turns it off), drained when the driver runs out of memory (a job that changes its batch or frame size, or shares the GPU
-// with another allocator, must not die while idle blocks sit here) and at process exit.
+// OpticalFlow call.  Same reuse rule as the host pool.  The pool is bounded (SCANNER_SHIM_DEV_POOL_MB; default a quarter
+// of the device's memory, at least 4 GB; 0 turns it off) and drained when the driver runs out of memory (a job that changes
+// its batch or frame size, or shares the GPU with another allocator, must not die while idle blocks sit here).
 // Ownership rule (Scanner's own for its pooled element buffers): whoever frees a buffer has finished with it -- a kernel's
 // execute() returns with its inputs consumed and its outputs complete (every kernel class of this library synchronises
 // its stream before it returns), so no queued work touches a block when it comes back here.  hipFree would ALSO have
@@ -107,8 +107,16 @@ size_t g_dev_pooled_bytes = 0;
 size_t dev_pool_cap() {
   static const size_t cap = [] {
     const char* e = getenv("SCANNER_SHIM_DEV_POOL_MB");
-    const long long mb = e && *e ? atoll(e) : 4096;
-    return (size_t)(mb < 0 ? 0 : mb) << 20;
+    if (e && *e) {
+      const long long mb = atoll(e);
+      return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }
+    // default: a quarter of the device's memory, at least 4 GB (the output of one 256-pair 1080p OpticalFlow call is
+    // 4.25 GB: under a fixed 4 GB cap every such execute() went back to hipMalloc / hipFree and their device-wide sync)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+    const size_t quarter = total_b / 4, floor_b = (size_t)4096 << 20;
+    return quarter > floor_b ? quarter : floor_b;
   }();
   return cap;
 }
@@ -137,14 +145,10 @@ size_t drain_dev_pool(int device) {
   return bytes;
 }
 
-struct DevPoolAtExit {
-  ~DevPoolAtExit() {
-    // the HIP runtime may already be shutting down: release what it still lets us release, ignore the rest
-    int n = 0;
-    if (hipGetDeviceCount(&n) == hipSuccess && n > 0) (void)drain_dev_pool(-1);
-    (void)hipGetLastError();
-  }
-} g_dev_pool_at_exit;
+// No drain from a static destructor: at that point the HIP runtime (and, in a Python process, torch's allocator) may already
+// be tearing down, daemon threads may still be in raw_free, and a late hipFree is a known source of exit-time hangs.  The
+// driver reclaims the pooled blocks when the process ends; a process that wants them back earlier calls
+// stshim_dev_pool_drain (scannertools_amd.engine registers it with atexit, which runs before the runtime goes away).
 
 u8* raw_alloc(DeviceHandle device, size_t size) {
   void* p = nullptr;

@@ -1,4 +1,5 @@
 // Context, error reporting, scratch arena and per-kernel event timing for libscannertools_hip.so.
+#include <cstring>
 #include <cstdlib>
 
 #include "st_internal.h"
@@ -82,7 +83,8 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
     // The library is compiled for gfx950 and its kernels are sized for that chip's 160 KB of LDS per workgroup (the Histogram
     // counters take 96 KB, the role-split flow iteration 129 / 158 KB, the convolution tiles up to 104 KB): a device with less
     // is refused here, once, instead of failing at some later launch.
-    if (prop.sharedMemPerBlock < kMinLdsBytes) {
+    // ... and the code object holds gfx950 code only: another architecture (even one with as much LDS) has no kernel to run
+    if (prop.sharedMemPerBlock < kMinLdsBytes || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
       (void)hipStreamDestroy(c->own_stream);
       delete c;
       return ST_ERR_UNSUPPORTED;

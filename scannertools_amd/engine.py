@@ -104,6 +104,10 @@ def _load_op_library(path):
         L.stshim_dev_pool_bytes.argtypes = []
         L.stshim_dev_pool_drain.restype = sz
         L.stshim_dev_pool_drain.argtypes = [ci]
+        # the library's device-buffer pool is handed back while the HIP runtime is still up (Python's atexit runs before the
+        # runtime's own teardown; the library itself no longer frees anything from a static destructor)
+        import atexit
+        atexit.register(L.stshim_dev_pool_drain, -1)
         _LIBS[path] = L
     return _LIBS[path]
 

@@ -139,6 +139,8 @@ def layers_from_prototxt(path):
         typ = str(layer.get("type", [""])[0])
         name = str(layer.get("name", [""])[0])
         bottoms, tops = layer.get("bottom", []), layer.get("top", [])
+        if typ in ("Convolution", "CONVOLUTION", "ReLU", "RELU", "Pooling", "POOLING", "Concat", "CONCAT") and not (bottoms and tops):
+            raise ValueError("prototxt layer %s (%s) has no %s blob" % (name, typ, "bottom" if not bottoms else "top"))
         if typ in ("Input",):
             shape = layer.get("input_param", [{}])[0].get("shape", [{}])[0].get("dim", [])
             if tops and len(shape) >= 2:
@@ -186,12 +188,24 @@ def names_from_prototxt(path):
     net = parse_prototxt(open(path).read())
     readers, pool_of, concats, alias = {}, {}, [], {}
     layers = net.get("layer", []) + net.get("layers", [])
+    def io(layer, key):
+        """First `top` / `bottom` blob of a layer; a layer without it is a malformed description (ValueError, like pose_net.h)."""
+        v = layer.get(key) or []
+        if not v:
+            raise ValueError("prototxt %s: layer %s (%s) has no %s blob" % (path, str(layer.get("name", ["?"])[0]),
+                                                                          str(layer.get("type", ["?"])[0]), key))
+        return v[0]
+
     for layer in layers:      # a ReLU that is not in place renames its blob
-        if str(layer.get("type", [""])[0]) in ("ReLU", "RELU") and layer["top"][0] != layer["bottom"][0]:
-            alias[layer["top"][0]] = layer["bottom"][0]
+        if str(layer.get("type", [""])[0]) in ("ReLU", "RELU") and io(layer, "top") != io(layer, "bottom"):
+            alias[io(layer, "top")] = io(layer, "bottom")
 
     def blob(b):
-        while b in alias:
+        seen = set()
+        while b in alias:   # two renaming ReLUs a -> b, b -> a would walk forever (pose_net.h caps its walk as well)
+            if b in seen:
+                raise ValueError("prototxt %s: the ReLU layers rename blob %r in a cycle" % (path, b))
+            seen.add(b)
             b = alias[b]
         return b
 
@@ -200,9 +214,9 @@ def names_from_prototxt(path):
     for layer in layers:
         typ = str(layer.get("type", [""])[0])
         if typ in ("Pooling", "POOLING"):
-            pool_of[blob(layer["bottom"][0])] = layer["top"][0]
+            pool_of[blob(io(layer, "bottom"))] = io(layer, "top")
         elif typ in ("Concat", "CONCAT"):
-            concats.append(([blob(b) for b in layer.get("bottom", [])], layer["top"][0]))
+            concats.append(([blob(b) for b in layer.get("bottom", [])], io(layer, "top")))
 
     def expect(conv, spec):
         aname, aci, aco, ak, arelu = spec

@@ -97,14 +97,19 @@ class OpenPoseKernelHIPImpl : public BatchedKernel, public VideoKernel {
     std::string proto = args_.model_directory + "/pose/coco/pose_deploy_linevec.prototxt", probe;
     if (!pose::read_file(proto, &probe)) proto.clear();
     const std::string model = args_.model_directory + "/pose/coco/pose_iter_440000.caffemodel";
-    bool loaded = net_.load(model, &err, proto);
-    if (!loaded && !proto.empty()) {
+    if (!proto.empty()) {
       // The description was found by probing, not named by the caller (OpenPoseArgs has no field for it): a file this
-      // reader cannot follow must not make a model unusable that loads by the published layer names.
-      std::string err2;
-      loaded = net_.load(model, &err2);
-      if (loaded) LOG(WARNING) << "OpenPose: ignoring " << proto << " (" << err << "); weights loaded by the published layer names";
+      // reader cannot FOLLOW (parse or structure) must not make a model unusable that loads by the published layer names.
+      // Only that failure falls back; a description that parses and then names weights the caffemodel lacks, or an upload
+      // that fails, is an error (and nothing is loaded twice over a half-loaded net).
+      std::vector<std::string> names;
+      std::string perr;
+      if (!pose::prototxt_layer_names(proto, &names, &perr)) {
+        LOG(WARNING) << "OpenPose: ignoring " << proto << " (" << perr << "); weights are looked up by the published layer names";
+        proto.clear();
+      }
     }
+    const bool loaded = net_.load(model, &err, proto);
     if (!loaded) RESULT_ERROR(&valid_, "OpenPose: %s", err.c_str());
     for (int c = 0; c < 57; ++c) chan_[c] = c < pose::kHeat ? pose::kOffHeat + c : pose::kOffPaf + (c - pose::kHeat);
   }

@@ -269,7 +269,7 @@ inline bool prototxt_layer_names(const std::string& path, std::vector<std::strin
   std::map<std::string, std::vector<const ProtoLayer*>> readers;
   std::vector<const ProtoLayer*> concats;
   for (auto& l : layers) {
-    if ((l.conv() || l.pool() || l.concat()) && (l.bottoms.empty() || l.tops.empty())) {
+    if ((l.conv() || l.pool() || l.concat() || l.relu()) && (l.bottoms.empty() || l.tops.empty())) {
       *err = "prototxt layer " + l.name + " names no bottom / top blob (" + path + ")";
       return false;
     }
@@ -415,6 +415,7 @@ class Net {
       *err = "SCANNERTOOLS_POSE_MATH=" + bad_math_ + " is not an arithmetic of this build (f32, bf16x3)";
       return false;
     }
+    release();  // a second load (or one after a failure part-way through) starts from nothing: no allocation is overwritten
     std::vector<std::string> file_names;
     if (!prototxt.empty() && !prototxt_layer_names(prototxt, &file_names, err)) return false;
     std::map<std::string, Blobs> blobs;

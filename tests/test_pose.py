@@ -559,6 +559,19 @@ def test_prototxt_is_read_and_checked(tmp_path):
     fancy = tmp_path / "fancy.prototxt"
     fancy.write_text("# a comment\n" + text.replace("convolution_param {", "convolution_param: {", 3).replace('"Convolution"', "'Convolution'", 2))
     assert pose_net.names_from_prototxt(fancy) == pose_net.caffe_layer_names() and pose_net.check_prototxt(fancy) == 92
+    # malformed descriptions are ValueErrors, never a hang or a KeyError: two renaming ReLUs in a cycle, a layer without blobs
+    cyc = tmp_path / "cycle.prototxt"
+    cyc.write_text(text + '\nlayer { name: "ra" type: "ReLU" bottom: "xa" top: "xb" }\nlayer { name: "rb" type: "ReLU" bottom: "xb" top: "xa" }\n'
+                          'layer { name: "cc" type: "Concat" bottom: "xa" bottom: "xb" top: "xc" }\n')
+    with pytest.raises(ValueError, match="cycle"):
+        pose_net.names_from_prototxt(cyc)
+    for frag in ('layer { name: "rn" type: "ReLU" bottom: "conv1_1" }', 'layer { name: "pn" type: "Pooling" top: "zz" }',
+                 'layer { name: "cn" type: "Concat" bottom: "conv1_1" }'):
+        nob = tmp_path / "noblob.prototxt"
+        nob.write_text(text + "\n" + frag + "\n")
+        for check in (pose_net.names_from_prototxt, pose_net.check_prototxt):
+            with pytest.raises(ValueError, match="blob"):
+                check(nob)
     broken = tmp_path / "broken.prototxt"
     broken.write_text(text[:len(text) // 2])
     with pytest.raises(ValueError):
