@@ -72,6 +72,7 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (const char* e = getenv("ST_ITER_TILE")) c->tile_mode = atoi(e);
   if (const char* e = getenv("ST_ITER_TILE_PX")) c->tile_px = atoll(e);
   c->fold_gray = getenv("ST_PYR_FOLD_GRAY") != nullptr;
+  if (const char* e = getenv("ST_POLY_U8")) c->poly_u8 = atoi(e) != 0;
   if (const char* e = getenv("ST_ITER_ROLES")) c->roles_mode = atoi(e);
   if (const char* e = getenv("ST_ROLES_NCW")) c->roles_ncw = atoi(e);
   if (const char* e = getenv("ST_ROLES_ROWS")) c->roles_rows = atoi(e);

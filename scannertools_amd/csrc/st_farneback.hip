@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrFusedArgs a) {
 // in one wave), three waves share a SIMD, and each role keeps only its own rings in registers.  Arithmetic and
 // association are those of k_pyr_fused (and of k_pyr0 / k_pyr_dec): bit-identical images.
 // ---------------------------------------------------------------------------------------------
-template <int ROLE>
+template <int ROLE, bool L0 = true>
 __device__ __forceinline__ void pyr_role_run(const PyrFusedArgs& a, unsigned (*srow)[PF_RB][PF_ROWDW]) {
   const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
   const int h = a.h, w = a.w;
@@ -953,7 +953,7 @@ __device__ __forceinline__ void pyr_role_run(const PyrFusedArgs& a, unsigned (*s
         float bb[12];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { bb[k] = pf_byte(d0, k); bb[4 + k] = pf_byte(d1, k); bb[8 + k] = pf_byte(d2, k); }
-        {
+        if (L0) {  // level 0 (L0 = false: k_polyexp takes it from the gray frame itself, see polyexp_body<.., U8>)
           float hp[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) hp[j] = bb[4 + j] * a.k0[1] + (bb[3 + j] + bb[5 + j]) * a.k0[0];
@@ -1047,10 +1047,11 @@ __device__ __forceinline__ void pyr_role_run(const PyrFusedArgs& a, unsigned (*s
   }
 }
 
+template <bool L0>
 __global__ __launch_bounds__(768) void k_pyr_roles(PyrFusedArgs a) {
   __shared__ unsigned srow[2][PF_RB][PF_ROWDW];
   const int role = threadIdx.x >> 8;  // wave-uniform; every role passes the same barriers
-  if (role == 0) pyr_role_run<0>(a, srow);
+  if (role == 0) pyr_role_run<0, L0>(a, srow);
   else if (role == 1) pyr_role_run<1>(a, srow);
   else pyr_role_run<2>(a, srow);
 }
@@ -1112,6 +1113,7 @@ __device__ __forceinline__ float4 ldf4(const float* __restrict__ base, unsigned 
 // ---------------------------------------------------------------------------------------------
 struct PolyArgs {
   const float* img;  // n x (h*w)
+  const uint8_t* gray;  // k_polyexp_u8: n x (h*w) gray bytes; level 0's 3x3 blur is evaluated on the fly
   float* R;          // n x (h*w float4 + h*w float), see "R layout" above update_matrices_px
   int h, w, rows_per_seg;
   PolyCoef c;
@@ -1140,9 +1142,16 @@ constexpr int PE_OUT = 240;
 //     was issued and waits for the batch's own stores (vmcnt retires in order).
 // Same values, same operations in the same order: bit-identical results.  Measured per 257 frames of 1080p, same box:
 // 4.38 -> 4.25 (i, ii) -> 4.21 ms (iii).
-template <int N, class A>
+// U8 (level 0 of the default pyramid only): the source is the GRAY frame and the level's image -- GaussianBlur with the fixed
+// 3 x 3 kernel [1/4 1/2 1/4] (sigma 0), BORDER_REFLECT_101, resize by 1 -- is evaluated where the row loader used to read
+// it: I0 is never written nor read (-7 of the 30 bytes per pixel the two kernels moved for this level).  Every intermediate
+// of that blur is a multiple of 1/16 below 256, exact in float whatever the order of operations, so the integer form
+// (b[x-1] + 2 b[x] + b[x+1] by one v_dot4_u32_u8 on a dword of four neighbouring bytes, rows combined 1-2-1, one conversion,
+// one multiplication by 1/16) gives the float expression's bits.  Per-thread constants place the dword inside the row and
+// carry the reflected weights at the frame's left / right edge; the rows of the 3-row window roll in registers.
+template <int N, class A, bool U8 = false>
 __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict__ img, float* __restrict__ Rbase, int h, int w,
-                                             int rows_per_seg, int bx, int by, int z) {
+                                             int rows_per_seg, int bx, int by, int z, const uint8_t* __restrict__ gray = nullptr) {
   constexpr int PXW = 3 * PE_RB + 1;   // words per pixel: PE_RB rows x 3 sums + 1 pad
   __shared__ float sv[2][256 * PXW];
   const int tid = threadIdx.x;
@@ -1164,11 +1173,37 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
   const __amdgpu_buffer_rsrc_t Ib = st_rsrc(I, 4 * (size_t)np), Rb = st_rsrc(R, 20 * (size_t)np);
   auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
   auto src = [&](int row) { return bld1(Ib, voff, 4u * (unsigned)w * (unsigned)d_clamp(row, 0, h - 1)); };  // row: uniform
+  // U8: dword of gray bytes (lx .. lx + 3) of a row, and the weights that make b[x-1] + 2 b[x] + b[x+1] of it (reflected at the edges)
+  const __amdgpu_buffer_rsrc_t Gb = st_rsrc(U8 ? gray + (size_t)z * (size_t)np : nullptr, U8 ? (size_t)np : 0);
+  const unsigned lx = !U8 ? 0u : xc == 0 ? 0u : xc >= w - 2 ? (unsigned)(w - 4) : (unsigned)(xc - 1);
+  const unsigned wsel = xc == 0 ? 0x00000202u : xc == w - 1 ? 0x02020000u : xc == w - 2 ? 0x01020100u : 0x00010201u;
+  auto graw = [&](int grow) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(Gb, (int)lx, (int)((unsigned)w * (unsigned)grow), 0); };  // grow: uniform, in range
+  auto hsum = [&](unsigned d) { return __builtin_amdgcn_udot4(d, wsel, 0u, false); };
+  auto blur16 = [](unsigned a0, unsigned b0, unsigned c0) { return (float)(a0 + 2u * b0 + c0) * 0.0625f; };
+  unsigned hsB = 0, hsC = 0;  // U8: row sums of the newest ring row and of the row below it (reflected)
 
   // ring[j] = source row (y - N + j) of this column for the batch starting at row y
   float ring[2 * N + PE_RB];
+  if (!U8) {
 #pragma unroll
-  for (int j = 0; j < 2 * N + PE_RB; ++j) ring[j] = src(y0 - N + j);
+    for (int j = 0; j < 2 * N + PE_RB; ++j) ring[j] = src(y0 - N + j);
+  } else {
+    constexpr int NR = 2 * N + PE_RB;
+    const int r0 = d_clamp(y0 - N, 0, h - 1);
+    const unsigned rm = graw(d_reflect101(r0 - 1, h)), rc = graw(r0);
+    unsigned rn[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) rn[j] = graw(d_reflect101(d_clamp(y0 - N + j, 0, h - 1) + 1, h));
+    unsigned hsA = hsum(rm);
+    hsB = hsum(rc);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      hsC = hsum(rn[j]);
+      ring[j] = blur16(hsA, hsB, hsC);
+      // the window moves on when the next ring entry is another row (clamped rows repeat)
+      if (j + 1 < NR && d_clamp(y0 - N + j + 1, 0, h - 1) != d_clamp(y0 - N + j, 0, h - 1)) { hsA = hsB; hsB = hsC; }
+    }
+  }
 
   int buf = 0;
   for (int y = y0; y < y1; y += PE_RB) {
@@ -1190,12 +1225,29 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
     }
     // prefetch the next batch's new source rows while the exchange is in flight
     float nxt[PE_RB];
+    unsigned nraw[PE_RB];
 #pragma unroll
-    for (int r = 0; r < PE_RB; ++r) nxt[r] = src(y + PE_RB + N + r);
+    for (int r = 0; r < PE_RB; ++r) {
+      if (U8) nraw[r] = graw(d_reflect101(min(y + PE_RB + N + r, h - 1) + 1, h));
+      else nxt[r] = src(y + PE_RB + N + r);
+    }
     __syncthreads();
     // Consume the prefetched rows BEFORE this batch's stores are issued: vmcnt retires in order
     // and counts stores, so waiting for these loads after the stores would also wait for the
     // stores' acknowledgements (the stall that bounded the first version of this kernel).
+    if (U8) {
+      // rows beyond the frame repeat the last row's value (the float path clamps the row index)
+      float last = ring[2 * N + PE_RB - 1];
+#pragma unroll
+      for (int r = 0; r < PE_RB; ++r) {
+        if (y + PE_RB + N + r <= h - 1) {   // uniform
+          const unsigned hsA = hsB;
+          hsB = hsC; hsC = hsum(nraw[r]);
+          last = blur16(hsA, hsB, hsC);
+        }
+        nxt[r] = last;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2 * N; ++j) ring[j] = ring[j + PE_RB];
 #pragma unroll
@@ -1244,6 +1296,15 @@ __device__ __forceinline__ void polyexp_body(const A& a, const float* __restrict
 template <int N>
 __global__ __launch_bounds__(256) void k_polyexp(PolyArgs a) {
   polyexp_body<N>(a, a.img, a.R, a.h, a.w, a.rows_per_seg, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// level 0 straight from the gray frames (default pyramid: 3 x 3 blur, no resize)
+template <int N>
+#ifndef ST_PE_U8_WAVES
+#define ST_PE_U8_WAVES 1   // experiments: 6 = force the float-source instance's six waves per SIMD (80 registers, 9 spilled: 5.0 ms against 4.5)
+#endif
+__global__ __launch_bounds__(256, ST_PE_U8_WAVES) void k_polyexp_u8(PolyArgs a) {
+  polyexp_body<N, PolyArgs, true>(a, nullptr, a.R, a.h, a.w, a.rows_per_seg, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, a.gray);
 }
 
 // Several pyramid levels in ONE launch (small batches: the expansions of the coarse levels are launches of a few dozen
@@ -2993,8 +3054,9 @@ bool pyr_fused_ok(int h, int w, const st_fb_params& p) {
 // imgs[k]: n x (h>>k)*(w>>k) floats
 // gray != null: from the gray images; else from the RGB frames of the device table `frames` (4-byte
 // aligned), the luma conversion folded into the loads
+// skip0 (role-split instance only): level 0 is not produced -- the expansion reads the gray frame (launch_polyexp's gray)
 int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* frames, int n, int h, int w,
-                     const st_fb_params& p, float* const imgs[4]) {
+                     const st_fb_params& p, float* const imgs[4], bool skip0 = false) {
   PyrFusedArgs a;
   memset(&a, 0, sizeof(a));
   a.gray = gray; a.frames = frames;
@@ -3035,7 +3097,9 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
   // role-split instance (k_pyr_roles) unless ST_PYR_ROLES=0 (read at st_ctx_create): 257 frames 1.23 against 1.50 ms, two frames 25 against 43 us
   const int roles_env = ctx->pyr_roles;
   const bool roles = gray && roles_env != 0;
-  if (roles) hipLaunchKernelGGL(k_pyr_roles, dim3(strips, (h + rows - 1) / rows, n), dim3(768), 0, ctx->stream, a);
+  if (skip0 && !roles) return st_set_error(ctx, ST_ERR_INVALID, "pyr: level 0 can only be left out of the role-split kernel");
+  if (roles && skip0) hipLaunchKernelGGL(k_pyr_roles<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(768), 0, ctx->stream, a);
+  else if (roles) hipLaunchKernelGGL(k_pyr_roles<true>, dim3(strips, (h + rows - 1) / rows, n), dim3(768), 0, ctx->stream, a);
   else if (gray) hipLaunchKernelGGL(k_pyr_fused<false>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_pyr_fused<true>, dim3(strips, (h + rows - 1) / rows, n), dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
@@ -3047,16 +3111,21 @@ int launch_pyr_fused(st_ctx* ctx, const uint8_t* gray, const uint8_t* const* fra
 // above the resource's 20 np bytes
 static bool polyexp_frame_fits(int h, int w) { return (unsigned long long)h * (unsigned long long)w <= (1ull << 26); }
 
-int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R) {
+// gray != null: level 0 of the default pyramid straight from the gray frames (k_polyexp_u8; img is not read)
+int launch_polyexp(st_ctx* ctx, const float* img, int n, int h, int w, int poly_n, double poly_sigma, float* R,
+                   const uint8_t* gray = nullptr) {
   if (!polyexp_frame_fits(h, w)) return st_set_error(ctx, ST_ERR_UNSUPPORTED, "polyexp: frames above 64 M pixels are not supported");
   PolyArgs a;
-  a.img = img; a.R = R; a.h = h; a.w = w;
+  a.img = img; a.gray = gray; a.R = R; a.h = h; a.w = w;
   poly_prepare(poly_n, poly_sigma, &a.c);
   const int strips = (w + PE_OUT - 1) / PE_OUT;
   a.rows_per_seg = polyexp_rows(ctx, h, strips, n, poly_n);
   dim3 grid(strips, (h + a.rows_per_seg - 1) / a.rows_per_seg, n);
   st_timed t(ctx, ST_K_POLYEXP);
-  if (poly_n == 5) hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), 0, ctx->stream, a);
+  if (gray && w < 8) return st_set_error(ctx, ST_ERR_INVALID, "polyexp: the gray-source instance needs rows of at least 8 pixels");
+  if (gray && poly_n == 5) hipLaunchKernelGGL(k_polyexp_u8<5>, grid, dim3(256), 0, ctx->stream, a);
+  else if (gray) hipLaunchKernelGGL(k_polyexp_u8<7>, grid, dim3(256), 0, ctx->stream, a);
+  else if (poly_n == 5) hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_polyexp<7>, grid, dim3(256), 0, ctx->stream, a);
   ST_HIP(ctx, hipGetLastError());
   return ST_OK;
@@ -3344,15 +3413,19 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
     hipLaunchKernelGGL(k_set_tables, dim3(1), dim3(64), 0, ctx->stream, ta);
     ST_HIP(ctx, hipGetLastError());
   }
-  if (pyr1) ST_TRY(launch_pyr_fused(ctx, pyr_rgb ? nullptr : gray, d_frames, nf, h, w, p, imgs));
+  // Level 0 straight from the gray frames (ST_POLY_U8, read at st_ctx_create): the role-split pyramid leaves level 0 out and the
+  // level-0 expansion evaluates the 3 x 3 blur itself -- large calls only (the single multi-level launch keeps its float source)
+  static const int single_max = getenv("ST_POLY_SINGLE_MAX") ? atoi(getenv("ST_POLY_SINGLE_MAX")) : 16;
+  const bool single = pyr1 && levels >= 1 && levels <= 3 && npairs <= single_max;
+  const bool poly_u8 = pyr1 && !pyr_rgb && !single && ctx->poly_u8 && ctx->pyr_roles != 0 && geom[0].ksize == 3 && geom[0].sigma <= 0 &&
+                       geom[0].lh == h && geom[0].lw == w && w >= 8;
+  if (pyr1) ST_TRY(launch_pyr_fused(ctx, pyr_rgb ? nullptr : gray, d_frames, nf, h, w, p, imgs, poly_u8));
   // Small batches: the expansions of all levels in ONE launch (level 0 first, the coarse levels fill its tail).  Measured
   // against the former arrangement -- level 0 on a second, low-priority stream beside the coarse levels' iterations --
   // at 1 / 2 / 4 / 8 pairs of 1080p per call: 292 / 444 / 731 / 1193 us per step against 308 / 458 / 744 / 1197: the
   // event record and wait of the second stream cost a launch's worth each, and the coarse iterations it overlapped with ran
   // two to four times slower beside the level-0 expansion whatever the stream priority.  (ST_POLY_SINGLE_MAX: pairs up to
   // which the single launch is used.)
-  static const int single_max = getenv("ST_POLY_SINGLE_MAX") ? atoi(getenv("ST_POLY_SINGLE_MAX")) : 16;
-  const bool single = pyr1 && levels >= 1 && levels <= 3 && npairs <= single_max;
   if (single) {
     int ks[4], nk = 0;
     for (int k = 0; k <= levels; ++k) ks[nk++] = k;
@@ -3360,7 +3433,8 @@ int farneback_pass(st_ctx* ctx, const uint8_t* const* frames, int nf, const int3
   } else {
     for (int k = levels; k >= 0; --k) {
       if (!pyr1) ST_TRY(launch_pyr(ctx, gray, nf, h, w, geom[k], img));
-      ST_TRY(launch_polyexp(ctx, pyr1 ? imgs[k] : img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k]));
+      ST_TRY(launch_polyexp(ctx, pyr1 ? imgs[k] : img, nf, geom[k].lh, geom[k].lw, p.poly_n, p.poly_sigma, R[k],
+                            k == 0 && poly_u8 ? gray : nullptr));
     }
   }
   // per-pair stages, coarse to fine

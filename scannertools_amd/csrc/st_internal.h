@@ -29,6 +29,7 @@ struct st_ctx {
   // bit, so this is a scheduling switch only.
   int tile_mode = -1;
   long long tile_px = 600000;
+  bool poly_u8 = true;     // level-0 expansion straight from the gray frames (k_polyexp_u8), level 0 left out of the pyramid pass; ST_POLY_U8=0: float source
   bool fold_gray = false;  // ST_PYR_FOLD_GRAY=1: luma conversion inside the one-pass pyramid (slower; A/B switch)
   // role-split kernels (scheduling switches like tile_mode, read when the context is created; results do not depend on them):
   // ST_ITER_ROLES / ST_PYR_ROLES: -1 by launch size (default), 0 never, 1 always; ST_ROLES_NCW: 0 = by cost, 4 or 5 column waves

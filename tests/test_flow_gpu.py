@@ -358,6 +358,26 @@ def test_flow_1080p_batch_launch_geometry(mode_ctxs):
     assert torch.equal(mode_ctxs["default"].optical_flow(d[:4]), got[:3])
 
 
+@pytest.mark.parametrize("h,w,n", [(256, 256, 18), (264, 1032, 18), (328, 1024, 20), (1080, 1920, 19), (2160, 3840, 18)])
+def test_polyexp_from_gray_frames_bit_exact(mode_ctxs, h, w, n):
+    """Calls above 16 pairs on one-pass-pyramid geometries: the level-0 expansion reads the GRAY frames and evaluates the
+    3 x 3 blur itself (k_polyexp_u8; level 0 is left out of k_pyr_roles).  Every intermediate of that blur is exact in
+    float, so the flows must equal the float-source schedule's bit for bit: single strips, a strip of 8 columns, several
+    segments, 1080p, 4K; random bytes (every edge weight and reflected row matters) and a textured stream."""
+    g = torch.Generator(device="cuda").manual_seed(h + w)
+    noise = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    for d in (noise, _torch_stream(n, h, w, h)):
+        a = mode_ctxs["polyu8"].optical_flow(d)
+        b = mode_ctxs["polyf32"].optical_flow(d)
+        assert torch.equal(a, b)
+        del a, b
+    if h <= 1080:
+        fr = _torch_stream(n, h, w, h)
+        got = mode_ctxs["polyu8"].optical_flow(fr)[n // 2].cpu().numpy()
+        f = fr.cpu().numpy()
+        _check_flow(got, oracle.optical_flow_rgb(f[n // 2], f[n // 2 + 1]))
+
+
 @pytest.mark.parametrize("h,w", [(1, 1), (1, 40), (40, 1), (2, 2), (3, 5), (31, 33)])
 def test_flow_tiny_frames(hip_ctx, h, w):
     """Degenerate geometries (single level, clamps everywhere) still match the oracle."""
