@@ -113,3 +113,50 @@ def test_config5_network_at_368x656(hip_ctx, math):
     assert scale > 1e-3
     assert float((got - ref).abs().max()) <= 1e-3 * scale, (float((got - ref).abs().max()), scale)
     assert float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+# ---------------------------------------------------------------- the north star's stream (bench.py extra.stream_10k)
+def test_stream_shard_path_equals_direct_calls(hip_ctx):
+    """bench.py's run_shard -- what extra.stream_10k times: calls of B rows over a rank's shard through
+    sharding.flow_shard / local_pairs, Scanner's clamped last window, flow fields in a ring -- produces, for one rank and for
+    each of three ranks, exactly the rows a direct call on the whole stream produces: histograms of every frame, flow of
+    every (i, i+1) pair, the (n-1, n-1) field for the last row (its window is clamped); a sample against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from scannertools_amd.sharding import flow_shard
+    n, h, w, B, bins = 70, 264, 328, 16, 256
+    frames = bench.fill_stream(torch, torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda"), 5)
+    direct_flow = hip_ctx.optical_flow(frames)                       # n - 1 fields
+    direct_hist = hip_ctx.histogram(frames, bins)
+    assert len({bytes(direct_hist[i].cpu().numpy().tobytes()) for i in range(n)}) == n      # distinct frames
+
+    class KeepRing(list):
+        """a 'ring' that keeps every call's output (the bench overwrites; the test wants to look)"""
+        def __init__(self):
+            super().__init__()
+            self.out = []
+        def __len__(self):
+            return 1 << 30
+        def __getitem__(self, i):
+            t = torch.empty((B, h, w, 2), dtype=torch.float32, device="cuda")
+            self.out.append(t)
+            return t
+
+    for world in (1, 3):
+        for rank in range(world):
+            rows, fr = flow_shard(n, rank, world)
+            ring = KeepRing()
+            hists = torch.empty((rows[1] - rows[0], 3, bins), dtype=torch.int32, device="cuda")
+            calls = bench.run_shard(torch, hip_ctx, frames[fr[0]:fr[1]], rows, fr[0], n, B, bins, ring, hists)
+            assert calls == -(-(rows[1] - rows[0]) // B) and fr[1] - fr[0] <= rows[1] - rows[0] + 1
+            got = torch.cat([t[:min(B, rows[1] - rows[0] - B * i)] for i, t in enumerate(ring.out)])
+            assert torch.equal(hists, direct_hist[rows[0]:rows[1]])
+            last = min(rows[1], n - 1)
+            assert torch.equal(got[:last - rows[0]], direct_flow[rows[0]:last])
+            if rows[1] == n:                                        # clamped window: the pair (n-1, n-1)
+                assert torch.equal(got[-1], hip_ctx.optical_flow(frames[n - 1:], pairs=[(0, 0)])[0])
+                assert float(got[-1].abs().max()) < 0.05
+    f = frames.cpu().numpy()
+    _check_flow(direct_flow[33].cpu().numpy(), oracle.optical_flow_rgb(f[33], f[34]))
