@@ -181,6 +181,24 @@ def fill_stream(torch, frames, seed, chunk=250):
     return frames
 
 
+def native_build_record(_native):
+    """Which library this run loaded: the hash of the sources it was built from (st_build_info) beside the tree's, the machine
+    that compiled it and this machine -- the .so files are not shipped to the GPU box, so the two hosts are the same there."""
+    import socket
+    try:
+        info = _native.build_info()
+        rec = {"library_source_hash": info["src"], "tree_source_hash": _native.source_hash(), "compiled_on": info["host"],
+               "compiled_at": info["at"], "this_host": socket.gethostname(), "built_on_this_host": info["host"] == socket.gethostname()}
+        path = os.path.join(os.path.dirname(_native.LIB_PATH), "build_record.json")
+        if os.path.exists(path):
+            b = json.load(open(path))
+            if b.get("host") == info["host"]:
+                rec["build_seconds"] = b.get("seconds")
+        return rec
+    except Exception as e:  # a record, not a requirement
+        return {"error": repr(e)}
+
+
 def fb_geometry(h, w):
     from scannertools_amd.hip import fb_levels, fb_level_geom
     levels = fb_levels(h, w)
@@ -1083,6 +1101,7 @@ def run_rank(args):
             "frames_by_rank": rank_frames,
             "flow_whole_path_frac_of_peak": fps / world * flow_model_bytes / 1e9 / HBM_PEAK_GBS,
             "data": "synthetic",
+            "native_build": native_build_record(_native),
             "config": {
                 "workload": "Farneback OpticalFlow op (3,0.5,false,15,3,5,1.2,0), %dx%d pair stream, stencil {0,1}, "
                             "+ per-channel %d-bin Histogram op on the same frames" % (w, h, args.bins),

@@ -21,6 +21,28 @@ def pytest_sessionstart(session):
     g.ensure_built()
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line at the very end of the session's output: which native library the tests ran against -- the hash of the
+    sources it was built from, the machine that compiled it and how long that took (the GPU box compiles what it tests)."""
+    try:
+        import json
+        import socket
+        from scannertools_amd import _native
+        info = _native.build_info()
+        rec = {}
+        path = os.path.join(ROOT, "scannertools_amd", "lib", "build_record.json")
+        if os.path.exists(path):
+            rec = json.load(open(path))
+        here = socket.gethostname()
+        terminalreporter.write_line(
+            "native build: libscannertools_hip.so src=%s (tree %s) compiled on %s at %s%s; this host: %s -> %s" % (
+                info["src"], _native.source_hash(), info["host"], info["at"],
+                " in %.1f s (%s, %s cpus)" % (rec["seconds"], rec["jobs"], rec["cpus"]) if rec.get("host") == info["host"] else "",
+                here, "BUILT HERE" if info["host"] == here else "built elsewhere"))
+    except Exception as e:  # never let the report line fail a session
+        terminalreporter.write_line("native build: unknown (%r)" % (e,))
+
+
 @pytest.fixture(scope="session")
 def hip_ctx():
     """One HipContext for the GPU session.  Fails (not skips) if the native library is missing."""
