@@ -65,6 +65,12 @@ int st_ctx_destroy(st_ctx* ctx);
 int st_ctx_set_stream(st_ctx* ctx, void* hip_stream);
 int st_ctx_reset_stream(st_ctx* ctx);
 int st_ctx_sync(st_ctx* ctx);
+/* Diagnostic: 1 if the context's last st_farneback_pairs call chose its kernels for a GPU shared with other kernel instances of
+ * this process (two or more other contexts had an OpticalFlow call in flight -- entered within 50 ms and not yet st_ctx_sync'ed --
+ * and the call had at most 4 pairs), else 0.  Scanner runs K instances of a kernel class per GPU (pipeline_instances_per_node,
+ * scannertools/tests/test_all.py:45,231); the choice is a scheduling matter only, results are bit-identical.  ST_CONCURRENT=0 / 1
+ * (read at st_ctx_create) switches the detection off / forces it. */
+int st_ctx_flow_concurrent(st_ctx* ctx);
 /* Cap on scratch the context may hold (bytes; 0 = default 64 GiB).  Large pair batches are
  * processed in passes that fit. */
 int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "st_ctx_set_stream": (_i, [_vp, _vp]),
     "st_ctx_reset_stream": (_i, [_vp]),
     "st_ctx_sync": (_i, [_vp]),
+    "st_ctx_flow_concurrent": (_i, [_vp]),
     "st_ctx_set_workspace_limit": (_i, [_vp, _sz]),
     "st_ctx_release_workspace": (_i, [_vp]),
     "st_ctx_last_error": (_c.c_char_p, [_vp]),

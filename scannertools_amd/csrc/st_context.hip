@@ -1,5 +1,8 @@
 // Context, error reporting, scratch arena and per-kernel event timing for libscannertools_hip.so.
 #include <cstring>
+#include <vector>
+#include <mutex>
+#include <chrono>
 #include <cstdlib>
 
 #include "st_internal.h"
@@ -18,6 +21,39 @@ int st_enter(st_ctx* ctx) {
   if (!ctx) return ST_ERR_INVALID;
   ST_HIP(ctx, hipSetDevice(ctx->device));
   return ST_OK;
+}
+
+// ---- registry of live contexts (for the concurrency-aware kernel choice) --------------------------------------------------
+namespace {
+std::mutex g_reg_mu;
+std::vector<st_ctx*> g_reg;
+long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+void reg_add(st_ctx* c) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.push_back(c); }
+void reg_remove(st_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (size_t i = 0; i < g_reg.size(); ++i)
+    if (g_reg[i] == c) { g_reg.erase(g_reg.begin() + i); break; }
+}
+}  // namespace
+
+bool st_flow_call_begins(st_ctx* ctx) {
+  const long long t = now_ns();
+  ctx->flow_enter_ns.store(t, std::memory_order_relaxed);
+  ctx->flow_busy.store(true, std::memory_order_release);
+  if (ctx->concurrency_mode >= 0) return ctx->concurrency_mode != 0;
+  constexpr long long kWindowNs = 50LL * 1000 * 1000;   // a call that began longer ago and was never synchronised is stale
+  // TWO other instances in flight: with one, the two calls overlap on the GPU only part of the time (each instance spends a
+  // third of its cycle on the host between its synchronisation and its next call) and the lone-instance choice wins
+  // (2 instances x 2 pairs per call, a sync per call: 5 440 frames/s against 4 990 with the shared-chip choice)
+  int others = 0;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (st_ctx* o : g_reg)
+    if (o != ctx && o->device == ctx->device && o->flow_busy.load(std::memory_order_acquire) &&
+        t - o->flow_enter_ns.load(std::memory_order_relaxed) < kWindowNs)
+      ++others;
+  return others >= 2;
 }
 
 ST_EXPORT int st_abi_version(void) { return ST_ABI_VERSION; }
@@ -78,6 +114,7 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
   if (const char* e = getenv("ST_ROLES_ROWS")) c->roles_rows = atoi(e);
   if (const char* e = getenv("ST_PYR_ROLES")) c->pyr_roles = atoi(e);
   if (const char* e = getenv("ST_CONV_TILE")) c->conv_tile = atoi(e);
+  if (const char* e = getenv("ST_CONCURRENT")) c->concurrency_mode = atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
     c->num_cus = prop.multiProcessorCount;
@@ -91,12 +128,14 @@ ST_EXPORT int st_ctx_create(int device_id, st_ctx** out_ctx) {
       return ST_ERR_UNSUPPORTED;
     }
   }
+  reg_add(c);
   *out_ctx = c;
   return ST_OK;
 }
 
 ST_EXPORT int st_ctx_destroy(st_ctx* ctx) {
   if (!ctx) return ST_ERR_INVALID;
+  reg_remove(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& t : ctx->timing) {
@@ -126,8 +165,11 @@ ST_EXPORT int st_ctx_reset_stream(st_ctx* ctx) {
 ST_EXPORT int st_ctx_sync(st_ctx* ctx) {
   ST_TRY(st_enter(ctx));
   ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->flow_busy.store(false, std::memory_order_release);   // nothing of this context is in flight any more
   return ST_OK;
 }
+
+ST_EXPORT int st_ctx_flow_concurrent(st_ctx* ctx) { return ctx && ctx->flow_concurrent ? 1 : 0; }
 
 ST_EXPORT int st_ctx_set_workspace_limit(st_ctx* ctx, size_t bytes) {
   if (!ctx) return ST_ERR_INVALID;

@@ -3243,7 +3243,13 @@ int launch_flow_iter(st_ctx* ctx, IterArgs a, int n_pairs) {
   // cannot give k_flow_iter3 its two workgroups per unit: measured at 1080p (frames/s through both ops, k_flow_iter3 ->
   // roles): 1 pair per call 2 790 -> 3 100, 2: 3 690 -> 4 240, 4: 4 990 -> 5 200, 8: 6 190 -> 6 640, 16: 7 750 -> 7 690,
   // 32: 8 570 -> 8 360, 64: 9 150 -> 8 610.  ST_ITER_ROLES=1 always, 0 never (read at st_ctx_create).
-  const int roles_env = ctx->roles_mode, roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
+  // Another kernel instance of this process has a flow call in flight on this GPU (Scanner's pipeline_instances_per_node;
+  // st_flow_call_begins): the role kernel's one 12- or 15-wave workgroup per CU cannot share a unit with the other instance's
+  // launches (129 / 158 KB of LDS each), k_flow_iter3's 64 KB workgroups can.  Measured, K instances x 1 / 2 pairs per call at
+  // 1080p: K = 2: 4 210 -> 4 640 / 5 510 -> 5 740 frames/s, K = 4: 4 750 -> 5 180 / 5 770 -> 6 810, K = 8: 4 870 -> 5 310 /
+  // 5 910 -> 6 870 (a lone instance: 3 540 -> 3 290, which is why the choice depends on it); profiles/r6_instances_modes.txt.
+  const int roles_env = ctx->roles_mode == -1 && ctx->flow_concurrent ? 0 : ctx->roles_mode;
+  const int roles_ncw = ctx->roles_ncw, roles_rows = ctx->roles_rows;
   // (the first iteration of a level -- coarse-flow source, expansions not yet in any cache -- is where the role kernel's single
   // maker wave per SIMD is weakest: 8 pairs, level 0: 264 us against k_flow_iter3's 226, while its field-source launches
   // win 183 : 195; it takes those launches only when k_flow_iter3 would leave more than a third of its slots empty)
@@ -3542,6 +3548,7 @@ ST_EXPORT int st_farneback_pairs(st_ctx* ctx, const uint8_t* const* frames_dev, 
   ST_TRY(check_params(ctx, p, h, w));
   if (n_pairs == 0) return ST_OK;
   if (!frames_dev || !pairs || !flow_out_dev) return st_set_error(ctx, ST_ERR_INVALID, "farneback: null table");
+  ctx->flow_concurrent = st_flow_call_begins(ctx) && n_pairs <= 4;   // larger calls fill the chip by themselves
   for (int i = 0; i < n_pairs; ++i) {
     if (pairs[2 * i] < 0 || pairs[2 * i] >= n_frames || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= n_frames)
       return st_set_error(ctx, ST_ERR_INVALID, "farneback: pair %d indexes outside [0,%d)", i, n_frames);

@@ -84,6 +84,10 @@ class HipContext:
     def sync(self):
         self._check(self._L.st_ctx_sync(self._h))
 
+    def flow_concurrent(self):
+        """True if the last optical_flow call chose its kernels for a GPU shared with other kernel instances (diagnostic)."""
+        return bool(self._L.st_ctx_flow_concurrent(self._h))
+
     def release_workspace(self):
         self._check(self._L.st_ctx_release_workspace(self._h))
 

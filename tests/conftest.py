@@ -65,14 +65,16 @@ FLOW_MODES = {"default": {}, "march": {"ST_ITER_TILE": "0", "ST_ITER_ROLES": "0"
               # the luma conversion folded into the one-pass pyramid instead of the separate gray pass
               "foldgray": {"ST_PYR_FOLD_GRAY": "1"},
               # level-0 expansion straight from the gray frames, level 0 left out of the pyramid pass (calls above 16 pairs)
-              "polyu8": {"ST_POLY_U8": "1"}, "polyf32": {"ST_POLY_U8": "0"}}
+              "polyu8": {"ST_POLY_U8": "1"}, "polyf32": {"ST_POLY_U8": "0"},
+              # kernels chosen as for a GPU shared with other kernel instances (no role-split workgroups for small calls)
+              "concurrent": {"ST_CONCURRENT": "1"}}
 
 
 def make_mode_ctx(mode, **kw):
     """A HipContext created under the environment of one scheduling mode."""
     from scannertools_amd.hip import HipContext
     env = FLOW_MODES[mode]
-    keys = ("ST_ITER_TILE", "ST_PYR_FOLD_GRAY", "ST_ITER_ROLES", "ST_ROLES_NCW", "ST_ROLES_ROWS", "ST_PYR_ROLES", "ST_POLY_U8")
+    keys = ("ST_ITER_TILE", "ST_PYR_FOLD_GRAY", "ST_ITER_ROLES", "ST_ROLES_NCW", "ST_ROLES_ROWS", "ST_PYR_ROLES", "ST_POLY_U8", "ST_CONCURRENT")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:

@@ -180,3 +180,34 @@ def test_four_instances_of_the_op_library_kernel_classes():
             assert len(got[k][1]) == 6
             for a, b in zip(got[k][1], serial[k][1]):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_small_calls_notice_other_instances_and_results_do_not_change():
+    """Kernel choice under concurrency (st_ctx_flow_concurrent): a small OpticalFlow call that finds TWO other contexts of the
+    process with a call in flight picks kernels that share a CU (no role-split workgroups); alone, beside one other instance,
+    with more than 4 pairs, or once the others have synchronised it does not.  The flows are the same bits either way."""
+    h, w = 256, 320
+    frames = torch.from_numpy(texture_stream(41, 10, h, w)[0]).cuda()
+    a, b, c = HipContext(0), HipContext(0), HipContext(0)
+    try:
+        alone = c.optical_flow(frames[:3]).clone()
+        assert not c.flow_concurrent()
+        c.sync()
+        a.optical_flow(frames[2:5])                 # in flight, not synchronised
+        beside_one = c.optical_flow(frames[:3]).clone()
+        assert not c.flow_concurrent()
+        c.sync()
+        b.optical_flow(frames[4:7])                 # a second one in flight
+        shared = c.optical_flow(frames[:3]).clone()
+        assert c.flow_concurrent()
+        big = c.optical_flow(frames[:9])            # 8 pairs: fills the chip by itself
+        assert not c.flow_concurrent()
+        a.sync(); b.sync(); c.sync()
+        after = c.optical_flow(frames[:3]).clone()
+        assert not c.flow_concurrent()
+        c.sync()
+        assert torch.equal(alone, beside_one) and torch.equal(alone, shared) and torch.equal(alone, after)
+        assert torch.equal(big[:2], alone)
+    finally:
+        for x in (a, b, c):
+            x.close()
