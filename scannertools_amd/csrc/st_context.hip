@@ -25,16 +25,18 @@ int st_enter(st_ctx* ctx) {
 
 // ---- registry of live contexts (for the concurrency-aware kernel choice) --------------------------------------------------
 namespace {
-std::mutex g_reg_mu;
-std::vector<st_ctx*> g_reg;
+// never destroyed: a context released from a static destructor of the host program must still find the registry
+struct CtxRegistry { std::mutex mu; std::vector<st_ctx*> live; };
+CtxRegistry& registry() { static CtxRegistry* r = new CtxRegistry; return *r; }
 long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-void reg_add(st_ctx* c) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.push_back(c); }
+void reg_add(st_ctx* c) { CtxRegistry& r = registry(); std::lock_guard<std::mutex> lk(r.mu); r.live.push_back(c); }
 void reg_remove(st_ctx* c) {
-  std::lock_guard<std::mutex> lk(g_reg_mu);
-  for (size_t i = 0; i < g_reg.size(); ++i)
-    if (g_reg[i] == c) { g_reg.erase(g_reg.begin() + i); break; }
+  CtxRegistry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (size_t i = 0; i < r.live.size(); ++i)
+    if (r.live[i] == c) { r.live.erase(r.live.begin() + i); break; }
 }
 }  // namespace
 
@@ -48,8 +50,9 @@ bool st_flow_call_begins(st_ctx* ctx) {
   // third of its cycle on the host between its synchronisation and its next call) and the lone-instance choice wins
   // (2 instances x 2 pairs per call, a sync per call: 5 440 frames/s against 4 990 with the shared-chip choice)
   int others = 0;
-  std::lock_guard<std::mutex> lk(g_reg_mu);
-  for (st_ctx* o : g_reg)
+  CtxRegistry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (st_ctx* o : r.live)
     if (o != ctx && o->device == ctx->device && o->flow_busy.load(std::memory_order_acquire) &&
         t - o->flow_enter_ns.load(std::memory_order_relaxed) < kWindowNs)
       ++others;
@@ -151,6 +154,7 @@ ST_EXPORT int st_ctx_destroy(st_ctx* ctx) {
 ST_EXPORT int st_ctx_set_stream(st_ctx* ctx, void* hip_stream) {
   ST_TRY(st_enter(ctx));
   ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->flow_busy.store(false, std::memory_order_release);
   ctx->stream = (hipStream_t)hip_stream;
   return ST_OK;
 }
@@ -158,6 +162,7 @@ ST_EXPORT int st_ctx_set_stream(st_ctx* ctx, void* hip_stream) {
 ST_EXPORT int st_ctx_reset_stream(st_ctx* ctx) {
   ST_TRY(st_enter(ctx));
   ST_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->flow_busy.store(false, std::memory_order_release);
   ctx->stream = ctx->own_stream;
   return ST_OK;
 }

@@ -38,7 +38,7 @@ struct st_ctx {
   int conv_tile = -1;   // ST_CONV_TILE: 0 = bf16x3 convolutions always on the per-tap kernel (st_conv.hip)
   // Concurrent kernel instances (Scanner's pipeline_instances_per_node: K contexts of one process on one GPU, each call followed
   // by st_ctx_sync).  flow_busy: an OpticalFlow call of this context has been enqueued and not yet synchronised; flow_enter_ns:
-  // when (steady clock).  st_other_flow_active() reads them to pick kernels that share the chip (st_context.hip).
+  // when (steady clock).  st_flow_call_begins() reads the other contexts' to pick kernels that share the chip (st_context.hip).
   std::atomic<bool> flow_busy{false};
   std::atomic<long long> flow_enter_ns{0};
   bool flow_concurrent = false;   // decided at the entry of the current st_farneback_pairs call
@@ -74,9 +74,9 @@ int st_set_error(st_ctx* ctx, int status, const char* fmt, ...);
 // Enter an API call: null check + select device.
 int st_enter(st_ctx* ctx);
 
-// Marks `ctx` as having an OpticalFlow call in flight and says whether ANOTHER context of this process has one in flight on the
-// same device (entered within the last 50 ms and not synchronised since): then a small launch should not take a whole CU per
-// workgroup.  A scheduling decision only -- the kernels it chooses between agree bit for bit.
+// Marks `ctx` as having an OpticalFlow call in flight and says whether TWO OR MORE other contexts of this process have one in
+// flight on the same device (entered within the last 50 ms and not synchronised since): then a small launch should not take a
+// whole CU per workgroup.  A scheduling decision only -- the kernels it chooses between agree bit for bit.
 bool st_flow_call_begins(st_ctx* ctx);
 
 // Scratch: reset at the start of a call, then bump-allocate (256-B aligned).  Grows the
